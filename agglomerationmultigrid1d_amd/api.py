@@ -1,0 +1,554 @@
+"""Host-side mirror of the reference's operator interface for the V-cycle hot path.
+
+The reference is Julia (no FFI of its own; Julia is not available in the build image), so the
+host side above the C ABI is Python and mirrors the reference names, argument meaning, return
+shapes and error behaviour:
+
+    reference (Julia)                                   here
+    --------------------------------------------------  -------------------------------------
+    apply_smoother(S, B; alpha)    src/smoother.jl:6-81   apply_smoother(S, B, alpha=1.0)
+    dg_smoother(mesh, A, :blockJac|:jac)  :142-168        dg_smoother(mesh, A, 'blockJac'|'jac')
+    cg_smoother(mesh, A, :jac|:addSchwarz|:hybridSchwarz) cg_smoother(mesh, A, ...)
+                                   :88-139
+    struct MeshHierarchy           src/mesh_heirarchy.jl:17-28   class MeshHierarchy
+    multigrid_v_cycle(H,x0,b;nPre,nPost,alpha) src/solvers.jl:19-50  multigrid_v_cycle(...)
+    ldiv!(H,b) / ldiv!(y,H,b)      src/solvers.jl:63-92   ldiv(H, b) / ldiv(y, H, b)
+    multigrid(H,x0,b,maxiter,tol)  src/solvers.jl:116-139 multigrid(...)
+    iterative_smoother_solve(A,S,x0,b;maxiter,tol,alpha)  iterative_smoother_solve(...)
+                                   src/solvers.jl:189-213
+
+Julia Symbols become strings.  Every compute step goes through libaggmg_hip.so (include/
+aggmg_hip.h); nothing here computes the hot path on the CPU.  Mesh arguments only need the
+fields the reference reads on this path: `mElements[i].mNodesInd` (1-based) and `mP`, or a
+ready `mBlockInds` array (see uniform.py for the O(n) descriptors used at scale).
+"""
+import ctypes
+
+import numpy as np
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+from . import _lib
+from ._lib import (ArgumentError, DimensionMismatch, check)
+
+_PD = ctypes.POINTER(ctypes.c_double)
+_PI64 = ctypes.POINTER(ctypes.c_int64)
+
+
+def _f64(x):
+    return np.ascontiguousarray(x, dtype=np.float64)
+
+
+def _pd(a):
+    return a.ctypes.data_as(_PD)
+
+
+# --------------------------------------------------------------------------------------------
+# context
+# --------------------------------------------------------------------------------------------
+class Context:
+    """One HIP device + stream (aggmg_create).  Not thread-safe, like the reference."""
+
+    def __init__(self, device=0):
+        self.lib = _lib.load()
+        h = ctypes.c_void_p()
+        check(self.lib.aggmg_create(int(device), ctypes.byref(h)), None)
+        self.handle = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.aggmg_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def check(self, status):
+        check(status, self.handle)
+
+    def synchronize(self):
+        self.check(self.lib.aggmg_synchronize(self.handle))
+
+    def set_stream(self, hip_stream):
+        """Launch on a caller-provided hipStream_t (integer / pointer), e.g.
+        torch.cuda.current_stream().cuda_stream."""
+        self.check(self.lib.aggmg_set_stream(self.handle, ctypes.c_void_p(hip_stream or None)))
+
+    # raw device vectors (harness plumbing; torch tensors' data_ptr() work equally well)
+    def alloc(self, n):
+        return DeviceVector(self, n)
+
+    def to_device(self, x):
+        x = _f64(x)
+        v = DeviceVector(self, x.size)
+        v.upload(x)
+        return v
+
+    def profile_enable(self, on=True):
+        self.check(self.lib.aggmg_profile_enable(self.handle, 1 if on else 0))
+
+    def profile_collect(self):
+        """-> {(kind_name, level): (total_ms, count)} for every tag seen since the last call."""
+        ms = np.zeros(_lib.PROFILE_NTAGS)
+        cnt = np.zeros(_lib.PROFILE_NTAGS, dtype=np.int64)
+        self.check(self.lib.aggmg_profile_collect(self.handle, _pd(ms), cnt.ctypes.data_as(_PI64)))
+        out = {}
+        for tag in np.nonzero(cnt)[0]:
+            out[(_lib.KIND_NAMES[tag // 16], int(tag % 16))] = (float(ms[tag]), int(cnt[tag]))
+        return out
+
+
+_default_ctx = None
+
+
+def default_context():
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context(0)
+    return _default_ctx
+
+
+class DeviceVector:
+    """fp64 vector in HBM owned by a Context."""
+
+    def __init__(self, ctx, n):
+        self.ctx = ctx
+        self.n = int(n)
+        p = ctypes.c_void_p()
+        ctx.check(ctx.lib.aggmg_dev_alloc(ctx.handle, self.n * 8, ctypes.byref(p)))
+        self.ptr = p
+
+    def upload(self, x):
+        x = _f64(x)
+        if x.size != self.n:
+            raise DimensionMismatch("DeviceVector.upload: size mismatch")
+        self.ctx.check(self.ctx.lib.aggmg_memcpy_h2d(self.ctx.handle, self.ptr, x.ctypes.data, x.size * 8))
+
+    def download(self):
+        out = np.empty(self.n)
+        self.ctx.check(self.ctx.lib.aggmg_memcpy_d2h(self.ctx.handle, out.ctypes.data, self.ptr, self.n * 8))
+        return out
+
+    def free(self):
+        if self.ptr:
+            self.ctx.lib.aggmg_dev_free(self.ctx.handle, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            if self.ctx.handle:
+                self.free()
+        except Exception:
+            pass
+
+
+def _ptr(v):
+    """device pointer of a DeviceVector / torch tensor / int"""
+    if v is None:
+        return ctypes.c_void_p(None)
+    if isinstance(v, DeviceVector):
+        return v.ptr
+    if hasattr(v, "data_ptr"):
+        return ctypes.c_void_p(v.data_ptr())
+    return ctypes.c_void_p(int(v))
+
+
+# --------------------------------------------------------------------------------------------
+# operators
+# --------------------------------------------------------------------------------------------
+class DeviceOperator:
+    """Device mirror of one SparseMatrixCSC{Float64,Int64} (H.mStiffness[k] / H.mInterpolation[k],
+    src/mesh_heirarchy.jl:20,26).  `A` is a SciPy sparse matrix or the Julia triple
+    (m, n, colptr, rowval, nzval) with 1-based Int64 indices."""
+
+    def __init__(self, A, kind=_lib.OP_STIFFNESS, ctx=None):
+        self.ctx = ctx or default_context()
+        if isinstance(A, tuple):
+            m, n, colptr, rowval, nzval = A
+            one_based = 1
+        else:
+            if not sp.issparse(A):
+                raise ArgumentError("DeviceOperator: dense operators are not supported "
+                                    "(the hierarchy constructors only produce sparse transfers)")
+            A = sp.csc_matrix(A)
+            A.sort_indices()
+            m, n = A.shape
+            colptr, rowval, nzval = A.indptr, A.indices, A.data
+            one_based = 0
+        colptr = np.ascontiguousarray(colptr, dtype=np.int64)
+        rowval = np.ascontiguousarray(rowval, dtype=np.int64)
+        nzval = _f64(nzval)
+        h = ctypes.c_void_p()
+        self.ctx.check(self.ctx.lib.aggmg_csc_upload(
+            self.ctx.handle, int(m), int(n), colptr.ctypes.data_as(_PI64), rowval.ctypes.data_as(_PI64),
+            _pd(nzval), one_based, int(kind), ctypes.byref(h)))
+        self.handle = h
+        self.shape = (int(m), int(n))
+        self.nnz = int(nzval.size)
+        self.kind = kind
+
+    def download(self, transposed=False):
+        """Device index maps and values: (rowptr, colind, vals), 0-based int32 CSR of the matrix
+        (or of its transpose)."""
+        nrows = self.shape[1] if transposed else self.shape[0]
+        rp = np.empty(nrows + 1, dtype=np.int32)
+        ci = np.empty(self.nnz, dtype=np.int32)
+        v = np.empty(self.nnz)
+        self.ctx.check(self.ctx.lib.aggmg_op_download(
+            self.ctx.handle, self.handle, 1 if transposed else 0,
+            rp.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
+            ci.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), _pd(v)))
+        return rp, ci, v
+
+    def release_host(self):
+        self.ctx.check(self.ctx.lib.aggmg_op_release_host(self.ctx.handle, self.handle))
+
+    def free(self):
+        if getattr(self, "handle", None) and self.ctx.handle:
+            self.ctx.lib.aggmg_op_free(self.ctx.handle, self.handle)
+        self.handle = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def _as_op(A, kind=_lib.OP_STIFFNESS, ctx=None):
+    return A if isinstance(A, DeviceOperator) else DeviceOperator(A, kind, ctx)
+
+
+# --------------------------------------------------------------------------------------------
+# smoothers (src/smoother.jl)
+# --------------------------------------------------------------------------------------------
+class AbstractSmoother:
+    """abstract type AbstractSmoother (src/AgglomerationMultigrid1D.jl:16)"""
+    handle = None
+
+    def free(self):
+        if getattr(self, "handle", None) and self.A.ctx.handle:
+            self.A.ctx.lib.aggmg_smoother_free(self.A.ctx.handle, self.handle)
+        self.handle = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    @property
+    def structured(self):
+        out = ctypes.c_int(0)
+        c = self.A.ctx
+        c.check(c.lib.aggmg_smoother_is_structured(c.handle, self.handle, ctypes.byref(out)))
+        return bool(out.value)
+
+
+class JacobiSmoother(AbstractSmoother):
+    """JacobiSmoother{mJac::Diagonal} src/smoother.jl:52-58"""
+
+    def __init__(self, A, ctx=None):
+        self.A = _as_op(A, ctx=ctx)
+        h = ctypes.c_void_p()
+        c = self.A.ctx
+        c.check(c.lib.aggmg_jacobi_setup(c.handle, self.A.handle, ctypes.byref(h)))
+        self.handle = h
+
+
+class _BlockSmoother(AbstractSmoother):
+    _kind = 0
+
+    def __init__(self, A, mBlockInds, ctx=None):
+        """mBlockInds: Matrix{Int64}(m x nb), 1-based, column i = index list of block i
+        (src/smoother.jl:13,76)."""
+        self.A = _as_op(A, ctx=ctx)
+        inds = np.asarray(mBlockInds, dtype=np.int64)
+        if inds.ndim != 2:
+            raise ArgumentError("mBlockInds must be an (m x nb) matrix")
+        self.mBlockInds = inds
+        m, nb = inds.shape
+        flat = np.ascontiguousarray(inds.T)  # column-major m x nb == C-order nb x m
+        h = ctypes.c_void_p()
+        c = self.A.ctx
+        c.check(c.lib.aggmg_blockjacobi_setup(c.handle, self.A.handle, m, nb,
+                                              flat.ctypes.data_as(_PI64), 1, self._kind,
+                                              ctypes.byref(h)))
+        self.handle = h
+
+
+class BlockJacobi(_BlockSmoother):
+    """BlockJacobi{mBlocks::Vector{LU}, mBlockInds} src/smoother.jl:64-81.  Blocks are
+    re-extracted from A on set-up (identical mathematics to src/smoother.jl:159-162)."""
+
+
+class AdditiveSchwarzSmoother(_BlockSmoother):
+    """src/smoother.jl:1-18 (same apply loop as BlockJacobi, overlapping blocks)"""
+
+
+class HybridSchwarzSmoother(_BlockSmoother):
+    """src/smoother.jl:24-46"""
+    _kind = 1
+
+
+def _mesh_block_inds(mesh):
+    if hasattr(mesh, "mBlockInds"):
+        return np.asarray(mesh.mBlockInds, dtype=np.int64)
+    n = len(mesh.mElements)
+    inds = np.zeros((mesh.mP + 1, n), dtype=np.int64)
+    for i, el in enumerate(mesh.mElements):
+        inds[:, i] = el.mNodesInd
+    return inds
+
+
+def dg_smoother(dgMesh, A, smootherType, ctx=None):
+    """dg_smoother(mesh, A, :jac | :blockJac) src/smoother.jl:142-168"""
+    if smootherType == 'jac':
+        return JacobiSmoother(A, ctx)
+    if smootherType == 'blockJac':
+        return BlockJacobi(A, _mesh_block_inds(dgMesh), ctx)
+    raise ArgumentError(f"dg_smoother: unknown smoother type {smootherType!r}")
+
+
+def cg_smoother(cgMesh, A, smootherType, ctx=None):
+    """cg_smoother(mesh, A, :jac | :addSchwarz | :hybridSchwarz) src/smoother.jl:88-139"""
+    if smootherType == 'jac':
+        return JacobiSmoother(A, ctx)
+    if smootherType == 'addSchwarz':
+        return AdditiveSchwarzSmoother(A, _mesh_block_inds(cgMesh), ctx)
+    if smootherType == 'hybridSchwarz':
+        return HybridSchwarzSmoother(A, _mesh_block_inds(cgMesh), ctx)
+    raise ArgumentError(f"cg_smoother: unknown smoother type {smootherType!r}")
+
+
+def apply_smoother(S, B, alpha=1.0):
+    """apply_smoother(A::AbstractSmoother, B::AbstractVecOrMat; alpha=1.0) -> new array
+    (src/smoother.jl:6,30,56,69).  B is not modified."""
+    B = np.asarray(B, dtype=np.float64)
+    if B.ndim not in (1, 2):
+        raise DimensionMismatch("apply_smoother: B must be a vector or a matrix")
+    N = B.shape[0]
+    ncols = 1 if B.ndim == 1 else B.shape[1]
+    Bf = np.asfortranarray(B.reshape(N, ncols))
+    Y = np.empty((N, ncols), order='F')
+    c = S.A.ctx
+    c.check(c.lib.aggmg_smoother_apply(c.handle, S.handle, Bf.ctypes.data_as(_PD), N, ncols,
+                                       float(alpha), Y.ctypes.data_as(_PD)))
+    return Y[:, 0].copy() if B.ndim == 1 else np.ascontiguousarray(Y)
+
+
+# --------------------------------------------------------------------------------------------
+# hierarchy (src/mesh_heirarchy.jl) and solvers (src/solvers.jl)
+# --------------------------------------------------------------------------------------------
+def _smoother_from_reference(S, A_op):
+    """Accept the reference's smoother objects (anything with `mJac`, or `mBlockInds` [+
+    `mCountingMatrix`]) as well as this module's; blocks are re-extracted from A on device."""
+    if isinstance(S, AbstractSmoother):
+        return S
+    if hasattr(S, "mCountingMatrix"):
+        return HybridSchwarzSmoother(A_op, S.mBlockInds)
+    if hasattr(S, "mBlockInds"):
+        return BlockJacobi(A_op, S.mBlockInds)
+    if hasattr(S, "mJac"):
+        return JacobiSmoother(A_op)
+    raise ArgumentError("unrecognised smoother object")
+
+
+class MeshHierarchy:
+    """struct MeshHierarchy (src/mesh_heirarchy.jl:17-28) with device mirrors of the operator
+    vectors.  Fields keep the reference's names; level 1 (index 0) is the finest.
+
+    MeshHierarchy(mMeshes, mStiffness, mSmoothers, mInterpolation, mBdConds=None, ...) is the
+    struct's positional constructor (the reference's two outer constructors do Galerkin set-up,
+    which is outside the hot path: SURVEY.md 8 a12/a13); `from_reference(H)` wraps any object
+    carrying the reference's fields (e.g. the set-up output of a Julia-side or oracle-side
+    constructor)."""
+
+    def __init__(self, mMeshes, mStiffness, mSmoothers, mInterpolation, mBdConds=None,
+                 mGradient=None, mDivergence=None, mC=None, ctx=None, keep_host=True):
+        n = len(mStiffness)
+        if n < 1:
+            raise ArgumentError("At least one mesh required.")
+        if mMeshes is not None and len(mMeshes) != n:
+            raise ArgumentError("Length of vector of meshes does not match the operators.")
+        if len(mInterpolation) != n - 1 or len(mSmoothers) < n - 1:
+            raise ArgumentError("Need one interpolation and one smoother per non-coarsest level.")
+        self.ctx = ctx or default_context()
+        self.mMeshes = mMeshes
+        self.mStiffness = list(mStiffness)
+        self.mInterpolation = list(mInterpolation)
+        self.mBdConds = mBdConds
+        self.mGradient, self.mDivergence, self.mC = mGradient, mDivergence, mC
+        self._ops = [_as_op(A, _lib.OP_STIFFNESS, self.ctx) for A in mStiffness]
+        self._Ls = [_as_op(L, _lib.OP_TRANSFER, self.ctx) for L in mInterpolation]
+        self.mSmoothers = [_smoother_from_reference(mSmoothers[k], self._ops[k]) for k in range(n - 1)]
+        arr = ctypes.c_void_p * n
+        ops = arr(*[o.handle for o in self._ops])
+        sms = arr(*([s.handle for s in self.mSmoothers] + [None]))
+        Ls = arr(*([l.handle for l in self._Ls] + [None]))
+        h = ctypes.c_void_p()
+        self.ctx.check(self.ctx.lib.aggmg_hier_create(self.ctx.handle, n, ops, sms, Ls, 0, ctypes.byref(h)))
+        self.handle = h
+        if not keep_host:
+            for o in self._ops + self._Ls:
+                o.release_host()
+
+    @classmethod
+    def from_reference(cls, H, ctx=None):
+        return cls(H.mMeshes, H.mStiffness, H.mSmoothers, H.mInterpolation,
+                   getattr(H, "mBdConds", None), getattr(H, "mGradient", None),
+                   getattr(H, "mDivergence", None), getattr(H, "mC", None), ctx=ctx)
+
+    @property
+    def nlevels(self):
+        return len(self._ops)
+
+    def structured_levels(self):
+        return [s.structured for s in self.mSmoothers]
+
+    def vcycle_dev(self, x0, b, x_out, nPre=3, nPost=3, alpha=2.0 / 3.0):
+        """Device-resident V-cycle: x0, b, x_out are DeviceVector / torch tensors / raw pointers;
+        asynchronous on the context stream."""
+        c = self.ctx
+        c.check(c.lib.aggmg_vcycle_dev(c.handle, self.handle, _ptr(x0), _ptr(b), int(nPre), int(nPost),
+                                       float(alpha), _ptr(x_out)))
+
+    def last_coarse_ms(self):
+        ms = ctypes.c_double(0.0)
+        self.ctx.check(self.ctx.lib.aggmg_hier_last_coarse_ms(self.ctx.handle, self.handle, ctypes.byref(ms)))
+        return ms.value
+
+    def free(self):
+        if getattr(self, "handle", None) and self.ctx.handle:
+            self.ctx.lib.aggmg_hier_free(self.ctx.handle, self.handle)
+        self.handle = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def multigrid_v_cycle(H, x0, b, nPre=3, nPost=3, alpha=2.0 / 3.0):
+    """multigrid_v_cycle(H, x0, b; nPre=3, nPost=3, alpha=2/3) -> x   (src/solvers.jl:19-50).
+    Returns a new vector; x0 and b are not modified."""
+    if not isinstance(nPre, (int, np.integer)) or not isinstance(nPost, (int, np.integer)):
+        raise TypeError("nPre / nPost must be integers (nPre::Integer, src/solvers.jl:20)")
+    x0 = _f64(x0)
+    b = _f64(b)
+    N = H._ops[0].shape[0]
+    if x0.shape != (N,) or b.shape != (N,):
+        raise DimensionMismatch("multigrid_v_cycle: x0 / b do not match the fine operator")
+    out = np.empty(N)
+    c = H.ctx
+    c.check(c.lib.aggmg_vcycle(c.handle, H.handle, _pd(x0), _pd(b), int(nPre), int(nPost), float(alpha),
+                               _pd(out)))
+    return out
+
+
+def ldiv(*args):
+    """ldiv!(H, b) -- overwrites b (src/solvers.jl:63-71);  ldiv!(y, H, b) (src/solvers.jl:84-92).
+    One V-cycle from a zero initial guess."""
+    if len(args) == 2:
+        H, b = args
+        y = b
+    elif len(args) == 3:
+        y, H, b = args
+    else:
+        raise TypeError("ldiv(H, b) or ldiv(y, H, b)")
+    u0 = np.zeros(H._ops[0].shape[0])
+    y[:] = multigrid_v_cycle(H, u0, b)
+    return None
+
+
+def _device_residual_norm(H_or_op, x, b):
+    op = H_or_op
+    r = np.empty(op.shape[0])
+    c = op.ctx
+    c.check(c.lib.aggmg_residual(c.handle, op.handle, _pd(_f64(x)), _pd(_f64(b)), _pd(r)))
+    return np.linalg.norm(r, 2)
+
+
+def multigrid(H, x0, b, maxiter, tol, exact=True):
+    """multigrid(H, x0, b, maxiter, tol) -> (x, iter, res, err)  (src/solvers.jl:116-139).
+    The reference solves the fine system directly for the error history (:120); pass
+    exact=False to skip that at sizes where a fine-level direct solve is not wanted (err is
+    then empty)."""
+    x0 = _f64(x0)
+    b = _f64(b)
+    x = np.zeros(len(x0))
+    u_exact = spla.spsolve(sp.csc_matrix(H.mStiffness[0]), b) if exact else None
+    err, res = [], []
+    nb = np.linalg.norm(b, 2)
+    for i in range(int(maxiter)):
+        x = multigrid_v_cycle(H, x0, b)
+        x0 = x
+        if exact:
+            err.append(np.linalg.norm(x - u_exact, 2))
+        res.append(_device_residual_norm(H._ops[0], x, b))
+        if res[i] < tol * nb:
+            break
+    return x, len(res), res, err
+
+
+def iterative_smoother_solve(A, smoother, x0, b, maxiter=1000, tol=1e-6, alpha=1.0, exact=True):
+    """iterative_smoother_solve(A, smoother, x0, b; maxiter=1000, tol=1e-6, alpha=1.0)
+    -> (x, iter, res, err)  (src/solvers.jl:189-213).  Each iteration is one fused device sweep
+    x = x0 + apply_smoother(S, b - A*x0; alpha)."""
+    op = smoother.A if not isinstance(A, DeviceOperator) else A
+    x0 = _f64(x0).copy()
+    b = _f64(b)
+    uExact = spla.spsolve(sp.csc_matrix(A), b) if (exact and not isinstance(A, DeviceOperator)) else None
+    err, res = [], []
+    nb = np.linalg.norm(b, 2)
+    c = op.ctx
+    x = np.zeros(len(x0))
+    for i in range(int(maxiter)):
+        x = x0.copy()
+        c.check(c.lib.aggmg_smooth(c.handle, op.handle, smoother.handle, _pd(x), _pd(b), float(alpha), 1))
+        x0 = x
+        if uExact is not None:
+            err.append(np.linalg.norm(x - uExact, 2))
+        res.append(_device_residual_norm(op, x, b))
+        if res[i] < tol * nb:
+            break
+    return x, len(res), res, err
+
+
+# stand-alone fused operations on host arrays (C ABI `aggmg_smooth`, `aggmg_residual`, ...)
+def smooth(A_op, S, u, b, alpha=2.0 / 3.0, nsweeps=1):
+    """nsweeps x `u += apply_smoother(S, b - A*u; alpha)` (src/solvers.jl:32-35) -> new vector"""
+    u = _f64(u).copy()
+    b = _f64(b)
+    c = A_op.ctx
+    c.check(c.lib.aggmg_smooth(c.handle, A_op.handle, S.handle, _pd(u), _pd(b), float(alpha), int(nsweeps)))
+    return u
+
+
+def residual(A_op, u, b):
+    """b - A*u (src/solvers.jl:33)"""
+    r = np.empty(A_op.shape[0])
+    c = A_op.ctx
+    c.check(c.lib.aggmg_residual(c.handle, A_op.handle, _pd(_f64(u)), _pd(_f64(b)), _pd(r)))
+    return r
+
+
+def restrict(L_op, r):
+    """L' * r (src/solvers.jl:36)"""
+    rc = np.empty(L_op.shape[1])
+    c = L_op.ctx
+    c.check(c.lib.aggmg_restrict(c.handle, L_op.handle, _pd(_f64(r)), _pd(rc)))
+    return rc
+
+
+def prolong_add(L_op, uc, u):
+    """u + L * uc (src/solvers.jl:42) -> new vector"""
+    u = _f64(u).copy()
+    c = L_op.ctx
+    c.check(c.lib.aggmg_prolong_add(c.handle, L_op.handle, _pd(_f64(uc)), _pd(u)))
+    return u

@@ -1,0 +1,1410 @@
+// libaggmg_hip.so -- host side of the C ABI declared in include/aggmg_hip.h.
+//
+// What lives here: format conversion on upload (Julia CSC Int64 -> device CSR int32, plus the
+// index-free block-tridiagonal form when the pattern allows it), smoother set-up (block
+// extraction + partial-pivot LU inverse), launch logic for the kernels in kernels.hpp, the
+// on-device V-cycle driver and the HIP-event profiler.  No CPU compute fallback exists: every
+// hot-path entry point launches HIP kernels or fails.
+#include "../../include/aggmg_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "kernels.hpp"
+
+using namespace aggmg;
+
+// ---------------------------------------------------------------------------------------------
+// objects behind the opaque handles
+// ---------------------------------------------------------------------------------------------
+static thread_local std::string g_create_error;
+
+struct ProfEvent {
+  hipEvent_t a, b;
+  int tag;
+};
+
+struct aggmg_ctx {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  std::string err;
+  bool profiling = false;
+  std::vector<ProfEvent> prof;
+  std::vector<hipEvent_t> ev_pool;
+  // scratch vectors for ping-pong / temporaries, grown on demand
+  double* scratch[3] = {nullptr, nullptr, nullptr};
+  int64_t scratch_len[3] = {0, 0, 0};
+};
+
+struct CsrDev {
+  int64_t nrows = 0, ncols = 0, nnz = 0;
+  int32_t* rowptr = nullptr;
+  int32_t* colind = nullptr;
+  double* vals = nullptr;
+  int lpr = 1;
+  CsrView view() const { return CsrView{rowptr, colind, vals, nrows}; }
+};
+
+struct HostCsr {
+  std::vector<int32_t> rowptr, colind;
+  std::vector<double> vals;
+};
+
+struct aggmg_op {
+  int64_t m = 0, n = 0, nnz = 0;
+  int kind = AGGMG_OP_STIFFNESS;
+  CsrDev csr;   // row-gather form of the matrix
+  CsrDev csrT;  // row-gather form of its transpose (transfers only)
+  HostCsr host; // host CSR kept for smoother / structure set-up until released
+  bool host_valid = false;
+};
+
+struct BtdDev {
+  int m = 0;
+  int64_t ne = 0;
+  bool cmp = false;
+  int c_sub = 0, r_sup = 0;
+  double *binv = nullptr, *dblk = nullptr, *scol = nullptr, *pcol = nullptr, *qrow = nullptr;
+  double *sub = nullptr, *sup = nullptr, *P = nullptr, *Q = nullptr;
+};
+
+struct aggmg_smoother {
+  int kind = 0;  // 0 point Jacobi, 1 block (Jacobi / additive Schwarz), 2 hybrid Schwarz
+  aggmg_op* A = nullptr;
+  int64_t N = 0, m = 0, nb = 0;
+  double* diag = nullptr;      // point Jacobi
+  double* binv = nullptr;      // [nb][m][m] row-major
+  int32_t* inds = nullptr;     // [nb][m]
+  double* counts = nullptr;    // hybrid Schwarz
+  bool overlapping = false;
+  bool contiguous = false;
+  std::unique_ptr<BtdDev> btd;  // structured fused form, or null
+};
+
+struct TransferBtd {
+  int mc = 0, rho = 0;
+  double* lf = nullptr;  // [N_f][mc]
+};
+
+struct Level {
+  aggmg_op* A = nullptr;
+  aggmg_smoother* S = nullptr;
+  aggmg_op* L = nullptr;  // level k+1 -> k
+  int64_t N = 0;
+  double *u[2] = {nullptr, nullptr}, *rhs = nullptr, *tmp = nullptr;
+  std::unique_ptr<TransferBtd> tb;  // structured transfer to level k+1, or null
+};
+
+struct BandedLU {
+  int64_t n = 0;
+  int kl = 0, ku = 0, ldab = 0;
+  std::vector<double> ab;
+  std::vector<int32_t> ipiv;
+};
+
+struct aggmg_hier {
+  std::vector<Level> lv;
+  int coarse_mode = 0;
+  BandedLU coarse;
+  std::vector<double> h_coarse;
+  double last_coarse_ms = 0.0;
+};
+
+// ---------------------------------------------------------------------------------------------
+// error helpers
+// ---------------------------------------------------------------------------------------------
+static int fail(aggmg_ctx* ctx, int code, const std::string& msg) {
+  if (ctx)
+    ctx->err = msg;
+  else
+    g_create_error = msg;
+  return code;
+}
+
+#define HIPCHK(expr)                                                                        \
+  do {                                                                                      \
+    hipError_t _e = (expr);                                                                 \
+    if (_e != hipSuccess)                                                                   \
+      return fail(ctx, AGGMG_ERR_HIP,                                                       \
+                  std::string(#expr) + ": " + hipGetErrorString(_e) + " (" + __FILE__ + ":" + \
+                      std::to_string(__LINE__) + ")");                                      \
+  } while (0)
+
+#define CHECK(expr)             \
+  do {                          \
+    int _s = (expr);            \
+    if (_s != AGGMG_OK) return _s; \
+  } while (0)
+
+template <typename T>
+static int dev_upload(aggmg_ctx* ctx, const std::vector<T>& h, T** d) {
+  *d = nullptr;
+  size_t bytes = std::max<size_t>(h.size(), 1) * sizeof(T);
+  HIPCHK(hipMalloc((void**)d, bytes));
+  if (!h.empty())
+    HIPCHK(hipMemcpyAsync(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return AGGMG_OK;
+}
+
+static int scratch(aggmg_ctx* ctx, int slot, int64_t len, double** out) {
+  if (ctx->scratch_len[slot] < len) {
+    if (ctx->scratch[slot]) {
+      HIPCHK(hipStreamSynchronize(ctx->stream));
+      HIPCHK(hipFree(ctx->scratch[slot]));
+    }
+    ctx->scratch[slot] = nullptr;
+    ctx->scratch_len[slot] = 0;
+    HIPCHK(hipMalloc((void**)&ctx->scratch[slot], (size_t)std::max<int64_t>(len, 1) * sizeof(double)));
+    ctx->scratch_len[slot] = len;
+  }
+  *out = ctx->scratch[slot];
+  return AGGMG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// profiler (HIP events on the launch stream)
+// ---------------------------------------------------------------------------------------------
+struct ProfScope {
+  aggmg_ctx* ctx;
+  int idx = -1;
+  ProfScope(aggmg_ctx* c, int kind, int level) : ctx(c) {
+    if (!ctx->profiling) return;
+    ProfEvent pe;
+    for (hipEvent_t* e : {&pe.a, &pe.b}) {
+      if (!ctx->ev_pool.empty()) {
+        *e = ctx->ev_pool.back();
+        ctx->ev_pool.pop_back();
+      } else if (hipEventCreate(e) != hipSuccess) {
+        return;
+      }
+    }
+    pe.tag = kind * 16 + (level & 15);
+    (void)hipEventRecord(pe.a, ctx->stream);
+    ctx->prof.push_back(pe);
+    idx = (int)ctx->prof.size() - 1;
+  }
+  ~ProfScope() {
+    if (idx >= 0) (void)hipEventRecord(ctx->prof[idx].b, ctx->stream);
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------------------------
+extern "C" const char* aggmg_version(void) { return "aggmg_hip 0.1 gfx950 fp64"; }
+
+extern "C" int aggmg_create(int device_id, aggmg_ctx** out) {
+  if (!out) return fail(nullptr, AGGMG_ERR_ARGUMENT, "aggmg_create: out is NULL");
+  *out = nullptr;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0)
+    return fail(nullptr, AGGMG_ERR_HIP,
+                std::string("aggmg_create: no HIP device available (") + hipGetErrorString(e) + ")");
+  if (device_id < 0 || device_id >= ndev)
+    return fail(nullptr, AGGMG_ERR_ARGUMENT, "aggmg_create: device_id out of range");
+  e = hipSetDevice(device_id);
+  if (e != hipSuccess) return fail(nullptr, AGGMG_ERR_HIP, hipGetErrorString(e));
+  aggmg_ctx* ctx = new aggmg_ctx();
+  ctx->device = device_id;
+  e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
+  if (e != hipSuccess) {
+    delete ctx;
+    return fail(nullptr, AGGMG_ERR_HIP, hipGetErrorString(e));
+  }
+  ctx->stream = ctx->own_stream;
+  *out = ctx;
+  return AGGMG_OK;
+}
+
+extern "C" int aggmg_destroy(aggmg_ctx* ctx) {
+  if (!ctx) return AGGMG_OK;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  for (auto& pe : ctx->prof) {
+    (void)hipEventDestroy(pe.a);
+    (void)hipEventDestroy(pe.b);
+  }
+  for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
+  for (int s = 0; s < 3; ++s)
+    if (ctx->scratch[s]) (void)hipFree(ctx->scratch[s]);
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+  delete ctx;
+  return AGGMG_OK;
+}
+
+extern "C" const char* aggmg_last_error(aggmg_ctx* ctx) {
+  return ctx ? ctx->err.c_str() : g_create_error.c_str();
+}
+
+extern "C" int aggmg_set_stream(aggmg_ctx* ctx, void* hip_stream) {
+  if (!ctx) return AGGMG_ERR_ARGUMENT;
+  ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+  return AGGMG_OK;
+}
+
+extern "C" int aggmg_synchronize(aggmg_ctx* ctx) {
+  if (!ctx) return AGGMG_ERR_ARGUMENT;
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return AGGMG_OK;
+}
+
+extern "C" int aggmg_dev_alloc(aggmg_ctx* ctx, int64_t nbytes, void** out) {
+  if (!ctx || !out || nbytes < 0) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_dev_alloc: bad argument");
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipMalloc(out, (size_t)std::max<int64_t>(nbytes, 8)));
+  return AGGMG_OK;
+}
+
+extern "C" int aggmg_dev_free(aggmg_ctx* ctx, void* ptr) {
+  if (!ctx) return AGGMG_ERR_ARGUMENT;
+  if (ptr) {
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipFree(ptr));
+  }
+  return AGGMG_OK;
+}
+
+extern "C" int aggmg_memcpy_h2d(aggmg_ctx* ctx, void* dst, const void* src, int64_t nbytes) {
+  if (!ctx) return AGGMG_ERR_ARGUMENT;
+  HIPCHK(hipMemcpyAsync(dst, src, (size_t)nbytes, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return AGGMG_OK;
+}
+
+extern "C" int aggmg_memcpy_d2h(aggmg_ctx* ctx, void* dst, const void* src, int64_t nbytes) {
+  if (!ctx) return AGGMG_ERR_ARGUMENT;
+  HIPCHK(hipMemcpyAsync(dst, src, (size_t)nbytes, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return AGGMG_OK;
+}
+
+extern "C" int aggmg_profile_enable(aggmg_ctx* ctx, int on) {
+  if (!ctx) return AGGMG_ERR_ARGUMENT;
+  ctx->profiling = on != 0;
+  return AGGMG_OK;
+}
+
+extern "C" int aggmg_profile_collect(aggmg_ctx* ctx, double* total_ms, int64_t* counts) {
+  if (!ctx || !total_ms || !counts) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_profile_collect: NULL");
+  for (int t = 0; t < AGGMG_PROFILE_NTAGS; ++t) {
+    total_ms[t] = 0.0;
+    counts[t] = 0;
+  }
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  for (auto& pe : ctx->prof) {
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, pe.a, pe.b));
+    total_ms[pe.tag] += ms;
+    counts[pe.tag] += 1;
+    ctx->ev_pool.push_back(pe.a);
+    ctx->ev_pool.push_back(pe.b);
+  }
+  ctx->prof.clear();
+  return AGGMG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// operators
+// ---------------------------------------------------------------------------------------------
+static int pick_lpr(int64_t nnz, int64_t nrows) {
+  double avg = nrows > 0 ? (double)nnz / (double)nrows : 1.0;
+  int lpr = 1;
+  while (lpr < 64 && (double)lpr * 1.5 < avg) lpr *= 2;
+  return lpr;
+}
+
+static int upload_csr(aggmg_ctx* ctx, int64_t nrows, int64_t ncols, const std::vector<int32_t>& rowptr,
+                      const std::vector<int32_t>& colind, const std::vector<double>& vals, CsrDev* d) {
+  d->nrows = nrows;
+  d->ncols = ncols;
+  d->nnz = (int64_t)colind.size();
+  d->lpr = pick_lpr(d->nnz, nrows);
+  CHECK(dev_upload(ctx, rowptr, &d->rowptr));
+  CHECK(dev_upload(ctx, colind, &d->colind));
+  CHECK(dev_upload(ctx, vals, &d->vals));
+  return AGGMG_OK;
+}
+
+static void free_csr(CsrDev* d) {
+  if (d->rowptr) (void)hipFree(d->rowptr);
+  if (d->colind) (void)hipFree(d->colind);
+  if (d->vals) (void)hipFree(d->vals);
+  *d = CsrDev();
+}
+
+extern "C" int aggmg_csc_upload(aggmg_ctx* ctx, int64_t m, int64_t n, const int64_t* colptr,
+                                const int64_t* rowval, const double* nzval, int one_based, int kind,
+                                aggmg_op** out) {
+  if (!ctx || !out || !colptr) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_csc_upload: NULL argument");
+  *out = nullptr;
+  if (m < 0 || n < 0) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_csc_upload: negative dimension");
+  const int64_t base = one_based ? 1 : 0;
+  const int64_t nnz = colptr[n] - base;
+  const int64_t lim = (int64_t)1 << 31;
+  if (m >= lim || n >= lim || nnz >= lim)
+    return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_csc_upload: dimension or nnz >= 2^31 (int32 device indices)");
+  if (nnz < 0 || (nnz > 0 && (!rowval || !nzval)))
+    return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_csc_upload: inconsistent colptr / NULL arrays");
+  if (kind != AGGMG_OP_STIFFNESS && kind != AGGMG_OP_TRANSFER)
+    return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_csc_upload: unknown kind");
+  HIPCHK(hipSetDevice(ctx->device));
+
+  // the CSC arrays, 0-based int32: this IS the CSR of the transpose
+  std::vector<int32_t> cptr(n + 1), rval(nnz);
+  for (int64_t j = 0; j <= n; ++j) {
+    int64_t v = colptr[j] - base;
+    if (v < 0 || v > nnz || (j > 0 && v < cptr[j - 1]))
+      return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_csc_upload: colptr not monotone");
+    cptr[j] = (int32_t)v;
+  }
+  for (int64_t j = 0; j < n; ++j) {
+    for (int32_t p = cptr[j]; p < cptr[j + 1]; ++p) {
+      int64_t r = rowval[p] - base;
+      if (r < 0 || r >= m) return fail(ctx, AGGMG_ERR_DIMENSION, "aggmg_csc_upload: row index out of range");
+      if (p > cptr[j] && r <= rval[p - 1])
+        return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_csc_upload: row indices not strictly ascending in a column");
+      rval[p] = (int32_t)r;
+    }
+  }
+  std::vector<double> cval(nzval, nzval + nnz);
+
+  // transpose to the row-gather CSR (counting sort; ascending columns inside every row)
+  auto op = std::make_unique<aggmg_op>();
+  op->m = m;
+  op->n = n;
+  op->nnz = nnz;
+  op->kind = kind;
+  HostCsr& h = op->host;
+  h.rowptr.assign(m + 1, 0);
+  h.colind.resize(nnz);
+  h.vals.resize(nnz);
+  for (int64_t p = 0; p < nnz; ++p) h.rowptr[rval[p] + 1]++;
+  for (int64_t i = 0; i < m; ++i) h.rowptr[i + 1] += h.rowptr[i];
+  {
+    std::vector<int32_t> next(h.rowptr.begin(), h.rowptr.end() - 1);
+    for (int64_t j = 0; j < n; ++j)
+      for (int32_t p = cptr[j]; p < cptr[j + 1]; ++p) {
+        int32_t q = next[rval[p]]++;
+        h.colind[q] = (int32_t)j;
+        h.vals[q] = cval[p];
+      }
+  }
+  op->host_valid = true;
+  CHECK(upload_csr(ctx, m, n, h.rowptr, h.colind, h.vals, &op->csr));
+  if (kind == AGGMG_OP_TRANSFER) CHECK(upload_csr(ctx, n, m, cptr, rval, cval, &op->csrT));
+  *out = op.release();
+  return AGGMG_OK;
+}
+
+extern "C" int aggmg_op_free(aggmg_ctx* ctx, aggmg_op* op) {
+  if (!ctx) return AGGMG_ERR_ARGUMENT;
+  if (!op) return AGGMG_OK;
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  free_csr(&op->csr);
+  free_csr(&op->csrT);
+  delete op;
+  return AGGMG_OK;
+}
+
+extern "C" int aggmg_op_shape(aggmg_ctx* ctx, const aggmg_op* op, int64_t* m, int64_t* n, int64_t* nnz) {
+  if (!ctx || !op) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_op_shape: NULL");
+  if (m) *m = op->m;
+  if (n) *n = op->n;
+  if (nnz) *nnz = op->nnz;
+  return AGGMG_OK;
+}
+
+extern "C" int aggmg_op_download(aggmg_ctx* ctx, const aggmg_op* op, int transposed, int32_t* rowptr,
+                                 int32_t* colind, double* vals) {
+  if (!ctx || !op) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_op_download: NULL");
+  const CsrDev& d = transposed ? op->csrT : op->csr;
+  if (!d.rowptr) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_op_download: orientation not stored for this op");
+  if (rowptr) HIPCHK(hipMemcpyAsync(rowptr, d.rowptr, (d.nrows + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+  if (colind && d.nnz) HIPCHK(hipMemcpyAsync(colind, d.colind, d.nnz * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+  if (vals && d.nnz) HIPCHK(hipMemcpyAsync(vals, d.vals, d.nnz * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return AGGMG_OK;
+}
+
+extern "C" int aggmg_op_release_host(aggmg_ctx* ctx, aggmg_op* op) {
+  if (!ctx || !op) return AGGMG_ERR_ARGUMENT;
+  op->host = HostCsr();
+  op->host_valid = false;
+  return AGGMG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// small dense helpers (host, set-up only)
+// ---------------------------------------------------------------------------------------------
+// In-place LU with partial pivoting (the arithmetic of LAPACK getf2), then the explicit inverse
+// by solving for the identity columns.  a, inv: m x m row-major.  false on an exactly-zero pivot
+// (Julia: SingularException, src/smoother.jl:160).
+static bool invert_block(int m, std::vector<double>& a, std::vector<double>& inv, std::vector<int>& piv) {
+  piv.resize(m);
+  for (int k = 0; k < m; ++k) {
+    int p = k;
+    double best = std::fabs(a[k * m + k]);
+    for (int i = k + 1; i < m; ++i) {
+      double v = std::fabs(a[i * m + k]);
+      if (v > best) {
+        best = v;
+        p = i;
+      }
+    }
+    piv[k] = p;
+    if (a[p * m + k] == 0.0) return false;
+    if (p != k)
+      for (int j = 0; j < m; ++j) std::swap(a[k * m + j], a[p * m + j]);
+    const double rp = 1.0 / a[k * m + k];
+    for (int i = k + 1; i < m; ++i) a[i * m + k] *= rp;
+    for (int i = k + 1; i < m; ++i) {
+      const double l = a[i * m + k];
+      for (int j = k + 1; j < m; ++j) a[i * m + j] -= l * a[k * m + j];
+    }
+  }
+  inv.assign((size_t)m * m, 0.0);
+  std::vector<double> x(m);
+  for (int c = 0; c < m; ++c) {
+    for (int i = 0; i < m; ++i) x[i] = (i == c) ? 1.0 : 0.0;
+    for (int k = 0; k < m; ++k)
+      if (piv[k] != k) std::swap(x[k], x[piv[k]]);
+    for (int i = 1; i < m; ++i) {
+      double s = x[i];
+      for (int j = 0; j < i; ++j) s -= a[i * m + j] * x[j];
+      x[i] = s;
+    }
+    for (int i = m - 1; i >= 0; --i) {
+      double s = x[i];
+      for (int j = i + 1; j < m; ++j) s -= a[i * m + j] * x[j];
+      x[i] = s / a[i * m + i];
+    }
+    for (int i = 0; i < m; ++i) inv[i * m + c] = x[i];
+  }
+  return true;
+}
+
+static double host_entry(const HostCsr& h, int64_t r, int64_t c) {
+  const int32_t* b = h.colind.data() + h.rowptr[r];
+  const int32_t* e = h.colind.data() + h.rowptr[r + 1];
+  const int32_t* it = std::lower_bound(b, e, (int32_t)c);
+  if (it != e && *it == (int32_t)c) return h.vals[it - h.colind.data()];
+  return 0.0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// smoothers
+// ---------------------------------------------------------------------------------------------
+static void free_btd(BtdDev* b) {
+  for (double* p : {b->binv, b->dblk, b->scol, b->pcol, b->qrow, b->sub, b->sup, b->P, b->Q})
+    if (p) (void)hipFree(p);
+}
+
+static bool btd_supported(int m, bool cmp) {
+  if (cmp) return m >= 2 && m <= 9;
+  return m >= 1 && m <= 5;
+}
+
+// Recognise "block-tridiagonal with contiguous aligned m-blocks" and build the fused-kernel form.
+static int build_btd(aggmg_ctx* ctx, aggmg_smoother* sm, const std::vector<double>& binv_all) {
+  const HostCsr& h = sm->A->host;
+  const int m = (int)sm->m;
+  const int64_t ne = sm->nb, N = sm->N;
+  for (int64_t r = 0; r < N; ++r) {
+    const int64_t e = r / m;
+    const int64_t lo = std::max<int64_t>(0, (e - 1) * m), hi = std::min<int64_t>(N, (e + 2) * m);
+    for (int32_t p = h.rowptr[r]; p < h.rowptr[r + 1]; ++p)
+      if (h.colind[p] < lo || h.colind[p] >= hi) return AGGMG_OK;  // not block-tridiagonal
+  }
+  std::vector<double> dblk((size_t)N * m, 0.0), sub((size_t)N * m, 0.0), sup((size_t)N * m, 0.0);
+  for (int64_t r = 0; r < N; ++r) {
+    const int64_t e = r / m;
+    for (int32_t p = h.rowptr[r]; p < h.rowptr[r + 1]; ++p) {
+      const int64_t c = h.colind[p];
+      const int64_t ce = c / m;
+      const int j = (int)(c - ce * m);
+      if (ce == e)
+        dblk[r * m + j] = h.vals[p];
+      else if (ce == e - 1)
+        sub[r * m + j] = h.vals[p];
+      else
+        sup[r * m + j] = h.vals[p];
+    }
+  }
+  // compressed pattern: Sub_e non-zero in one common column, Sup_e in one common row
+  int c_sub = -1, r_sup = -1;
+  bool cmp = m >= 2;
+  for (int64_t r = 0; r < N && cmp; ++r) {
+    const int i = (int)(r % m);
+    for (int j = 0; j < m; ++j) {
+      if (sub[r * m + j] != 0.0) {
+        if (c_sub < 0) c_sub = j;
+        if (c_sub != j) cmp = false;
+      }
+      if (sup[r * m + j] != 0.0) {
+        if (r_sup < 0) r_sup = i;
+        if (r_sup != i) cmp = false;
+      }
+    }
+  }
+  if (c_sub < 0) c_sub = 0;
+  if (r_sup < 0) r_sup = 0;
+  if (cmp && !btd_supported(m, true)) cmp = false;
+  if (!cmp && !btd_supported(m, false)) return AGGMG_OK;  // generic path
+
+  auto b = std::make_unique<BtdDev>();
+  b->m = m;
+  b->ne = ne;
+  b->cmp = cmp;
+  b->c_sub = c_sub;
+  b->r_sup = r_sup;
+  // binv_all is [nb][m][m] row-major == [N][m]
+  int st = dev_upload(ctx, binv_all, &b->binv);
+  if (st == AGGMG_OK) st = dev_upload(ctx, dblk, &b->dblk);
+  if (cmp) {
+    std::vector<double> scol(N), pcol(N), qrow((size_t)ne * m);
+    for (int64_t r = 0; r < N; ++r) scol[r] = sub[r * m + c_sub];
+    for (int64_t e = 0; e < ne; ++e) {
+      for (int j = 0; j < m; ++j) qrow[e * m + j] = sup[(e * m + r_sup) * m + j];
+      for (int i = 0; i < m; ++i) {
+        double acc = 0.0;
+        for (int j = 0; j < m; ++j) acc += binv_all[(e * m + i) * m + j] * scol[e * m + j];
+        pcol[e * m + i] = acc;
+      }
+    }
+    if (st == AGGMG_OK) st = dev_upload(ctx, scol, &b->scol);
+    if (st == AGGMG_OK) st = dev_upload(ctx, pcol, &b->pcol);
+    if (st == AGGMG_OK) st = dev_upload(ctx, qrow, &b->qrow);
+  } else {
+    std::vector<double> P((size_t)N * m), Q((size_t)N * m);
+    for (int64_t e = 0; e < ne; ++e)
+      for (int i = 0; i < m; ++i)
+        for (int j = 0; j < m; ++j) {
+          double p = 0.0, q = 0.0;
+          for (int k = 0; k < m; ++k) {
+            const double bi = binv_all[(e * m + i) * m + k];
+            p += bi * sub[(e * m + k) * m + j];
+            q += bi * sup[(e * m + k) * m + j];
+          }
+          P[(e * m + i) * m + j] = p;
+          Q[(e * m + i) * m + j] = q;
+        }
+    if (st == AGGMG_OK) st = dev_upload(ctx, sub, &b->sub);
+    if (st == AGGMG_OK) st = dev_upload(ctx, sup, &b->sup);
+    if (st == AGGMG_OK) st = dev_upload(ctx, P, &b->P);
+    if (st == AGGMG_OK) st = dev_upload(ctx, Q, &b->Q);
+  }
+  if (st != AGGMG_OK) {
+    free_btd(b.get());
+    return st;
+  }
+  sm->btd = std::move(b);
+  return AGGMG_OK;
+}
+
+extern "C" int aggmg_blockjacobi_setup(aggmg_ctx* ctx, aggmg_op* A, int64_t m, int64_t nb,
+                                       const int64_t* blockinds, int one_based, int kind,
+                                       aggmg_smoother** out) {
+  if (!ctx || !A || !out || !blockinds) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_blockjacobi_setup: NULL argument");
+  *out = nullptr;
+  if (A->m != A->n) return fail(ctx, AGGMG_ERR_DIMENSION, "aggmg_blockjacobi_setup: operator is not square");
+  if (!A->host_valid) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_blockjacobi_setup: host copy of the operator was released");
+  if (m <= 0 || nb < 0 || m > 64) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_blockjacobi_setup: block size must be in 1..64");
+  if (kind != 0 && kind != 1) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_blockjacobi_setup: unknown kind");
+  HIPCHK(hipSetDevice(ctx->device));
+  const int64_t N = A->m;
+  const int64_t base = one_based ? 1 : 0;
+  auto sm = std::make_unique<aggmg_smoother>();
+  sm->kind = kind == 1 ? 2 : 1;
+  sm->A = A;
+  sm->N = N;
+  sm->m = m;
+  sm->nb = nb;
+  std::vector<int32_t> inds((size_t)nb * m);
+  std::vector<double> counts(N, 0.0);
+  bool contiguous = (nb * m == N);
+  for (int64_t k = 0; k < nb; ++k)
+    for (int64_t i = 0; i < m; ++i) {
+      int64_t v = blockinds[k * m + i] - base;
+      if (v < 0 || v >= N) return fail(ctx, AGGMG_ERR_DIMENSION, "aggmg_blockjacobi_setup: block index out of range");
+      inds[k * m + i] = (int32_t)v;
+      counts[v] += 1.0;
+      if (v != k * m + i) contiguous = false;
+    }
+  bool overlapping = false;
+  for (int64_t i = 0; i < N; ++i)
+    if (counts[i] > 1.0) overlapping = true;
+  sm->overlapping = overlapping;
+  sm->contiguous = contiguous;
+
+  std::vector<double> binv((size_t)nb * m * m), blk((size_t)m * m), inv;
+  std::vector<int> piv;
+  for (int64_t k = 0; k < nb; ++k) {
+    for (int64_t i = 0; i < m; ++i)
+      for (int64_t j = 0; j < m; ++j) blk[i * m + j] = host_entry(A->host, inds[k * m + i], inds[k * m + j]);
+    if (!invert_block((int)m, blk, inv, piv))
+      return fail(ctx, AGGMG_ERR_SINGULAR,
+                  "aggmg_blockjacobi_setup: singular block " + std::to_string(k + 1) + " (SingularException)");
+    std::copy(inv.begin(), inv.end(), binv.begin() + k * m * m);
+  }
+  CHECK(dev_upload(ctx, binv, &sm->binv));
+  CHECK(dev_upload(ctx, inds, &sm->inds));
+  if (sm->kind == 2) CHECK(dev_upload(ctx, counts, &sm->counts));
+  if (contiguous && !overlapping && sm->kind == 1) CHECK(build_btd(ctx, sm.get(), binv));
+  *out = sm.release();
+  return AGGMG_OK;
+}
+
+extern "C" int aggmg_jacobi_setup(aggmg_ctx* ctx, aggmg_op* A, aggmg_smoother** out) {
+  if (!ctx || !A || !out) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_jacobi_setup: NULL argument");
+  *out = nullptr;
+  if (A->m != A->n) return fail(ctx, AGGMG_ERR_DIMENSION, "aggmg_jacobi_setup: operator is not square");
+  if (!A->host_valid) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_jacobi_setup: host copy of the operator was released");
+  HIPCHK(hipSetDevice(ctx->device));
+  auto sm = std::make_unique<aggmg_smoother>();
+  sm->kind = 0;
+  sm->A = A;
+  sm->N = A->m;
+  std::vector<double> d(A->m);
+  for (int64_t i = 0; i < A->m; ++i) d[i] = host_entry(A->host, i, i);  // A[i,i], 0.0 when not stored
+  CHECK(dev_upload(ctx, d, &sm->diag));
+  *out = sm.release();
+  return AGGMG_OK;
+}
+
+extern "C" int aggmg_smoother_free(aggmg_ctx* ctx, aggmg_smoother* sm) {
+  if (!ctx) return AGGMG_ERR_ARGUMENT;
+  if (!sm) return AGGMG_OK;
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  for (void* p : {(void*)sm->diag, (void*)sm->binv, (void*)sm->inds, (void*)sm->counts})
+    if (p) (void)hipFree(p);
+  if (sm->btd) free_btd(sm->btd.get());
+  delete sm;
+  return AGGMG_OK;
+}
+
+extern "C" int aggmg_smoother_is_structured(aggmg_ctx* ctx, const aggmg_smoother* sm, int* out) {
+  if (!ctx || !sm || !out) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_smoother_is_structured: NULL");
+  *out = sm->btd ? 1 : 0;
+  return AGGMG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// launches
+// ---------------------------------------------------------------------------------------------
+template <int MODE>
+static int launch_csr(aggmg_ctx* ctx, const CsrDev& A, const double* x, const double* b, const double* dg,
+                      double alpha, double* y) {
+  if (A.nrows == 0) return AGGMG_OK;
+  const int lpr = A.lpr;
+  const int64_t rows_per_block = kThreads / lpr;
+  const int64_t nblk = (A.nrows + rows_per_block - 1) / rows_per_block;
+  if (nblk >= ((int64_t)1 << 31)) return fail(ctx, AGGMG_ERR_UNSUPPORTED, "grid too large");
+  dim3 grid((unsigned)nblk), block(kThreads);
+  CsrView v = A.view();
+  switch (lpr) {
+#define CASE(L)                                                                             \
+  case L:                                                                                   \
+    hipLaunchKernelGGL((csr_row_kernel<L, MODE>), grid, block, 0, ctx->stream, v, x, b, dg, alpha, y); \
+    break;
+    CASE(1) CASE(2) CASE(4) CASE(8) CASE(16) CASE(32) CASE(64)
+#undef CASE
+    default:
+      return fail(ctx, AGGMG_ERR_UNSUPPORTED, "bad lanes-per-row");
+  }
+  HIPCHK(hipGetLastError());
+  return AGGMG_OK;
+}
+
+template <int M, bool CMP>
+struct BtdTile {
+  // slabs per tile: sized so a tile is ~256 elements while the per-thread register arrays
+  // (NS x (2..3) x M doubles) stay well under the 128-VGPR / 4-waves-per-SIMD step
+  static constexpr int NS = (M <= 2) ? 2 : (M == 3) ? 3 : (M == 4) ? 4 : (M <= 7) ? 3 : 2;
+  static constexpr int EPS = kThreads / M;
+  static constexpr int TE = EPS * NS;
+};
+
+template <int M, bool CMP>
+static int launch_btd_t(aggmg_ctx* ctx, FusedArgs a, int halo) {
+  using T = BtdTile<M, CMP>;
+  const int align = a.lf_out ? a.rho_out : 1;
+  int owned = ((T::TE - 2 * halo) / align) * align;
+  if (owned <= 0) return fail(ctx, AGGMG_ERR_UNSUPPORTED, "fused tile too small for the requested halo");
+  a.owned = owned;
+  a.halo_left = halo;
+  const int64_t ntiles = (a.lv.ne + owned - 1) / owned;
+  if (ntiles == 0) return AGGMG_OK;
+  const size_t lds = (size_t)2 * (T::TE + 2) * M * sizeof(double);
+  hipLaunchKernelGGL((btd_fused_kernel<M, CMP, T::NS>), dim3((unsigned)ntiles), dim3(kThreads), lds,
+                     ctx->stream, a);
+  HIPCHK(hipGetLastError());
+  return AGGMG_OK;
+}
+
+template <int M, bool CMP>
+static int btd_max_halo() {
+  return (BtdTile<M, CMP>::TE - 8) / 2;
+}
+
+static int launch_btd(aggmg_ctx* ctx, const BtdDev& b, const FusedArgs& a, int halo) {
+#define CASE(MM)                                        \
+  case MM:                                              \
+    return b.cmp ? launch_btd_t<MM, true>(ctx, a, halo) \
+                 : launch_btd_t<MM, false>(ctx, a, halo);
+#define CASE_C(MM) \
+  case MM:         \
+    return launch_btd_t<MM, true>(ctx, a, halo);
+  switch (b.m) {
+    case 1:
+      return launch_btd_t<1, false>(ctx, a, halo);
+      CASE(2) CASE(3) CASE(4) CASE(5) CASE_C(6) CASE_C(7) CASE_C(8) CASE_C(9)
+    default:
+      return fail(ctx, AGGMG_ERR_UNSUPPORTED, "block size not instantiated for the fused kernel");
+  }
+#undef CASE
+#undef CASE_C
+}
+
+static int btd_tile_elems(const BtdDev& b) {
+  switch (b.m) {
+    case 1: return BtdTile<1, false>::TE;
+    case 2: return BtdTile<2, false>::TE;
+    case 3: return BtdTile<3, false>::TE;
+    case 4: return BtdTile<4, false>::TE;
+    case 5: return BtdTile<5, false>::TE;
+    case 6: return BtdTile<6, true>::TE;
+    case 7: return BtdTile<7, true>::TE;
+    case 8: return BtdTile<8, true>::TE;
+    case 9: return BtdTile<9, true>::TE;
+  }
+  return 0;
+}
+
+static FusedArgs btd_args(const BtdDev& b) {
+  FusedArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.lv = BtdLevel{b.binv, b.dblk, b.scol, b.pcol, b.qrow, b.sub, b.sup, b.P, b.Q, b.ne, b.c_sub, b.r_sup};
+  return a;
+}
+
+// Max sweeps fused into one launch: the halo costs 2*S/TE redundant work.
+static int btd_max_sweeps(const BtdDev& b, int extra) {
+  const int te = btd_tile_elems(b);
+  int s = std::min(8, te / 8) - extra;
+  return std::max(1, s);
+}
+
+// structured: nsweeps sweeps from u_in (may be nullptr = zero) into u_out (!= u_in)
+static int btd_smooth(aggmg_ctx* ctx, const BtdDev& b, const double* u_in, const double* rhs, double alpha,
+                      int nsweeps, double* u_out, int level, int64_t N) {
+  const int smax = btd_max_sweeps(b, 0);
+  const double* src = u_in;
+  int left = nsweeps;
+  if (left == 0) {
+    if (u_in)
+      HIPCHK(hipMemcpyAsync(u_out, u_in, N * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    else
+      HIPCHK(hipMemsetAsync(u_out, 0, N * sizeof(double), ctx->stream));
+    return AGGMG_OK;
+  }
+  // chunk chain: src -> (scratch0 / scratch1 alternating) -> ... -> u_out
+  const int nchunks = (left + smax - 1) / smax;
+  double *t0 = nullptr, *t1 = nullptr;
+  if (nchunks > 1) {
+    CHECK(scratch(ctx, 0, N, &t0));
+    if (nchunks > 2) CHECK(scratch(ctx, 1, N, &t1));
+  }
+  for (int c = 0; c < nchunks; ++c) {
+    const int s = std::min(left, smax);
+    double* dst = (c == nchunks - 1) ? u_out : (((nchunks - 1 - c) % 2 == 1) ? t0 : t1);
+    FusedArgs a = btd_args(b);
+    a.u_in = src;
+    a.b = rhs;
+    a.u_out = dst;
+    a.alpha = alpha;
+    a.nsweeps = s;
+    {
+      ProfScope ps(ctx, AGGMG_KIND_SMOOTH, level);
+      CHECK(launch_btd(ctx, b, a, s));
+    }
+    src = dst;
+    left -= s;
+  }
+  return AGGMG_OK;
+}
+
+// generic: one sweep u_out = u_in + alpha * S^{-1}(b - A u_in); u_out may alias u_in for block
+// smoothers, must differ for point Jacobi.
+static int generic_sweep(aggmg_ctx* ctx, aggmg_op* A, aggmg_smoother* sm, const double* u_in, const double* rhs,
+                         double alpha, double* u_out, int level) {
+  const int64_t N = A->m;
+  if (sm->kind == 0) {
+    ProfScope ps(ctx, AGGMG_KIND_JACOBI, level);
+    return launch_csr<kJacobi>(ctx, A->csr, u_in, rhs, sm->diag, alpha, u_out);
+  }
+  double *r = nullptr, *y = nullptr;
+  CHECK(scratch(ctx, 1, N, &r));
+  CHECK(scratch(ctx, 2, N, &y));
+  {
+    ProfScope ps(ctx, AGGMG_KIND_RESIDUAL, level);
+    CHECK(launch_csr<kResidual>(ctx, A->csr, u_in, rhs, nullptr, 0.0, r));
+  }
+  ProfScope ps(ctx, AGGMG_KIND_BLOCK_APPLY, level);
+  HIPCHK(hipMemsetAsync(y, 0, N * sizeof(double), ctx->stream));
+  const int64_t nthreads = sm->nb * sm->m;
+  const unsigned nblk = (unsigned)((nthreads + kThreads - 1) / kThreads);
+  if (nblk) {
+    if (sm->overlapping)
+      hipLaunchKernelGGL((block_apply_kernel<true>), dim3(nblk), dim3(kThreads), 0, ctx->stream, sm->binv,
+                         sm->inds, (int)sm->m, sm->nb, r, y);
+    else
+      hipLaunchKernelGGL((block_apply_kernel<false>), dim3(nblk), dim3(kThreads), 0, ctx->stream, sm->binv,
+                         sm->inds, (int)sm->m, sm->nb, r, y);
+    HIPCHK(hipGetLastError());
+  }
+  const unsigned nb2 = (unsigned)((N + kThreads - 1) / kThreads);
+  if (nb2) {
+    hipLaunchKernelGGL(axpy_scaled_kernel, dim3(nb2), dim3(kThreads), 0, ctx->stream, N, u_in, y,
+                       sm->kind == 2 ? sm->counts : nullptr, alpha, u_out);
+    HIPCHK(hipGetLastError());
+  }
+  return AGGMG_OK;
+}
+
+static int check_pair(aggmg_ctx* ctx, aggmg_op* A, aggmg_smoother* sm, const char* who) {
+  if (!ctx) return AGGMG_ERR_ARGUMENT;
+  if (!A || !sm) return fail(ctx, AGGMG_ERR_ARGUMENT, std::string(who) + ": NULL handle");
+  if (A->m != A->n || sm->N != A->m)
+    return fail(ctx, AGGMG_ERR_DIMENSION, std::string(who) + ": operator / smoother size mismatch");
+  return AGGMG_OK;
+}
+
+extern "C" int aggmg_smooth_dev(aggmg_ctx* ctx, aggmg_op* A, aggmg_smoother* sm, const double* u_in,
+                                const double* b, double alpha, int nsweeps, double* u_out) {
+  CHECK(check_pair(ctx, A, sm, "aggmg_smooth"));
+  if (!b || !u_out || nsweeps < 0) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_smooth: bad argument");
+  const int64_t N = A->m;
+  if (N == 0) return AGGMG_OK;
+  if (sm->btd && sm->A == A) {
+    if (u_out != u_in) return btd_smooth(ctx, *sm->btd, u_in, b, alpha, nsweeps, u_out, 0, N);
+    double* t = nullptr;  // in-place request: stage through scratch (extra copy)
+    CHECK(scratch(ctx, 2, N, &t));
+    CHECK(btd_smooth(ctx, *sm->btd, u_in, b, alpha, nsweeps, t, 0, N));
+    HIPCHK(hipMemcpyAsync(u_out, t, N * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    return AGGMG_OK;
+  }
+  // generic path; point Jacobi ping-pongs through scratch 0
+  const double* src = u_in;
+  double* t = nullptr;
+  CHECK(scratch(ctx, 0, N, &t));
+  if (!u_in) {
+    HIPCHK(hipMemsetAsync(u_out, 0, N * sizeof(double), ctx->stream));
+    src = u_out;
+  }
+  if (nsweeps == 0) {
+    if (src != u_out) HIPCHK(hipMemcpyAsync(u_out, src, N * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    return AGGMG_OK;
+  }
+  for (int s = 0; s < nsweeps; ++s) {
+    if (sm->kind == 0) {
+      // choose destinations so that the last sweep lands in u_out
+      double* dst = ((nsweeps - 1 - s) % 2 == 0) ? u_out : t;
+      if (dst == src) {  // only possible on the first sweep when src == u_out
+        HIPCHK(hipMemcpyAsync(t, src, N * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+        src = t;
+        if (dst == t) dst = u_out;  // unreachable, kept for clarity
+      }
+      CHECK(generic_sweep(ctx, A, sm, src, b, alpha, dst, 0));
+      src = dst;
+    } else {
+      CHECK(generic_sweep(ctx, A, sm, src, b, alpha, u_out, 0));
+      src = u_out;
+    }
+  }
+  return AGGMG_OK;
+}
+
+extern "C" int aggmg_residual_dev(aggmg_ctx* ctx, aggmg_op* A, const double* u, const double* b, double* r_out) {
+  if (!ctx) return AGGMG_ERR_ARGUMENT;
+  if (!A || !u || !b || !r_out) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_residual: NULL argument");
+  ProfScope ps(ctx, AGGMG_KIND_RESIDUAL, 0);
+  return launch_csr<kResidual>(ctx, A->csr, u, b, nullptr, 0.0, r_out);
+}
+
+extern "C" int aggmg_restrict_dev(aggmg_ctx* ctx, aggmg_op* L, const double* r, double* rc_out) {
+  if (!ctx) return AGGMG_ERR_ARGUMENT;
+  if (!L || !r || !rc_out) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_restrict: NULL argument");
+  if (!L->csrT.rowptr) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_restrict: operator was not uploaded as a transfer");
+  ProfScope ps(ctx, AGGMG_KIND_RESTRICT, 0);
+  return launch_csr<kSpmvSet>(ctx, L->csrT, r, nullptr, nullptr, 0.0, rc_out);
+}
+
+extern "C" int aggmg_prolong_add_dev(aggmg_ctx* ctx, aggmg_op* L, const double* uc, double* u_inout) {
+  if (!ctx) return AGGMG_ERR_ARGUMENT;
+  if (!L || !uc || !u_inout) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_prolong_add: NULL argument");
+  ProfScope ps(ctx, AGGMG_KIND_PROLONG, 0);
+  return launch_csr<kSpmvAdd>(ctx, L->csr, uc, nullptr, nullptr, 0.0, u_inout);
+}
+
+// ---------------------------------------------------------------------------------------------
+// host-pointer wrappers
+// ---------------------------------------------------------------------------------------------
+struct DevVec {
+  aggmg_ctx* ctx;
+  double* p = nullptr;
+  explicit DevVec(aggmg_ctx* c) : ctx(c) {}
+  ~DevVec() {
+    if (p) {
+      (void)hipStreamSynchronize(ctx->stream);
+      (void)hipFree(p);
+    }
+  }
+  int alloc(int64_t n, const double* host) {
+    HIPCHK(hipMalloc((void**)&p, (size_t)std::max<int64_t>(n, 1) * sizeof(double)));
+    if (host && n) HIPCHK(hipMemcpyAsync(p, host, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    return AGGMG_OK;
+  }
+  int fetch(int64_t n, double* host) {
+    if (n) HIPCHK(hipMemcpyAsync(host, p, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return AGGMG_OK;
+  }
+};
+
+extern "C" int aggmg_smooth(aggmg_ctx* ctx, aggmg_op* A, aggmg_smoother* sm, double* u_inout, const double* b,
+                            double alpha, int nsweeps) {
+  CHECK(check_pair(ctx, A, sm, "aggmg_smooth"));
+  if (!u_inout || !b) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_smooth: NULL argument");
+  HIPCHK(hipSetDevice(ctx->device));
+  const int64_t N = A->m;
+  DevVec du(ctx), db(ctx), dout(ctx);
+  CHECK(du.alloc(N, u_inout));
+  CHECK(db.alloc(N, b));
+  CHECK(dout.alloc(N, nullptr));
+  CHECK(aggmg_smooth_dev(ctx, A, sm, du.p, db.p, alpha, nsweeps, dout.p));
+  return dout.fetch(N, u_inout);
+}
+
+extern "C" int aggmg_residual(aggmg_ctx* ctx, aggmg_op* A, const double* u, const double* b, double* r_out) {
+  if (!ctx) return AGGMG_ERR_ARGUMENT;
+  if (!A || !u || !b || !r_out) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_residual: NULL argument");
+  HIPCHK(hipSetDevice(ctx->device));
+  DevVec du(ctx), db(ctx), dr(ctx);
+  CHECK(du.alloc(A->n, u));
+  CHECK(db.alloc(A->m, b));
+  CHECK(dr.alloc(A->m, nullptr));
+  CHECK(aggmg_residual_dev(ctx, A, du.p, db.p, dr.p));
+  return dr.fetch(A->m, r_out);
+}
+
+extern "C" int aggmg_restrict(aggmg_ctx* ctx, aggmg_op* L, const double* r, double* rc_out) {
+  if (!ctx) return AGGMG_ERR_ARGUMENT;
+  if (!L || !r || !rc_out) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_restrict: NULL argument");
+  HIPCHK(hipSetDevice(ctx->device));
+  DevVec dr(ctx), dc(ctx);
+  CHECK(dr.alloc(L->m, r));
+  CHECK(dc.alloc(L->n, nullptr));
+  CHECK(aggmg_restrict_dev(ctx, L, dr.p, dc.p));
+  return dc.fetch(L->n, rc_out);
+}
+
+extern "C" int aggmg_prolong_add(aggmg_ctx* ctx, aggmg_op* L, const double* uc, double* u_inout) {
+  if (!ctx) return AGGMG_ERR_ARGUMENT;
+  if (!L || !uc || !u_inout) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_prolong_add: NULL argument");
+  HIPCHK(hipSetDevice(ctx->device));
+  DevVec dc(ctx), du(ctx);
+  CHECK(dc.alloc(L->n, uc));
+  CHECK(du.alloc(L->m, u_inout));
+  CHECK(aggmg_prolong_add_dev(ctx, L, dc.p, du.p));
+  return du.fetch(L->m, u_inout);
+}
+
+extern "C" int aggmg_smoother_apply(aggmg_ctx* ctx, aggmg_smoother* sm, const double* B, int64_t N, int64_t ncols,
+                                    double alpha, double* Y) {
+  if (!ctx) return AGGMG_ERR_ARGUMENT;
+  if (!sm || !B || !Y) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_smoother_apply: NULL argument");
+  if (N != sm->N || ncols < 0) return fail(ctx, AGGMG_ERR_DIMENSION, "aggmg_smoother_apply: DimensionMismatch");
+  HIPCHK(hipSetDevice(ctx->device));
+  DevVec dB(ctx), dY(ctx), dT(ctx);
+  CHECK(dB.alloc(N * ncols, B));
+  CHECK(dY.alloc(N * ncols, nullptr));
+  CHECK(dT.alloc(N, nullptr));
+  const unsigned nb2 = (unsigned)((N + kThreads - 1) / kThreads);
+  for (int64_t c = 0; c < ncols && N > 0; ++c) {
+    const double* bc = dB.p + c * N;
+    double* yc = dY.p + c * N;
+    ProfScope ps(ctx, AGGMG_KIND_BLOCK_APPLY, 0);
+    if (sm->kind == 0) {
+      // alpha * (Diagonal \ B): reuse the scaled-axpy kernel with counts := diag
+      hipLaunchKernelGGL(axpy_scaled_kernel, dim3(nb2), dim3(kThreads), 0, ctx->stream, N, (const double*)nullptr,
+                         bc, (const double*)sm->diag, alpha, yc);
+    } else {
+      HIPCHK(hipMemsetAsync(dT.p, 0, N * sizeof(double), ctx->stream));
+      const unsigned nblk = (unsigned)((sm->nb * sm->m + kThreads - 1) / kThreads);
+      if (nblk) {
+        if (sm->overlapping)
+          hipLaunchKernelGGL((block_apply_kernel<true>), dim3(nblk), dim3(kThreads), 0, ctx->stream, sm->binv,
+                             sm->inds, (int)sm->m, sm->nb, bc, dT.p);
+        else
+          hipLaunchKernelGGL((block_apply_kernel<false>), dim3(nblk), dim3(kThreads), 0, ctx->stream, sm->binv,
+                             sm->inds, (int)sm->m, sm->nb, bc, dT.p);
+      }
+      hipLaunchKernelGGL(axpy_scaled_kernel, dim3(nb2), dim3(kThreads), 0, ctx->stream, N, (const double*)nullptr,
+                         (const double*)dT.p, sm->kind == 2 ? (const double*)sm->counts : (const double*)nullptr,
+                         alpha, yc);
+    }
+    HIPCHK(hipGetLastError());
+  }
+  return dY.fetch(N * ncols, Y);
+}
+
+// ---------------------------------------------------------------------------------------------
+// coarsest-level direct solve (host, banded LU with partial pivoting = dgbtf2 / dgbtrs order)
+// ---------------------------------------------------------------------------------------------
+static int banded_factor(aggmg_ctx* ctx, const HostCsr& h, int64_t n, BandedLU* f) {
+  int kl = 0, ku = 0;
+  for (int64_t i = 0; i < n; ++i)
+    for (int32_t p = h.rowptr[i]; p < h.rowptr[i + 1]; ++p) {
+      const int64_t j = h.colind[p];
+      kl = std::max<int64_t>(kl, i - j);
+      ku = std::max<int64_t>(ku, j - i);
+    }
+  const int64_t ldab = 2 * (int64_t)kl + ku + 1;
+  if ((double)ldab * (double)n * 8.0 > 8e9)
+    return fail(ctx, AGGMG_ERR_UNSUPPORTED,
+                "coarsest operator bandwidth too large for the host banded solver (kl=" + std::to_string(kl) +
+                    ", ku=" + std::to_string(ku) + ", n=" + std::to_string(n) + ")");
+  f->n = n;
+  f->kl = kl;
+  f->ku = ku;
+  f->ldab = (int)ldab;
+  f->ab.assign((size_t)ldab * n, 0.0);
+  f->ipiv.assign(n, 0);
+  const int kv = ku + kl;
+  auto AB = [&](int64_t r, int64_t c) -> double& { return f->ab[(size_t)c * ldab + r]; };
+  for (int64_t i = 0; i < n; ++i)
+    for (int32_t p = h.rowptr[i]; p < h.rowptr[i + 1]; ++p) {
+      const int64_t j = h.colind[p];
+      AB(kv + i - j, j) = h.vals[p];
+    }
+  int64_t ju = 0;
+  for (int64_t j = 0; j < n; ++j) {
+    const int64_t km = std::min<int64_t>(kl, n - 1 - j);
+    int64_t jp = 0;
+    double best = std::fabs(AB(kv, j));
+    for (int64_t i = 1; i <= km; ++i) {
+      const double v = std::fabs(AB(kv + i, j));
+      if (v > best) {
+        best = v;
+        jp = i;
+      }
+    }
+    f->ipiv[j] = (int32_t)(j + jp);
+    if (AB(kv + jp, j) == 0.0)
+      return fail(ctx, AGGMG_ERR_SINGULAR, "coarsest operator is singular (SingularException)");
+    ju = std::max(ju, std::min<int64_t>(j + ku + jp, n - 1));
+    if (jp != 0)
+      for (int64_t c = j; c <= ju; ++c) std::swap(AB(kv + jp - (c - j), c), AB(kv - (c - j), c));
+    if (km > 0) {
+      const double rp = 1.0 / AB(kv, j);
+      for (int64_t i = 1; i <= km; ++i) AB(kv + i, j) *= rp;
+      for (int64_t c = j + 1; c <= ju; ++c) {
+        const double t = AB(kv - (c - j), c);
+        if (t != 0.0)
+          for (int64_t i = 1; i <= km; ++i) AB(kv + i - (c - j), c) -= AB(kv + i, j) * t;
+      }
+    }
+  }
+  return AGGMG_OK;
+}
+
+static void banded_solve(const BandedLU& f, double* b) {
+  const int64_t n = f.n, ldab = f.ldab;
+  const int kl = f.kl, kv = f.ku + f.kl;
+  auto AB = [&](int64_t r, int64_t c) -> double { return f.ab[(size_t)c * ldab + r]; };
+  if (kl > 0)
+    for (int64_t j = 0; j < n - 1; ++j) {
+      const int64_t lm = std::min<int64_t>(kl, n - 1 - j);
+      const int64_t l = f.ipiv[j];
+      if (l != j) std::swap(b[l], b[j]);
+      const double bj = b[j];
+      for (int64_t i = 1; i <= lm; ++i) b[j + i] -= bj * AB(kv + i, j);
+    }
+  for (int64_t j = n - 1; j >= 0; --j) {
+    b[j] /= AB(kv, j);
+    const double bj = b[j];
+    const int64_t lo = std::max<int64_t>(0, j - kv);
+    for (int64_t i = lo; i < j; ++i) b[i] -= bj * AB(kv - (j - i), j);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// hierarchy + V-cycle
+// ---------------------------------------------------------------------------------------------
+// structured transfer: every fine row's stored columns lie in the mc modes of coarse element
+// J = (fine element) / rho
+static int build_transfer(aggmg_ctx* ctx, const aggmg_op* L, int mf, int64_t nef, int hint_mc, TransferBtd* out,
+                          bool* ok) {
+  *ok = false;
+  if (!L->host_valid) return AGGMG_OK;
+  const HostCsr& h = L->host;
+  const int64_t Nf = L->m, Nc = L->n;
+  if (Nf != nef * mf) return AGGMG_OK;
+  for (int mc = 1; mc <= 16; ++mc) {
+    if (hint_mc > 0 && mc != hint_mc) continue;
+    if (Nc % mc) continue;
+    const int64_t nec = Nc / mc;
+    if (nec == 0 || nef % nec) continue;
+    const int64_t rho = nef / nec;
+    if (rho > 64) continue;
+    bool fits = true;
+    for (int64_t r = 0; r < Nf && fits; ++r) {
+      const int64_t J = (r / mf) / rho;
+      for (int32_t p = h.rowptr[r]; p < h.rowptr[r + 1]; ++p)
+        if (h.colind[p] < J * mc || h.colind[p] >= (J + 1) * mc) {
+          fits = false;
+          break;
+        }
+    }
+    if (!fits) continue;
+    std::vector<double> lf((size_t)Nf * mc, 0.0);
+    for (int64_t r = 0; r < Nf; ++r) {
+      const int64_t J = (r / mf) / rho;
+      for (int32_t p = h.rowptr[r]; p < h.rowptr[r + 1]; ++p) lf[r * mc + (h.colind[p] - J * mc)] = h.vals[p];
+    }
+    CHECK(dev_upload(ctx, lf, &out->lf));
+    out->mc = mc;
+    out->rho = (int)rho;
+    *ok = true;
+    return AGGMG_OK;
+  }
+  return AGGMG_OK;
+}
+
+extern "C" int aggmg_hier_free(aggmg_ctx* ctx, aggmg_hier* h) {
+  if (!ctx) return AGGMG_ERR_ARGUMENT;
+  if (!h) return AGGMG_OK;
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  for (auto& l : h->lv) {
+    for (double* p : {l.u[0], l.u[1], l.rhs, l.tmp})
+      if (p) (void)hipFree(p);
+    if (l.tb && l.tb->lf) (void)hipFree(l.tb->lf);
+  }
+  delete h;
+  return AGGMG_OK;
+}
+
+extern "C" int aggmg_hier_create(aggmg_ctx* ctx, int nlevels, aggmg_op* const* stiffness,
+                                 aggmg_smoother* const* smoothers, aggmg_op* const* interpolation,
+                                 int coarse_mode, aggmg_hier** out) {
+  if (!ctx || !out || !stiffness) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_hier_create: NULL argument");
+  *out = nullptr;
+  if (nlevels < 1 || nlevels > 16) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_hier_create: nlevels must be in 1..16");
+  if (nlevels > 1 && (!smoothers || !interpolation))
+    return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_hier_create: smoothers / interpolation missing");
+  if (coarse_mode != AGGMG_COARSE_HOST_BANDED) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_hier_create: unknown coarse_mode");
+  HIPCHK(hipSetDevice(ctx->device));
+  std::unique_ptr<aggmg_hier> h(new aggmg_hier());
+  h->coarse_mode = coarse_mode;
+  h->lv.resize(nlevels);
+  for (int k = 0; k < nlevels; ++k) {
+    Level& l = h->lv[k];
+    l.A = stiffness[k];
+    if (!l.A || l.A->m != l.A->n) return fail(ctx, AGGMG_ERR_DIMENSION, "aggmg_hier_create: stiffness must be square");
+    l.N = l.A->m;
+    if (k < nlevels - 1) {
+      l.S = smoothers[k];
+      l.L = interpolation[k];
+      if (!l.S || !l.L) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_hier_create: NULL smoother / interpolation");
+      if (l.S->N != l.N) return fail(ctx, AGGMG_ERR_DIMENSION, "aggmg_hier_create: smoother size mismatch at level " + std::to_string(k + 1));
+      if (l.L->m != l.N || l.L->n != stiffness[k + 1]->m)
+        return fail(ctx, AGGMG_ERR_DIMENSION, "aggmg_hier_create: interpolation size mismatch at level " + std::to_string(k + 1));
+      if (!l.L->csrT.rowptr) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_hier_create: interpolation must be uploaded with AGGMG_OP_TRANSFER");
+    }
+    for (double** p : {&l.u[0], &l.u[1], &l.rhs, &l.tmp})
+      HIPCHK(hipMalloc((void**)p, (size_t)std::max<int64_t>(l.N, 1) * sizeof(double)));
+  }
+  // structured transfers between consecutive levels whose fine side runs the fused kernel
+  for (int k = 0; k + 1 < nlevels; ++k) {
+    Level& l = h->lv[k];
+    if (!(l.S->btd && l.S->A == l.A)) continue;
+    int hint = 0;
+    if (k + 2 < nlevels && h->lv[k + 1].S && h->lv[k + 1].S->btd) hint = h->lv[k + 1].S->btd->m;
+    auto tb = std::make_unique<TransferBtd>();
+    bool ok = false;
+    CHECK(build_transfer(ctx, l.L, l.S->btd->m, l.S->btd->ne, hint, tb.get(), &ok));
+    if (ok) l.tb = std::move(tb);
+  }
+  // coarsest level: factor once
+  {
+    const aggmg_op* Ac = h->lv[nlevels - 1].A;
+    if (!Ac->host_valid) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_hier_create: host copy of the coarsest operator was released");
+    CHECK(banded_factor(ctx, Ac->host, Ac->m, &h->coarse));
+    h->h_coarse.assign(Ac->m, 0.0);
+  }
+  *out = h.release();
+  return AGGMG_OK;
+}
+
+static int coarse_solve(aggmg_ctx* ctx, aggmg_hier* h, const double* rhs_dev, double* u_dev) {
+  const int64_t n = h->coarse.n;
+  HIPCHK(hipMemcpyAsync(h->h_coarse.data(), rhs_dev, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  auto t0 = std::chrono::steady_clock::now();
+  banded_solve(h->coarse, h->h_coarse.data());
+  HIPCHK(hipMemcpyAsync(u_dev, h->h_coarse.data(), n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  h->last_coarse_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  return AGGMG_OK;
+}
+
+extern "C" int aggmg_vcycle_dev(aggmg_ctx* ctx, aggmg_hier* h, const double* x0, const double* b, int nPre,
+                                int nPost, double alpha, double* x_out) {
+  if (!ctx) return AGGMG_ERR_ARGUMENT;
+  if (!h || !x0 || !b || !x_out) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_vcycle: NULL argument");
+  if (nPre < 0 || nPost < 0) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_vcycle: negative sweep count");
+  if (x_out == x0 || x_out == b) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_vcycle: x_out must not alias x0 or b");
+  const int n = (int)h->lv.size();
+  h->last_coarse_ms = 0.0;
+  // ---- descend (src/solvers.jl:28-37) --------------------------------------------------------
+  for (int k = 0; k < n - 1; ++k) {
+    Level& l = h->lv[k];
+    Level& c = h->lv[k + 1];
+    const double* rhs = k == 0 ? b : l.rhs;
+    const double* uin = k == 0 ? x0 : nullptr;  // u[k] = zeros for k > 1 (:29-31)
+    const bool structured = l.S->btd && l.S->A == l.A;
+    if (structured && l.tb && nPre + 1 <= btd_max_sweeps(*l.S->btd, 0)) {
+      FusedArgs a = btd_args(*l.S->btd);
+      a.u_in = uin;
+      a.b = rhs;
+      a.u_out = l.u[0];
+      a.alpha = alpha;
+      a.nsweeps = nPre;
+      a.do_residual = 1;
+      a.lf_out = l.tb->lf;
+      a.rc_out = c.rhs;
+      a.mc_out = l.tb->mc;
+      a.rho_out = l.tb->rho;
+      ProfScope ps(ctx, AGGMG_KIND_FUSED_DOWN, k);
+      CHECK(launch_btd(ctx, *l.S->btd, a, nPre + 1));
+    } else {
+      if (structured) {
+        CHECK(btd_smooth(ctx, *l.S->btd, uin, rhs, alpha, nPre, l.u[0], k, l.N));
+      } else {
+        // generic sweeps, result in l.u[0]
+        const double* src = uin;
+        if (!src) {
+          HIPCHK(hipMemsetAsync(l.u[0], 0, l.N * sizeof(double), ctx->stream));
+          src = l.u[0];
+        }
+        if (nPre == 0 && src != l.u[0])
+          HIPCHK(hipMemcpyAsync(l.u[0], src, l.N * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+        for (int s = 0; s < nPre; ++s) {
+          double* dst;
+          if (l.S->kind == 0) {
+            dst = ((nPre - 1 - s) % 2 == 0) ? l.u[0] : l.u[1];
+            if (dst == src) {
+              HIPCHK(hipMemcpyAsync(l.u[1], src, l.N * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+              src = l.u[1];
+            }
+          } else {
+            dst = l.u[0];
+          }
+          CHECK(generic_sweep(ctx, l.A, l.S, src, rhs, alpha, dst, k));
+          src = dst;
+        }
+      }
+      {
+        ProfScope ps(ctx, AGGMG_KIND_RESIDUAL, k);
+        CHECK(launch_csr<kResidual>(ctx, l.A->csr, l.u[0], rhs, nullptr, 0.0, l.tmp));
+      }
+      ProfScope ps(ctx, AGGMG_KIND_RESTRICT, k);
+      CHECK(launch_csr<kSpmvSet>(ctx, l.L->csrT, l.tmp, nullptr, nullptr, 0.0, c.rhs));
+    }
+  }
+  // ---- coarsest solve (:39) ------------------------------------------------------------------
+  {
+    Level& c = h->lv[n - 1];
+    const double* rhs = n == 1 ? b : c.rhs;
+    double* dst = n == 1 ? x_out : c.u[0];
+    CHECK(coarse_solve(ctx, h, rhs, dst));
+  }
+  // ---- ascend (:41-47) -----------------------------------------------------------------------
+  for (int k = n - 2; k >= 0; --k) {
+    Level& l = h->lv[k];
+    Level& c = h->lv[k + 1];
+    const double* rhs = k == 0 ? b : l.rhs;
+    double* dst = k == 0 ? x_out : l.u[1];
+    const double* uc = (k + 1 == n - 1) ? c.u[0] : c.u[1];
+    const bool structured = l.S->btd && l.S->A == l.A;
+    if (structured && l.tb && nPost <= btd_max_sweeps(*l.S->btd, 0)) {
+      FusedArgs a = btd_args(*l.S->btd);
+      a.u_in = l.u[0];
+      a.b = rhs;
+      a.u_out = dst;
+      a.alpha = alpha;
+      a.nsweeps = nPost;
+      a.lf_in = l.tb->lf;
+      a.uc = uc;
+      a.mc_in = l.tb->mc;
+      a.rho_in = l.tb->rho;
+      ProfScope ps(ctx, AGGMG_KIND_FUSED_UP, k);
+      CHECK(launch_btd(ctx, *l.S->btd, a, std::max(nPost, 0)));
+    } else {
+      {
+        ProfScope ps(ctx, AGGMG_KIND_PROLONG, k);
+        CHECK(launch_csr<kSpmvAdd>(ctx, l.L->csr, uc, nullptr, nullptr, 0.0, l.u[0]));
+      }
+      if (structured) {
+        CHECK(btd_smooth(ctx, *l.S->btd, l.u[0], rhs, alpha, nPost, dst, k, l.N));
+      } else {
+        const double* src = l.u[0];
+        if (nPost == 0) HIPCHK(hipMemcpyAsync(dst, src, l.N * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+        double* alt = (dst == l.u[1]) ? l.tmp : l.u[1];
+        for (int s = 0; s < nPost; ++s) {
+          double* d2;
+          if (l.S->kind == 0) {
+            d2 = ((nPost - 1 - s) % 2 == 0) ? dst : alt;
+            if (d2 == src) return fail(ctx, AGGMG_ERR_UNSUPPORTED, "internal: ping-pong aliasing");
+          } else {
+            d2 = (s == nPost - 1) ? dst : l.u[0];
+          }
+          CHECK(generic_sweep(ctx, l.A, l.S, src, rhs, alpha, d2, k));
+          src = d2;
+        }
+      }
+    }
+  }
+  return AGGMG_OK;
+}
+
+extern "C" int aggmg_vcycle(aggmg_ctx* ctx, aggmg_hier* h, const double* x0, const double* b, int nPre, int nPost,
+                            double alpha, double* x_out) {
+  if (!ctx) return AGGMG_ERR_ARGUMENT;
+  if (!h || !x0 || !b || !x_out) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_vcycle: NULL argument");
+  HIPCHK(hipSetDevice(ctx->device));
+  const int64_t N = h->lv[0].N;
+  DevVec dx(ctx), db(ctx), dout(ctx);
+  CHECK(dx.alloc(N, x0));
+  CHECK(db.alloc(N, b));
+  CHECK(dout.alloc(N, nullptr));
+  CHECK(aggmg_vcycle_dev(ctx, h, dx.p, db.p, nPre, nPost, alpha, dout.p));
+  return dout.fetch(N, x_out);
+}
+
+extern "C" int aggmg_hier_last_coarse_ms(aggmg_ctx* ctx, const aggmg_hier* h, double* ms) {
+  if (!ctx || !h || !ms) return AGGMG_ERR_ARGUMENT;
+  *ms = h->last_coarse_ms;
+  return AGGMG_OK;
+}

@@ -1,0 +1,355 @@
+// Device kernels of libaggmg_hip (gfx950 / CDNA4, wave64, fp64).
+//
+// Two families:
+//  * generic CSR row kernels (any assembled matrix: CG levels, unstructured transfers,
+//    Schwarz blocks) -- LPR lanes per row, coalesced index/value reads, __shfl_xor reduction;
+//  * the LDS-tiled fused block-tridiagonal ("BTD") kernel for DG / agglomerated-DG levels:
+//    one workgroup owns a tile of elements plus a halo, keeps the iterate in LDS and the
+//    operator rows in registers, and runs  [prolong-add] -> S block-Jacobi sweeps ->
+//    [residual -> restriction]  on one pass over HBM (temporal blocking: the operator is read
+//    once per launch, not once per sweep).
+//
+// The path is HBM-bound fp64 streaming (0.17 flop/B): no MFMA on purpose.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace aggmg {
+
+constexpr int kThreads = 256;
+
+// ------------------------------------------------------------------------------------------
+// generic CSR
+// ------------------------------------------------------------------------------------------
+struct CsrView {
+  const int32_t* rowptr;
+  const int32_t* colind;
+  const double* vals;
+  int64_t nrows;
+};
+
+enum CsrMode : int {
+  kSpmvSet = 0,   // y = A x                      (restriction with the transposed orientation)
+  kSpmvAdd = 1,   // y += A x                     (prolongation-add,     src/solvers.jl:42)
+  kResidual = 2,  // y = b - A x                  (src/solvers.jl:33,36,44)
+  kJacobi = 3     // y = x + alpha*((b - A x)/d)  (JacobiSmoother,       src/smoother.jl:56-58)
+};
+
+// LPR lanes cooperate on one row; rows are contiguous across the workgroup so rowptr / b / y
+// accesses are coalesced and the value / index streams are read in LPR-wide contiguous pieces.
+template <int LPR, int MODE>
+__global__ __launch_bounds__(kThreads) void csr_row_kernel(CsrView A, const double* __restrict__ x,
+                                                           const double* __restrict__ b,
+                                                           const double* __restrict__ dg,
+                                                           double alpha, double* __restrict__ y) {
+  constexpr int kRows = kThreads / LPR;
+  const int64_t row = (int64_t)blockIdx.x * kRows + threadIdx.x / LPR;
+  const int sub = threadIdx.x % LPR;
+  double acc = 0.0;
+  if (row < A.nrows) {
+    const int p0 = A.rowptr[row], p1 = A.rowptr[row + 1];
+    for (int p = p0 + sub; p < p1; p += LPR) acc += A.vals[p] * x[A.colind[p]];
+  }
+#pragma unroll
+  for (int off = LPR / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off, LPR);
+  if (row < A.nrows && sub == 0) {
+    if (MODE == kSpmvSet) y[row] = acc;
+    if (MODE == kSpmvAdd) y[row] += acc;
+    if (MODE == kResidual) y[row] = b[row] - acc;
+    if (MODE == kJacobi) {
+      const double r = b[row] - acc;
+      const double yy = r / dg[row];
+      y[row] = x[row] + alpha * yy;
+    }
+  }
+}
+
+// y[inds] (+)= Binv_blk * r[inds]   -- generic block apply (arbitrary, possibly overlapping,
+// index lists: BlockJacobi / AdditiveSchwarz / HybridSchwarz, src/smoother.jl:6-18,30-46,69-81).
+// One thread per (block, local row).  ATOMIC for overlapping blocks (y pre-zeroed).
+template <bool ATOMIC>
+__global__ __launch_bounds__(kThreads) void block_apply_kernel(const double* __restrict__ binv,
+                                                               const int32_t* __restrict__ inds,
+                                                               int m, int64_t nb,
+                                                               const double* __restrict__ r,
+                                                               double* __restrict__ y) {
+  const int64_t t = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  const int64_t blk = t / m;
+  const int i = (int)(t - blk * m);
+  if (blk >= nb) return;
+  const double* Bi = binv + (blk * m + i) * m;
+  const int32_t* id = inds + blk * m;
+  double acc = 0.0;
+  for (int j = 0; j < m; ++j) acc += Bi[j] * r[id[j]];
+  if (ATOMIC)
+    atomicAdd(&y[id[i]], acc);
+  else
+    y[id[i]] = acc;
+}
+
+// out = (u ? u : 0) + alpha * (y / (cnt ? cnt : 1))
+__global__ __launch_bounds__(kThreads) void axpy_scaled_kernel(int64_t n, const double* __restrict__ u,
+                                                               const double* __restrict__ y,
+                                                               const double* __restrict__ cnt,
+                                                               double alpha, double* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (i >= n) return;
+  double v = y[i];
+  if (cnt) v = v / cnt[i];
+  v = alpha * v;
+  out[i] = u ? u[i] + v : v;
+}
+
+// ------------------------------------------------------------------------------------------
+// fused block-tridiagonal kernel
+// ------------------------------------------------------------------------------------------
+// Level data, all fp64, row-major per DoF row (row = e*M + i):
+//   binv [N][M]  rows of the inverse of the diagonal block  B_e^{-1}
+//   dblk [N][M]  rows of the diagonal block                 D_e  (= B_e)
+// CMP (nodal DG): the sub-diagonal block has ONE non-zero column c_sub, the super-diagonal
+// block ONE non-zero row r_sup:
+//   scol [N]     Sub_e[:, c_sub]        pcol [N]   (B_e^{-1} Sub_e)[:, c_sub]
+//   qrow [ne][M] Sup_e[r_sup, :]
+// dense (agglomerated levels, any pattern):
+//   sub, sup [N][M] rows of Sub_e, Sup_e;   P, Q [N][M] rows of B_e^{-1}Sub_e, B_e^{-1}Sup_e
+// With these, one damped block-Jacobi sweep  u <- u + alpha*B^{-1}(b - A u)  is the stencil
+//   u_e <- u_e + alpha*( g_e - P_e u_{e-1} - Q_e u_{e+1} - u_e ),   g_e = B_e^{-1} b_e
+// (B^{-1}D = I is used algebraically; differs from the reference's LU solve at round-off only).
+struct BtdLevel {
+  const double *binv, *dblk;
+  const double *scol, *pcol, *qrow;
+  const double *sub, *sup, *P, *Q;
+  int64_t ne;
+  int c_sub, r_sup;
+};
+
+struct FusedArgs {
+  BtdLevel lv;
+  const double* u_in;  // nullptr: iterate starts at zero (src/solvers.jl:29-31)
+  const double* b;
+  double* u_out;       // nullptr: iterate not stored (residual-only call)
+  double alpha;
+  int nsweeps;
+  // optional prolongation-add before the sweeps: u += LF_in * uc   (src/solvers.jl:42)
+  const double* lf_in;  // [N][mc_in] rows of L for the owning coarse element
+  const double* uc;
+  int mc_in, rho_in;
+  // optional residual after the sweeps (src/solvers.jl:36), stored and/or restricted
+  int do_residual;
+  double* r_out;         // may be nullptr
+  const double* lf_out;  // [N][mc_out]; nullptr: no restriction
+  double* rc_out;        // rc = L' r
+  int mc_out, rho_out;
+  // tiling
+  int owned;      // owned elements per tile (multiple of rho_out)
+  int halo_left;  // elements of halo on the left of the owned range
+};
+
+template <int M, bool CMP, int NS>
+__global__ __launch_bounds__(kThreads) void btd_fused_kernel(FusedArgs a) {
+  constexpr int EPS = kThreads / M;  // elements per slab
+  constexpr int TE = EPS * NS;       // elements per tile (owned + halos)
+  extern __shared__ double lds[];
+  // two iterate buffers, each padded by one zero element on both sides: index (x*M + j),
+  // x in [-1, TE]
+  double* buf0 = lds + M;
+  double* buf1 = lds + (TE + 2) * M + M;
+
+  const int tid = threadIdx.x;
+  const bool active = tid < EPS * M;
+  const int le = tid / M;
+  const int i = tid - le * M;
+  const int64_t ne = a.lv.ne;
+  const int64_t e0 = (int64_t)blockIdx.x * a.owned - a.halo_left;  // element at x = 0
+
+  if (tid < M) {
+    buf0[-M + tid] = 0.0;
+    buf0[TE * M + tid] = 0.0;
+    buf1[-M + tid] = 0.0;
+    buf1[TE * M + tid] = 0.0;
+  }
+
+  double g[NS], bb[NS], uu[NS];
+  double bi[NS][M];                              // B^{-1} rows, dead after g is formed
+  double binv_r[NS], sc[NS], pc[NS], qv[NS][M];  // CMP
+  double Pr[NS][M], Qr[NS][M];                   // dense
+  bool valid[NS];
+
+  // ---- load phase: everything this tile needs from HBM, issued up front --------------------
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const int x = s * EPS + le;
+    const int64_t e = e0 + x;
+    valid[s] = active && e >= 0 && e < ne;
+    const int64_t row = e * M + i;
+    uu[s] = 0.0;
+    bb[s] = 0.0;
+#pragma unroll
+    for (int j = 0; j < M; ++j) bi[s][j] = 0.0;
+    if (valid[s]) {
+#pragma unroll
+      for (int j = 0; j < M; ++j) bi[s][j] = a.lv.binv[row * M + j];
+      bb[s] = a.b[row];
+      if (a.u_in) uu[s] = a.u_in[row];
+      if (CMP) {
+        sc[s] = a.lv.scol[row];
+        pc[s] = a.lv.pcol[row];
+#pragma unroll
+        for (int j = 0; j < M; ++j) qv[s][j] = a.lv.qrow[e * M + j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+          Pr[s][j] = a.lv.P[row * M + j];
+          Qr[s][j] = a.lv.Q[row * M + j];
+        }
+      }
+      if (a.lf_in) {  // u += L uc : J = e / rho, ascending mode order (CSC scatter order)
+        const int64_t J = e / a.rho_in;
+        double add = 0.0;
+        for (int c = 0; c < a.mc_in; ++c) add += a.lf_in[row * a.mc_in + c] * a.uc[J * a.mc_in + c];
+        uu[s] += add;
+      }
+    } else {
+      if (CMP) {
+        sc[s] = 0.0;
+        pc[s] = 0.0;
+#pragma unroll
+        for (int j = 0; j < M; ++j) qv[s][j] = 0.0;
+      } else {
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+          Pr[s][j] = 0.0;
+          Qr[s][j] = 0.0;
+        }
+      }
+    }
+    binv_r[s] = 0.0;
+#pragma unroll
+    for (int j = 0; j < M; ++j)
+      if (j == a.lv.r_sup) binv_r[s] = bi[s][j];
+    if (active) {
+      buf0[x * M + i] = uu[s];
+      buf1[x * M + i] = bb[s];
+    }
+  }
+  __syncthreads();
+  // g = B^{-1} b  (the element's whole b_e is read back from LDS)
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const int x = s * EPS + le;
+    g[s] = 0.0;
+    if (active) {
+      double acc = 0.0;
+#pragma unroll
+      for (int j = 0; j < M; ++j) acc += bi[s][j] * buf1[x * M + j];
+      g[s] = acc;
+    }
+  }
+  __syncthreads();
+
+  // ---- sweeps: LDS ping-pong ---------------------------------------------------------------
+  double* cur = buf0;
+  double* nxt = buf1;
+  for (int sw = 0; sw < a.nsweeps; ++sw) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const int x = s * EPS + le;
+      if (active) {
+        const double* um = cur + (x - 1) * M;
+        const double* up = cur + (x + 1) * M;
+        double acc = g[s];
+        if (CMP) {
+          acc -= pc[s] * um[a.lv.c_sub];
+          double dot = 0.0;
+#pragma unroll
+          for (int j = 0; j < M; ++j) dot += qv[s][j] * up[j];
+          acc -= binv_r[s] * dot;
+        } else {
+#pragma unroll
+          for (int j = 0; j < M; ++j) acc -= Pr[s][j] * um[j];
+#pragma unroll
+          for (int j = 0; j < M; ++j) acc -= Qr[s][j] * up[j];
+        }
+        double un = uu[s] + a.alpha * (acc - uu[s]);
+        if (!valid[s]) un = 0.0;
+        uu[s] = un;
+        nxt[x * M + i] = un;
+      }
+    }
+    __syncthreads();
+    double* t = cur;
+    cur = nxt;
+    nxt = t;
+  }
+
+  // ---- store the iterate of the owned elements ---------------------------------------------
+  const int xo0 = a.halo_left, xo1 = a.halo_left + a.owned;
+  if (a.u_out) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const int x = s * EPS + le;
+      if (valid[s] && x >= xo0 && x < xo1) a.u_out[(e0 + x) * M + i] = uu[s];
+    }
+  }
+
+  if (!a.do_residual) return;
+
+  // ---- residual r = b - A u on the owned elements, ascending column order -------------------
+  double rr[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const int x = s * EPS + le;
+    rr[s] = 0.0;
+    if (valid[s] && x >= xo0 && x < xo1) {
+      const int64_t e = e0 + x;
+      const int64_t row = e * M + i;
+      const double* um = cur + (x - 1) * M;
+      const double* ux = cur + x * M;
+      const double* up = cur + (x + 1) * M;
+      double t = 0.0;
+      if (CMP) {
+        t += sc[s] * um[a.lv.c_sub];
+#pragma unroll
+        for (int j = 0; j < M; ++j) t += a.lv.dblk[row * M + j] * ux[j];
+        if (i == a.lv.r_sup) {
+#pragma unroll
+          for (int j = 0; j < M; ++j) t += qv[s][j] * up[j];
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < M; ++j) t += a.lv.sub[row * M + j] * um[j];
+#pragma unroll
+        for (int j = 0; j < M; ++j) t += a.lv.dblk[row * M + j] * ux[j];
+#pragma unroll
+        for (int j = 0; j < M; ++j) t += a.lv.sup[row * M + j] * up[j];
+      }
+      rr[s] = bb[s] - t;
+      if (a.r_out) a.r_out[row] = rr[s];
+    }
+  }
+  if (!a.lf_out) return;
+
+  // ---- restriction rc = L' r: r through LDS (the idle buffer), one thread per (J, mode) -----
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const int x = s * EPS + le;
+    if (active) nxt[x * M + i] = rr[s];
+  }
+  __syncthreads();
+  const int rho = a.rho_out, mc = a.mc_out;
+  const int ncoarse = a.owned / rho;  // owned coarse elements of this tile
+  const int64_t J0 = ((int64_t)blockIdx.x * a.owned) / rho;
+  const int64_t nec = ne / rho;
+  for (int t = tid; t < ncoarse * mc; t += kThreads) {
+    const int Jl = t / mc, c = t - Jl * mc;
+    const int64_t J = J0 + Jl;
+    if (J >= nec) continue;
+    const int xb = a.halo_left + Jl * rho;       // first fine element (tile-local)
+    const int64_t rowb = (e0 + xb) * (int64_t)M;  // first fine row (global)
+    double acc = 0.0;
+    for (int k = 0; k < rho * M; ++k) acc += a.lf_out[(rowb + k) * mc + c] * nxt[xb * M + k];
+    a.rc_out[J * mc + c] = acc;
+  }
+}
+
+}  // namespace aggmg

@@ -1,0 +1,161 @@
+/*
+ * aggmg_hip.h -- C ABI of libaggmg_hip.so: the MI355X (gfx950) V-cycle hot path of
+ * AgglomerationMultigrid1D (reference: Julia, /root/reference at build time).
+ *
+ * The reference has no FFI; its seams are Julia multiple dispatch.  Every
+ * entry point below names the reference interface it replaces (file:line in the reference tree).
+ * A Julia `ccall` shim binding exactly these symbols is in julia/AggMGHip.jl and described in
+ * INTEGRATION.md; the Python mirror (agglomerationmultigrid1d_amd/) binds them through ctypes.
+ *
+ * Conventions
+ *   - plain C, no torch / HIP types in any signature; handles are opaque pointers;
+ *   - every function returns an int status (0 = ok, < 0 = error class below) and records a
+ *     message retrievable with aggmg_last_error();
+ *   - "host" entry points take caller-owned host pointers (e.g. Julia GC-owned arrays), are
+ *     synchronous on return and never modify their inputs unless documented (`*_inout`);
+ *   - "_dev" entry points take device pointers valid on the context's device and enqueue on the
+ *     context's stream without synchronising;
+ *   - all vectors are fp64, matrices arrive as Julia SparseMatrixCSC{Float64,Int64}
+ *     (colptr[n+1], rowval[nnz], nzval[nnz], 1-based when one_based != 0);
+ *   - one context is not thread-safe (the reference is single-threaded).
+ */
+#ifndef AGGMG_HIP_H
+#define AGGMG_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Error classes; the Julia shim maps them back to the reference's exception types. */
+#define AGGMG_OK 0
+#define AGGMG_ERR_ARGUMENT (-1)    /* ArgumentError      src/mesh_heirarchy.jl:33-39,142-148 */
+#define AGGMG_ERR_DIMENSION (-2)   /* DimensionMismatch  src/block_diagonal.jl:138,167-169,300-302 */
+#define AGGMG_ERR_SINGULAR (-3)    /* SingularException  la.lu in src/smoother.jl:160 */
+#define AGGMG_ERR_HIP (-4)         /* HIP runtime failure (no reference counterpart) */
+#define AGGMG_ERR_UNSUPPORTED (-5) /* ErrorException     error(...) paths */
+
+typedef struct aggmg_ctx aggmg_ctx;
+typedef struct aggmg_op aggmg_op;             /* device mirror of one SparseMatrixCSC */
+typedef struct aggmg_smoother aggmg_smoother; /* device mirror of one AbstractSmoother */
+typedef struct aggmg_hier aggmg_hier;         /* device mirror of one MeshHierarchy */
+
+/* ---- context ------------------------------------------------------------------------------ */
+int aggmg_create(int device_id, aggmg_ctx** out);
+int aggmg_destroy(aggmg_ctx* ctx);
+const char* aggmg_last_error(aggmg_ctx* ctx); /* ctx may be NULL: last error of failed create */
+/* Run on a caller-provided hipStream_t (e.g. torch's current stream).  NULL restores the
+ * context's own non-blocking stream. */
+int aggmg_set_stream(aggmg_ctx* ctx, void* hip_stream);
+int aggmg_synchronize(aggmg_ctx* ctx);
+/* Raw device memory owned by the context's device (plumbing for harnesses without torch). */
+int aggmg_dev_alloc(aggmg_ctx* ctx, int64_t nbytes, void** out);
+int aggmg_dev_free(aggmg_ctx* ctx, void* ptr);
+int aggmg_memcpy_h2d(aggmg_ctx* ctx, void* dst_dev, const void* src_host, int64_t nbytes);
+int aggmg_memcpy_d2h(aggmg_ctx* ctx, void* dst_host, const void* src_dev, int64_t nbytes);
+
+/* ---- operators: H.mStiffness[k], H.mInterpolation[k] (src/mesh_heirarchy.jl:20,26) ---------- */
+#define AGGMG_OP_STIFFNESS 0 /* used as A*u only                    src/solvers.jl:33,36,44 */
+#define AGGMG_OP_TRANSFER 1  /* used as L*v and L'*v                src/solvers.jl:36,42   */
+/* Upload a SparseMatrixCSC (m x n).  The device keeps a row-gather form (CSR, int32 indices)
+ * and, for transfers, the transposed orientation too (the CSC arrays as given are the CSR of
+ * L').  Index maps are preserved exactly: entry order inside a row/column is ascending, explicit
+ * zeros stay stored.  Rejects dimensions or nnz >= 2^31 (AGGMG_ERR_ARGUMENT). */
+int aggmg_csc_upload(aggmg_ctx* ctx, int64_t m, int64_t n, const int64_t* colptr,
+                     const int64_t* rowval, const double* nzval, int one_based, int kind,
+                     aggmg_op** out);
+int aggmg_op_free(aggmg_ctx* ctx, aggmg_op* op);
+int aggmg_op_shape(aggmg_ctx* ctx, const aggmg_op* op, int64_t* m, int64_t* n, int64_t* nnz);
+/* Read the device index maps back (bit-exactness tests of the transfer index maps).
+ * transposed == 0: CSR of the matrix (rowptr[m+1], colind[nnz], vals[nnz]);
+ * transposed != 0: CSR of its transpose (rowptr[n+1], ...), transfers only.  0-based int32. */
+int aggmg_op_download(aggmg_ctx* ctx, const aggmg_op* op, int transposed, int32_t* rowptr,
+                      int32_t* colind, double* vals);
+/* Free the host-side copy kept for smoother set-up once all smoothers on this op exist. */
+int aggmg_op_release_host(aggmg_ctx* ctx, aggmg_op* op);
+
+/* ---- smoothers: src/smoother.jl ------------------------------------------------------------- */
+/* dg_smoother(mesh, A, :blockJac) src/smoother.jl:153-165 and cg_smoother(..., :addSchwarz /
+ * :hybridSchwarz) :104-134.  blockinds is the reference's mBlockInds Matrix{Int64}(m x nb),
+ * column-major, 1-based when one_based != 0.  Diagonal blocks A[inds,inds] are extracted and
+ * factorised with partial pivoting (exact zero pivot -> AGGMG_ERR_SINGULAR naming the block).
+ * kind: 0 = BlockJacobi (also AdditiveSchwarz: same apply loop, blocks may overlap),
+ *       1 = HybridSchwarz (result divided by the per-node block count, src/smoother.jl:24-46). */
+int aggmg_blockjacobi_setup(aggmg_ctx* ctx, aggmg_op* A, int64_t m, int64_t nb,
+                            const int64_t* blockinds, int one_based, int kind,
+                            aggmg_smoother** out);
+/* dg_smoother / cg_smoother (..., :jac): JacobiSmoother(Diagonal(A)) src/smoother.jl:95-102,146-152 */
+int aggmg_jacobi_setup(aggmg_ctx* ctx, aggmg_op* A, aggmg_smoother** out);
+int aggmg_smoother_free(aggmg_ctx* ctx, aggmg_smoother* sm);
+/* apply_smoother(S, B; alpha) -> alpha * (S \ B), B is N x ncols column-major, result in Y.
+ * src/smoother.jl:6-18,30-46,56-58,69-81.  Host pointers. */
+int aggmg_smoother_apply(aggmg_ctx* ctx, aggmg_smoother* sm, const double* B, int64_t N,
+                         int64_t ncols, double alpha, double* Y);
+/* 1 when the (operator, smoother) pair was recognised as block-tridiagonal with contiguous
+ * aligned element blocks and runs the LDS-tiled fused kernels; 0 = generic CSR path. */
+int aggmg_smoother_is_structured(aggmg_ctx* ctx, const aggmg_smoother* sm, int* out);
+
+/* ---- fused hot-path operations -------------------------------------------------------------- */
+/* nsweeps x  `u += apply_smoother(S, b - A*u; alpha)`   src/solvers.jl:32-35,43-46, :199 */
+int aggmg_smooth(aggmg_ctx* ctx, aggmg_op* A, aggmg_smoother* sm, double* u_inout,
+                 const double* b, double alpha, int nsweeps);
+/* r = b - A*u                                           src/solvers.jl:33,36,44 */
+int aggmg_residual(aggmg_ctx* ctx, aggmg_op* A, const double* u, const double* b, double* r_out);
+/* rc = L' * r                                           src/solvers.jl:36 */
+int aggmg_restrict(aggmg_ctx* ctx, aggmg_op* L, const double* r, double* rc_out);
+/* u += L * uc                                           src/solvers.jl:42 */
+int aggmg_prolong_add(aggmg_ctx* ctx, aggmg_op* L, const double* uc, double* u_inout);
+/* Device-pointer variants (asynchronous on the context stream).  u_out may equal u_in. */
+int aggmg_smooth_dev(aggmg_ctx* ctx, aggmg_op* A, aggmg_smoother* sm, const double* u_in,
+                     const double* b, double alpha, int nsweeps, double* u_out);
+int aggmg_residual_dev(aggmg_ctx* ctx, aggmg_op* A, const double* u, const double* b,
+                       double* r_out);
+int aggmg_restrict_dev(aggmg_ctx* ctx, aggmg_op* L, const double* r, double* rc_out);
+int aggmg_prolong_add_dev(aggmg_ctx* ctx, aggmg_op* L, const double* uc, double* u_inout);
+
+/* ---- hierarchy: MeshHierarchy + multigrid_v_cycle ------------------------------------------- */
+#define AGGMG_COARSE_HOST_BANDED 0 /* factor once on the host (banded LU, partial pivoting) */
+/* Mirrors the operator vectors of `struct MeshHierarchy` src/mesh_heirarchy.jl:17-28:
+ * stiffness[nlevels], smoothers[nlevels-1] (the coarsest level is solved directly,
+ * src/solvers.jl:39), interpolation[nlevels-1] with interpolation[k]: level k+1 -> level k.
+ * Level 0 is the finest. */
+int aggmg_hier_create(aggmg_ctx* ctx, int nlevels, aggmg_op* const* stiffness,
+                      aggmg_smoother* const* smoothers, aggmg_op* const* interpolation,
+                      int coarse_mode, aggmg_hier** out);
+int aggmg_hier_free(aggmg_ctx* ctx, aggmg_hier* h);
+/* multigrid_v_cycle(H, x0, b; nPre, nPost, alpha) -> x    src/solvers.jl:19-50.
+ * x0 and b are not modified (src/solvers.jl:25-26); x_out may alias neither. */
+int aggmg_vcycle(aggmg_ctx* ctx, aggmg_hier* h, const double* x0, const double* b, int nPre,
+                 int nPost, double alpha, double* x_out);
+int aggmg_vcycle_dev(aggmg_ctx* ctx, aggmg_hier* h, const double* x0, const double* b, int nPre,
+                     int nPost, double alpha, double* x_out);
+/* Milliseconds the last aggmg_vcycle* call spent in the coarsest direct solve (host path:
+ * D2H + solve + H2D, measured with the host clock). */
+int aggmg_hier_last_coarse_ms(aggmg_ctx* ctx, const aggmg_hier* h, double* ms);
+
+/* ---- measurement ---------------------------------------------------------------------------- */
+/* HIP-event timing of kernel launches on the context stream, by tag = kind * 16 + level
+ * (level < 16; level 0 for the stand-alone fused ops).  While enabled every launch is bracketed
+ * by two events; aggmg_profile_collect synchronises and returns per-tag total ms and counts
+ * (arrays of AGGMG_PROFILE_NTAGS), then resets. */
+#define AGGMG_PROFILE_NTAGS 256
+#define AGGMG_KIND_FUSED_DOWN 0 /* [u=0|x0] -> nPre sweeps -> residual -> restriction */
+#define AGGMG_KIND_FUSED_UP 1   /* prolong-add -> nPost sweeps */
+#define AGGMG_KIND_SMOOTH 2     /* structured multi-sweep smoother kernel */
+#define AGGMG_KIND_RESIDUAL 3
+#define AGGMG_KIND_RESTRICT 4
+#define AGGMG_KIND_PROLONG 5
+#define AGGMG_KIND_JACOBI 6      /* generic CSR fused point-Jacobi sweep */
+#define AGGMG_KIND_BLOCK_APPLY 7 /* generic gather block apply */
+#define AGGMG_KIND_OTHER 8
+int aggmg_profile_enable(aggmg_ctx* ctx, int on);
+int aggmg_profile_collect(aggmg_ctx* ctx, double* total_ms, int64_t* counts);
+
+/* Library / build identification ("aggmg_hip gfx950 ..."). */
+const char* aggmg_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AGGMG_HIP_H */
