@@ -1,0 +1,417 @@
+"""O(n) set-up of the operators the hot path consumes, for the uniform-mesh model problem.
+
+The reference assembles `G, D, C`, `A = C - D*(M\\G)`, the agglomerated levels and their
+Galerkin operators through a pointer-y object graph with O(n^2) traps, which
+cannot build the 2^20..2^24-element configurations of BASELINE.json.  This module produces the
+same matrices with vectorised NumPy on block-banded arrays:
+
+    dg_flux_operators(::DgMesh)        src/dg_mesh.jl:144-336      -> DgLevel
+    dg_flux_rhs(::DgMesh)              src/dg_mesh.jl:342-457      -> DgLevel.rhs()
+    A = C - D*(M_LU \\ G)               src/mesh_heirarchy.jl:71-72 -> _stiffness_blocks
+    aggdg_dg_interpolation             src/interpolation.jl:270-292
+    aggdg_aggdg_interpolation          src/interpolation.jl:226-264
+    Galerkin L'XL on G, D, C           src/mesh_heirarchy.jl:98-103
+    agglomerated mass matrices         src/agglomerated_dg_mesh.jl:444-461,611-628
+
+Values agree with the loop-for-loop CPU restatement at small n to round-off and the transfer
+index maps (colptr / rowval of every L) agree bit for bit -- tests/test_uniform_setup.py.
+Only the shapes the BASELINE configurations need are covered: a nodal DG fine level (any p >= 0)
+followed by agglomerated levels (pAgg in {0,1}) with uniform ratios.  It is set-up code: the hot
+path itself never runs here.
+"""
+import math
+
+import numpy as np
+import scipy.sparse as sp
+
+
+# ------------------------------------------------------------------------------------------
+# reference-element numerics (src/legendre.jl, src/gauss_quad.jl, src/reference_element.jl)
+# ------------------------------------------------------------------------------------------
+def legendre_vandermonde(x, p, deriv=False):
+    """Values (and derivatives) of P_0..P_p at points x by the three-term recurrence
+    (src/legendre.jl:14-25,44-58).  -> (len(x), p+1)"""
+    x = np.atleast_1d(np.asarray(x, dtype=np.float64))
+    F = np.zeros((len(x), p + 1))
+    Dv = np.zeros((len(x), p + 1))
+    F[:, 0] = 1.0
+    if p >= 1:
+        F[:, 1] = x
+        Dv[:, 1] = 1.0
+    for i in range(2, p + 1):
+        F[:, i] = ((2 * i - 1) * x * F[:, i - 1] - (i - 1) * F[:, i - 2]) / i
+        Dv[:, i] = (2 * i - 1) * F[:, i - 1] + Dv[:, i - 2]
+    return (F, Dv) if deriv else F
+
+
+def gauss_quad(p):
+    """Golub-Welsch rule exact to degree p (src/gauss_quad.jl:6-13)."""
+    n = int(math.ceil((p + 1) / 2))
+    k = np.arange(1, n, dtype=np.float64)
+    off = k / np.sqrt(4 * k**2 - 1)
+    ev, evec = np.linalg.eigh(np.diag(off, 1) + np.diag(off, -1))
+    return ev, 2 * evec[0, :]**2
+
+
+class RefElement:
+    """src/reference_element.jl:15-57: nodes [-1, 1, cos(pi i/p)], nodal basis = inv(Vandermonde),
+    Gauss rule of degree 2p, reference mass matrix."""
+
+    def __init__(self, p):
+        self.p = p
+        x = np.zeros(p + 1)
+        if p >= 1:
+            x[:2] = [-1.0, 1.0]
+            x[2:] = np.cos(np.pi * np.arange(1, p) / p)
+        self.nodes = x
+        self.coeff = np.linalg.inv(legendre_vandermonde(x, p))
+        self.gq, self.gw = gauss_quad(2 * p)
+        F, Dv = legendre_vandermonde(self.gq, p, deriv=True)
+        nq = len(self.gq)
+        # basis values / derivatives at the Gauss points: one dot product per (point, function),
+        # as src/reference_element.jl:75-90 does
+        self.phi = np.array([[np.dot(self.coeff[:, i], F[l]) for i in range(p + 1)] for l in range(nq)])
+        self.dphi = np.array([[np.dot(self.coeff[:, i], Dv[l]) for i in range(p + 1)] for l in range(nq)])
+        M = np.zeros((p + 1, p + 1))
+        for j in range(p + 1):
+            for i in range(j + 1):
+                for l in range(nq):
+                    M[i, j] += self.gw[l] * self.phi[l, i] * self.phi[l, j]
+        self.mass = np.triu(M) + np.triu(M, 1).T
+
+    def basis_at(self, xi):
+        return legendre_vandermonde(xi, self.p) @ self.coeff
+
+
+# ------------------------------------------------------------------------------------------
+# block-banded helpers
+# ------------------------------------------------------------------------------------------
+def _shift_up(X):
+    """Y[k] = X[k+1], zero at the end"""
+    Y = np.zeros_like(X)
+    Y[:-1] = X[1:]
+    return Y
+
+
+def _shift_down(X):
+    """Y[k] = X[k-1], zero at the start"""
+    Y = np.zeros_like(X)
+    Y[1:] = X[:-1]
+    return Y
+
+
+def _lt_x_l(Lrow, X, Lcol):
+    """batched Lrow[k]' @ X[k] @ Lcol[k]"""
+    return np.matmul(np.matmul(Lrow.transpose(0, 2, 1), X), Lcol)
+
+
+def block_tridiag_to_csc(sub, diag, sup, keep_zeros=False):
+    """CSC (0-based int64 colptr/rowval, values) of the block-tridiagonal matrix with blocks
+    sub[k] = (k, k-1), diag[k] = (k, k), sup[k] = (k, k+1), keeping the numerically non-zero
+    entries (the pattern `C - D*X` has in SparseArrays) in ascending row order
+    per column."""
+    ne, m, _ = diag.shape
+    # column strip of element k: rows of elements k-1 (sup[k-1]), k (diag[k]), k+1 (sub[k+1])
+    strip = np.zeros((ne, m, 3 * m))
+    strip[:, :, m:2 * m] = diag.transpose(0, 2, 1)
+    if ne > 1:
+        strip[1:, :, 0:m] = sup[:-1].transpose(0, 2, 1)
+        strip[:-1, :, 2 * m:] = sub[1:].transpose(0, 2, 1)
+    mask = np.ones(strip.shape, dtype=bool) if keep_zeros else (strip != 0.0)
+    mask[0, :, 0:m] = False
+    mask[-1, :, 2 * m:] = False
+    rows = (np.arange(ne, dtype=np.int64)[:, None, None] - 1) * m + np.arange(3 * m, dtype=np.int64)[None, None, :]
+    rows = np.broadcast_to(rows, strip.shape)
+    counts = mask.sum(axis=2).reshape(-1)
+    colptr = np.zeros(ne * m + 1, dtype=np.int64)
+    np.cumsum(counts, out=colptr[1:])
+    return colptr, rows[mask], strip[mask], ne * m
+
+
+def _csc(colptr, rowval, nzval, shape):
+    return sp.csc_matrix((nzval, rowval, colptr), shape=shape)
+
+
+class LevelDescriptor:
+    """What the hot path reads from a reference mesh object: `mP` and the element index lists
+    (`mBlockInds`, (p+1) x n, 1-based, contiguous: (k-1)(p+1)+1 .. k(p+1), src/dg_mesh.jl:44,
+    src/agglomerated_dg_mesh.jl:89,505)."""
+
+    def __init__(self, mP, ne):
+        self.mP = mP
+        self.ne = ne
+
+    @property
+    def mBlockInds(self):
+        m = self.mP + 1
+        return (np.arange(self.ne, dtype=np.int64)[None, :] * m + np.arange(1, m + 1, dtype=np.int64)[:, None])
+
+
+# ------------------------------------------------------------------------------------------
+# the hierarchy builder
+# ------------------------------------------------------------------------------------------
+class UniformDgAggHierarchy:
+    """DgMesh(p) on a uniform n-element mesh of [xin, xout] followed by agglomerated-DG levels
+    (first level `ratios[0]`:1 base elements, then `ratios[i]`:1 agglomerates), operators by
+    Galerkin products on G, D, C with `A = C - D(M\\G)` per level -- the D4 extension of the
+    DG-fine constructor (recurrence of src/mesh_heirarchy.jl:89-106).
+
+    Boundary conditions as in tests/dg_heirarchy_test.jl: bc = ((kind, value), (kind, value)),
+    kind in {'neu', 'dir'}; default left Neumann -sin(xin), right Dirichlet cos(xout), f = cos,
+    CDir = 1000 n."""
+
+    def __init__(self, n, p=3, pAgg=1, ratios=(4, 2, 2), CDir=None, xin=0.0, xout=1.0, bc=None,
+                 func=np.cos):
+        if pAgg not in (0, 1):
+            raise ValueError("Only implemented for p = 0 and p = 1.")  # agglomerated_dg_mesh.jl:312
+        if p < 1 and len(ratios):
+            # AgglomeratedDgElement1 reads baseMesh.mElements[k].mNodesX[2]
+            # (src/agglomerated_dg_mesh.jl:183-189: "assumes the baseMesh has at least p >= 1")
+            raise ValueError("agglomeration needs a base mesh with p >= 1")
+        tot = int(np.prod(ratios)) if len(ratios) else 1
+        if n % tot:
+            raise ValueError("n must be divisible by the product of the agglomeration ratios")
+        self.n, self.p, self.pAgg, self.ratios = n, p, pAgg, tuple(ratios)
+        self.CDir = 1000.0 * n if CDir is None else float(CDir)
+        self.bc = bc or (('neu', -math.sin(xin)), ('dir', math.cos(xout)))
+        self.func = func
+        self.ref = RefElement(p)
+        i = np.arange(n + 1, dtype=np.float64)
+        self.xv = np.empty(n + 1)
+        self.xv[0] = xin
+        self.xv[1:] = xin + (i[1:] / n) * (xout - xin)      # tests/mesh_generator.jl:11-13
+        self.h = self.xv[1:] - self.xv[:-1]
+        self.xc = (self.xv[:-1] + self.xv[1:]) / 2.0
+        self.J = self.h / 2.0
+        self._build_fine()
+        self.levels = [dict(m=p + 1, ne=n, G=(self.Gl, self.Gd), D=(self.Dd, self.Du), C=self.Cd,
+                            M=self.M, A=self._stiffness_blocks(self.Gl, self.Gd, self.Dd, self.Du,
+                                                               self.Cd, self.M))]
+        self.transfers = []     # Lb[k]: (ne_f, m_f, m_c) rows of L per fine element, rho
+        self._build_agglomerated()
+
+    # ---- fine DG level -----------------------------------------------------------------------
+    def _build_fine(self):
+        n, p, ref = self.n, self.p, self.ref
+        m = p + 1
+        nL, nR = (0, 1) if p >= 1 else (0, 0)
+        V = np.zeros((m, m))
+        if p >= 1:  # volume term, accumulated over the Gauss points in loop order
+            for l in range(len(ref.gw)):
+                V += (ref.gw[l] * ref.dphi[l])[:, None] * ref.phi[l][None, :]
+        Gd = np.broadcast_to(V, (n, m, m)).copy()
+        Dd = np.broadcast_to(V, (n, m, m)).copy()
+        Gl = np.zeros((n, m, m))
+        Du = np.zeros((n, m, m))
+        Cd = np.zeros((n, m, m))
+        lk, rk = self.bc[0][0], self.bc[1][0]
+        # interior vertices: uhat = u_L, qhat = q_R (src/dg_mesh.jl:219-249)
+        Gd[:-1, nR, nR] += -1.0       # right end of element k, uhat = own value
+        Gl[1:, nL, nR] += 1.0         # left end of element k, uhat from element k-1
+        Dd[1:, nL, nL] += 1.0         # left end, qhat = own q
+        Du[:-1, nR, nL] += -1.0       # right end, qhat from element k+1
+        # boundary vertices (src/dg_mesh.jl:170-218)
+        if lk == 'dir':
+            Dd[0, nL, nL] += 1.0
+            Cd[0, nL, nL] += self.CDir
+        else:
+            Gd[0, nL, nL] += 1.0
+        if rk == 'dir':
+            Dd[-1, nR, nR] += -1.0
+            Cd[-1, nR, nR] += self.CDir
+        else:
+            Gd[-1, nR, nR] += -1.0
+        self.Gd, self.Gl, self.Dd, self.Du, self.Cd = Gd, Gl, Dd, Du, Cd
+        self.M = self.J[:, None, None] * ref.mass[None, :, :]
+
+    def rhs(self):
+        """b = f - D*(M\\r) with (f, r) = dg_flux_rhs (src/dg_mesh.jl:342-457;
+        tests/dg_heirarchy_test.jl:39-40)."""
+        n, p, ref = self.n, self.p, self.ref
+        nL, nR = (0, 1) if p >= 1 else (0, 0)
+        xq = self.xc[:, None] + self.h[:, None] / 2.0 * ref.gq[None, :]
+        fq = self.func(xq)
+        f = np.zeros((n, p + 1))
+        for l in range(len(ref.gw)):
+            f += (self.J[:, None] * ref.gw[l]) * ref.phi[l][None, :] * fq[:, l][:, None]
+        r = np.zeros((n, p + 1))
+        (lk, lv), (rk, rv) = self.bc
+        if lk == 'dir':
+            f[0, nL] += self.CDir * lv
+            r[0, nL] += -lv
+        else:
+            f[0, nL] += -lv
+        if rk == 'dir':
+            f[-1, nR] += self.CDir * rv
+            r[-1, nR] += rv
+        else:
+            f[-1, nR] += rv
+        y = np.linalg.solve(self.M, r[:, :, None])[:, :, 0]
+        Dy = np.einsum('kij,kj->ki', self.Dd, y) + np.einsum('kij,kj->ki', self.Du, _shift_up(y))
+        return (f - Dy).reshape(-1)
+
+    @staticmethod
+    def _stiffness_blocks(Gl, Gd, Dd, Du, Cd, M):
+        """Blocks of A = C - D*(M \\ G) for block-lower-bidiagonal G (Gl, Gd), block-upper-
+        bidiagonal D (Dd, Du), block-diagonal C and M.  -> (sub, diag, sup)"""
+        XGd = np.linalg.solve(M, Gd)
+        XGl = np.linalg.solve(M, Gl)
+        diag = Cd - (Dd @ XGd + Du @ _shift_up(XGl))
+        sub = -(Dd @ XGl)
+        sup = -(Du @ _shift_up(XGd))
+        return sub, diag, sup
+
+    # ---- agglomerated levels -------------------------------------------------------------------
+    def _modal(self, lo, hi, x):
+        """evaluate_local_modal_basis_fun (src/agglomerated_dg_mesh.jl:297-315) for boxes
+        [lo, hi] broadcast against points x -> (..., pAgg+1)"""
+        out = np.ones(x.shape + (self.pAgg + 1,))
+        if self.pAgg == 1:
+            xC = (lo + hi) / 2.0
+            hh = hi - lo
+            out[..., 1] = 2 * (x - xC) / hh
+        return out
+
+    def _build_agglomerated(self):
+        n, ref = self.n, self.ref
+        mc = self.pAgg + 1
+        gq, gw = gauss_quad(2 * self.pAgg)
+        xq = self.xc[:, None] + self.h[:, None] / 2.0 * gq[None, :]          # (n, nq) base Gauss points
+        prev = self.levels[0]
+        base_per = 1
+        prev_phi_q = None   # modal basis of the previous agglomerated level at base Gauss points
+        for li, rho in enumerate(self.ratios):
+            base_per *= rho
+            ne = n // base_per
+            # bounding boxes from the base DG elements' end nodes mRefMap(-1), mRefMap(+1)
+            # (src/agglomerated_dg_mesh.jl:183-189 reads baseMesh.mElements[k].mNodesX[1:2])
+            lo = (self.xc + self.h / 2.0 * (-1.0))[0:n:base_per]
+            hi = (self.xc + self.h / 2.0 * (1.0))[base_per - 1::base_per]
+            # modal basis of this level at the base elements' Gauss points: (ne, base_per, nq, mc)
+            phi_q = self._modal(lo[:, None, None], hi[:, None, None], xq.reshape(ne, base_per, -1))
+            Jb = self.J.reshape(ne, base_per)
+            # mass: sum over base elements k, Gauss points l, in loop order k then l
+            M = np.zeros((ne, mc, mc))
+            for k in range(base_per):
+                for l in range(len(gw)):
+                    M += (Jb[:, k] * gw[l])[:, None, None] * phi_q[:, k, l, :, None] * phi_q[:, k, l, None, :]
+            if li == 0:
+                # aggdg_dg_interpolation: modal basis at the base DG nodes
+                xn = self.xc[:, None] + self.h[:, None] / 2.0 * ref.nodes[None, :]   # (n, m_f)
+                Lb = self._modal(np.repeat(lo, rho)[:, None], np.repeat(hi, rho)[:, None], xn)
+            else:
+                # aggdg_aggdg_interpolation: N then M_f \ N per fine agglomerate
+                nef = prev['ne']
+                bpf = base_per // rho                       # base elements per fine agglomerate
+                fphi = prev_phi_q                           # (nef, bpf, nq, mc)
+                cphi = phi_q.reshape(nef, bpf, len(gw), mc)  # coarse basis, grouped by fine agglomerate
+                Jf = self.J.reshape(nef, bpf)
+                N = np.zeros((nef, mc, mc))
+                for k in range(bpf):
+                    for l in range(len(gw)):
+                        N += (Jf[:, k] * gw[l])[:, None, None] * fphi[:, k, l, :, None] * cphi[:, k, l, None, :]
+                Lb = np.linalg.solve(prev['M'], N)
+            self.transfers.append(dict(Lb=Lb, rho=rho, mc=mc))
+            # Galerkin products on the block-bidiagonal G, D and block-diagonal C
+            Gl, Gd = prev['G']
+            Dd, Du = prev['D']
+            Gl_c, Gd_c = self._galerkin_lower(Lb, Gl, Gd, rho)
+            Du_c, Dd_c = self._galerkin_upper(Lb, Du, Dd, rho)
+            Cd_c = self._galerkin_diag(Lb, prev['C'], rho)
+            lvl = dict(m=mc, ne=ne, G=(Gl_c, Gd_c), D=(Dd_c, Du_c), C=Cd_c, M=M,
+                       A=self._stiffness_blocks(Gl_c, Gd_c, Dd_c, Du_c, Cd_c, M))
+            self.levels.append(lvl)
+            prev = lvl
+            prev_phi_q = phi_q
+
+    @staticmethod
+    def _galerkin_diag(Lb, Xd, rho):
+        t = _lt_x_l(Lb, Xd, Lb)
+        return t.reshape(-1, rho, *t.shape[1:]).sum(axis=1)
+
+    @staticmethod
+    def _galerkin_lower(Lb, Xl, Xd, rho):
+        """L'XL for block-lower-bidiagonal X (Xl[k] couples k to k-1)."""
+        d = _lt_x_l(Lb, Xd, Lb)
+        l = _lt_x_l(Lb, Xl, _shift_down(Lb))   # rows of k, cols of k-1
+        d = d.reshape(-1, rho, *d.shape[1:])
+        l = l.reshape(-1, rho, *l.shape[1:])
+        diag = d.sum(axis=1) + l[:, 1:].sum(axis=1)   # couplings inside the agglomerate
+        sub = l[:, 0].copy()                          # first fine element couples to previous agglomerate
+        return sub, diag
+
+    @staticmethod
+    def _galerkin_upper(Lb, Xu, Xd, rho):
+        """L'XL for block-upper-bidiagonal X (Xu[k] couples k to k+1)."""
+        d = _lt_x_l(Lb, Xd, Lb)
+        u = _lt_x_l(Lb, Xu, _shift_up(Lb))
+        d = d.reshape(-1, rho, *d.shape[1:])
+        u = u.reshape(-1, rho, *u.shape[1:])
+        diag = d.sum(axis=1) + u[:, :-1].sum(axis=1)
+        sup = u[:, -1].copy()
+        return sup, diag
+
+    # ---- products for the hot path -----------------------------------------------------------
+    @property
+    def nlevels(self):
+        return len(self.levels)
+
+    def stiffness_csc(self, k):
+        """H.mStiffness[k] as scipy CSC (numerical pattern of `C - D*(M\\G)`)."""
+        sub, diag, sup = self.levels[k]['A']
+        colptr, rowval, nzval, N = block_tridiag_to_csc(sub, diag, sup)
+        return _csc(colptr, rowval, nzval, (N, N))
+
+    def interpolation_csc(self, k):
+        """H.mInterpolation[k] (level k+1 -> k): every column holds all rows of its agglomerate,
+        zeros included."""
+        t = self.transfers[k]
+        Lb, rho, mc = t['Lb'], t['rho'], t['mc']
+        nef, mf, _ = Lb.shape
+        nec = nef // rho
+        R = rho * mf
+        vals = Lb.reshape(nec, R, mc).transpose(0, 2, 1).reshape(-1)
+        colptr = np.arange(nec * mc + 1, dtype=np.int64) * R
+        rowval = (np.repeat(np.arange(nec, dtype=np.int64), mc)[:, None] * R + np.arange(R, dtype=np.int64)[None, :]).reshape(-1)
+        return _csc(colptr, rowval, vals, (nef * mf, nec * mc))
+
+    def descriptor(self, k):
+        lv = self.levels[k]
+        return LevelDescriptor(lv['m'] - 1, lv['ne'])
+
+    def algorithmic_bytes(self, nPre=3, nPost=3):
+        """SURVEY.md 8(d) / BASELINE.md section 3 byte model, from the actual nnz:
+        per-level sweep S, residual R, restriction and prolongation bytes and the V-cycle sum."""
+        out = []
+        n = self.nlevels
+        for k in range(n - 1):
+            lv = self.levels[k]
+            N = lv['m'] * lv['ne']
+            sub, diag, sup = lv['A']
+            nnzA = int(np.count_nonzero(diag)) + int(np.count_nonzero(sub[1:])) + int(np.count_nonzero(sup[:-1]))
+            Nc = self.levels[k + 1]['m'] * self.levels[k + 1]['ne']
+            nnzL = self.transfers[k]['Lb'].size
+            S = 12 * nnzA + 4 * (N + 1) + 8 * lv['m'] * N + 24 * N
+            R = 12 * nnzA + 4 * (N + 1) + 24 * N
+            Td = 12 * nnzL + 4 * (Nc + 1) + 8 * N + 8 * Nc
+            Tu = 12 * nnzL + 4 * (N + 1) + 8 * Nc + 16 * N
+            out.append(dict(N=N, nnzA=nnzA, nnzL=nnzL, sweep=S, residual=R, restrict=Td, prolong=Tu,
+                            vcycle=(nPre + nPost) * S + R + Td + Tu))
+        return out
+
+
+def build_device_hierarchy(U, ctx=None, keep_host=False):
+    """Upload a UniformDgAggHierarchy through the CSC boundary and return the product
+    MeshHierarchy (block-Jacobi on every smoothed level, src/mesh_heirarchy.jl:58,73,85,104)."""
+    from .api import BlockJacobi, DeviceOperator, MeshHierarchy
+    from . import _lib
+    n = U.nlevels
+    ops, sms = [], []
+    for k in range(n):
+        op = DeviceOperator(U.stiffness_csc(k), _lib.OP_STIFFNESS, ctx)
+        ops.append(op)
+        if k < n - 1:
+            sms.append(BlockJacobi(op, U.descriptor(k).mBlockInds, ctx))
+    Ls = [DeviceOperator(U.interpolation_csc(k), _lib.OP_TRANSFER, ctx) for k in range(n - 1)]
+    H = MeshHierarchy([U.descriptor(k) for k in range(n)], ops, sms, Ls, ctx=ctx, keep_host=keep_host)
+    return H

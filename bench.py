@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""bench.py -- V-cycle hot path of AgglomerationMultigrid1D on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--log2-elems E]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step is one multigrid_v_cycle (V(3,3), alpha = 2/3, src/solvers.jl:19-50) over the
+BASELINE.json config-3 hierarchy: DG p=3 fine level (2^E elements, default E=22) ->
+AggDG pAgg=1 (4:1) -> AggDG (2:1) -> AggDG (2:1), all operators and vectors resident in HBM
+before the timed region.  For N > 1 the same hierarchy is partitioned by contiguous element
+range (strong scaling, config 4).  Rank 0 prints ONE JSON line.
+
+metric  fine-level DoF-updates/s per V-cycle = N_fine * (nPre + nPost) / t_vcycle, the whole
+        cycle timed (the coarsest direct solve included; its share is reported beside it).
+roofline  dominant kernel = the fused fine-level launch; achieved = algorithmic bytes per launch
+        (SURVEY.md 8d byte model, from actual nnz) / its mean HIP-event duration measured inside
+        the timed region on the launch stream.
+cpu_baseline  the plain-C single-thread restatement (oracle/aggmg_oracle_c.c, kind "port") on a
+        bounded sample of the same workload, host cores of this box, rank 0, N = 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--log2-elems", type=int, default=22, help="fine DG elements = 2^E (config 3: 22)")
+    ap.add_argument("--p", type=int, default=3)
+    ap.add_argument("--cpu-log2-elems", type=int, default=20, help="size of the CPU-baseline sample")
+    ap.add_argument("--cpu-cycles", type=int, default=4)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-smoother-bench", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(args, nPre, nPost, alpha):
+    """Plain-C port of the reference algorithm, 1 thread, on a 2^cpu_log2_elems-element instance
+    of the same hierarchy (same p, ratios, BCs).  Checker code: only timed, never shipped."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import c_oracle
+    from agglomerationmultigrid1d_amd.uniform import UniformDgAggHierarchy
+    n = 2 ** args.cpu_log2_elems
+    U = UniformDgAggHierarchy(n, p=args.p, pAgg=1, ratios=(4, 2, 2))
+    C = c_oracle.COracleHierarchy([U.stiffness_csc(k) for k in range(U.nlevels)],
+                                  [U.interpolation_csc(k) for k in range(U.nlevels - 1)],
+                                  [U.levels[k]['m'] for k in range(U.nlevels - 1)])
+    b = U.rhs()
+    x = np.zeros(len(b))
+    tot = coarse = 0.0
+    for _ in range(args.cpu_cycles):
+        x, dt, cs = C.vcycle(x, b, nPre, nPost, alpha)
+        tot += dt
+        coarse += cs
+    N = len(b)
+    return {
+        "value": N * (nPre + nPost) * args.cpu_cycles / tot,
+        "unit": "DoF-updates/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"{args.cpu_cycles} V(3,3) cycles, same hierarchy at 2^{args.cpu_log2_elems} fine elements "
+                  f"(N_fine={N}), plain-C restatement, 1 thread of {os.cpu_count()} host cores; "
+                  f"coarsest solve {1e3 * coarse / args.cpu_cycles:.1f} ms of {1e3 * tot / args.cpu_cycles:.1f} ms per cycle",
+        "ms_per_cycle": 1e3 * tot / args.cpu_cycles,
+    }
+
+
+def smoother_bench(mg, ctx, args, alpha):
+    """BASELINE config 2: DG n=2^20 p=3, 100 fused block-Jacobi sweeps and 100 residuals."""
+    from agglomerationmultigrid1d_amd.uniform import UniformDgAggHierarchy
+    from agglomerationmultigrid1d_amd import _lib
+    n = 2 ** 20
+    U = UniformDgAggHierarchy(n, p=args.p, pAgg=1, ratios=())
+    op = mg.DeviceOperator(U.stiffness_csc(0), _lib.OP_STIFFNESS, ctx)
+    S = mg.BlockJacobi(op, U.descriptor(0).mBlockInds, ctx)
+    N = op.shape[0]
+    b = ctx.to_device(U.rhs())
+    u = ctx.to_device(np.zeros(N))
+    v = ctx.alloc(N)
+    r = ctx.alloc(N)
+    lib = ctx.lib
+    from agglomerationmultigrid1d_amd.api import _ptr
+    out = {}
+    nnzA = op.nnz
+    S_bytes = 12 * nnzA + 4 * (N + 1) + 8 * 4 * N + 24 * N
+    R_bytes = 12 * nnzA + 4 * (N + 1) + 24 * N
+    for label, per_launch in (("sweeps_1_per_launch", 1), ("sweeps_4_per_launch", 4), ("sweeps_8_per_launch", 8)):
+        reps = 100 // per_launch
+        for _ in range(2):
+            ctx.check(lib.aggmg_smooth_dev(ctx.handle, op.handle, S.handle, _ptr(u), _ptr(b), alpha, per_launch, _ptr(v)))
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        src, dst = u, v
+        for _ in range(reps):
+            ctx.check(lib.aggmg_smooth_dev(ctx.handle, op.handle, S.handle, _ptr(src), _ptr(b), alpha, per_launch, _ptr(dst)))
+            src, dst = dst, src
+        ctx.synchronize()
+        dt = time.perf_counter() - t0
+        sweeps = reps * per_launch
+        out[label] = {"dof_updates_per_s": N * sweeps / dt, "us_per_sweep": 1e6 * dt / sweeps,
+                      "algorithmic_GBs": S_bytes * sweeps / dt / 1e9,
+                      "frac_of_8TBs": S_bytes * sweeps / dt / 1e9 / HBM_PEAK_GBS}
+    ctx.check(lib.aggmg_residual_dev(ctx.handle, op.handle, _ptr(u), _ptr(b), _ptr(r)))
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(100):
+        ctx.check(lib.aggmg_residual_dev(ctx.handle, op.handle, _ptr(u), _ptr(b), _ptr(r)))
+    ctx.synchronize()
+    dt = time.perf_counter() - t0
+    out["residual"] = {"us_per_residual": 1e6 * dt / 100, "algorithmic_GBs": R_bytes * 100 / dt / 1e9,
+                       "frac_of_8TBs": R_bytes * 100 / dt / 1e9 / HBM_PEAK_GBS}
+    out["workload"] = f"config 2: DG n=2^20 p={args.p}, block-Jacobi m={args.p + 1}, N={N}, nnz(A)={nnzA}"
+    return out
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    nPre = nPost = 3
+    alpha = 2.0 / 3.0
+    if world != args.gpus:
+        if not (world == 1 and args.gpus == 1):
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    import agglomerationmultigrid1d_amd as mg
+    from agglomerationmultigrid1d_amd.uniform import UniformDgAggHierarchy, build_device_hierarchy
+
+    if world > 1:
+        from agglomerationmultigrid1d_amd import distributed as dist_mg
+        return dist_mg.bench_main(args, rank, world, local_rank, nPre, nPost, alpha)
+
+    ctx = mg.Context(local_rank)
+    n = 2 ** args.log2_elems
+    t_setup = time.perf_counter()
+    U = UniformDgAggHierarchy(n, p=args.p, pAgg=1, ratios=(4, 2, 2))
+    H = build_device_hierarchy(U, ctx)
+    bytes_model = U.algorithmic_bytes(nPre, nPost)
+    N = U.levels[0]['m'] * U.levels[0]['ne']
+    b = ctx.to_device(U.rhs())
+    xa = ctx.to_device(np.zeros(N))
+    xb = ctx.alloc(N)
+    level_sizes = [lv['m'] * lv['ne'] for lv in U.levels]
+    del U
+    t_setup = time.perf_counter() - t_setup
+    assert all(H.structured_levels()), "fused HIP kernels were not selected"
+
+    src, dst = xa, xb
+    for _ in range(args.warmup):
+        H.vcycle_dev(src, b, dst, nPre, nPost, alpha)
+        src, dst = dst, src
+    ctx.synchronize()
+    ctx.profile_enable(True)
+    coarse_ms = 0.0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        H.vcycle_dev(src, b, dst, nPre, nPost, alpha)
+        coarse_ms += H.last_coarse_ms()
+        src, dst = dst, src
+    ctx.synchronize()
+    dt = time.perf_counter() - t0
+    ctx.profile_enable(False)
+    prof = ctx.profile_collect()
+
+    ms_per_step = 1e3 * dt / args.steps
+    value = N * (nPre + nPost) * args.steps / dt
+    vcycle_bytes = sum(l['vcycle'] for l in bytes_model)
+    # dominant kernel by total event time
+    dom = max(prof.items(), key=lambda kv: kv[1][0])
+    (dkind, dlevel), (dms, dcnt) = dom
+    lm = bytes_model[dlevel]
+    per_launch = {"fused_down": nPre * lm['sweep'] + lm['residual'] + lm['restrict'],
+                  "fused_up": nPost * lm['sweep'] + lm['prolong']}.get(dkind, lm['sweep'])
+    achieved = per_launch / (dms / dcnt * 1e-3) / 1e9
+    traffic = None
+    tfile = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tfile):
+        try:
+            traffic = json.load(open(tfile)).get(f"{dkind}_L{dlevel}_log2n{args.log2_elems}")
+        except Exception:
+            traffic = None
+    kern_ms = {f"{k}_L{l}": {"ms_per_launch": v[0] / v[1], "launches": v[1]} for (k, l), v in sorted(prof.items())}
+    out = {
+        "metric": "fine_level_dof_updates_per_s_per_vcycle",
+        "value": value,
+        "unit": "DoF-updates/s",
+        "n_gpus": 1,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": f"config 3: V(3,3) cycle, alpha=2/3, DG p={args.p} n=2^{args.log2_elems} -> AggDG pAgg=1 "
+                               f"4:1 -> 2:1 -> 2:1 (4 levels), uniform mesh, Neumann/Dirichlet, CDir=1000n",
+                   "fine_dofs": N, "level_dofs": level_sizes, "nPre": nPre, "nPost": nPost,
+                   "parallelism": "single GPU"},
+        "achieved_algorithmic_GBs_vcycle": vcycle_bytes * args.steps / dt / 1e9,
+        "coarse_solve_ms_per_step": coarse_ms / args.steps,
+        "value_excl_coarse_solve": N * (nPre + nPost) / max(1e-3 * (ms_per_step - coarse_ms / args.steps), 1e-12),
+        "roofline": {"bound": "hbm", "kernel": f"btd_fused_kernel<{args.p + 1},cmp> {dkind} level {dlevel + 1}",
+                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": traffic, "algorithmic_bytes_per_launch": per_launch,
+                     "ms_per_launch": dms / dcnt, "launches_timed": dcnt,
+                     "note": "achieved = algorithmic bytes (SURVEY 8d model: CSR int32 + fp64, every sweep re-reading "
+                             "the operator) / HIP-event duration; the fused kernel reads the operator once per launch, "
+                             "so achieved may exceed what the same launch physically moves"},
+        "kernels": kern_ms,
+        "setup_s": t_setup,
+    }
+    if not args.no_smoother_bench:
+        out["smoother_only"] = smoother_bench(mg, ctx, args, alpha)
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args, nPre, nPost, alpha)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
