@@ -15,9 +15,10 @@ ERR_ARGUMENT, ERR_DIMENSION, ERR_SINGULAR, ERR_HIP, ERR_UNSUPPORTED = -1, -2, -3
 OP_STIFFNESS, OP_TRANSFER = 0, 1
 PROFILE_NTAGS = 256
 KIND_FUSED_DOWN, KIND_FUSED_UP, KIND_SMOOTH, KIND_RESIDUAL, KIND_RESTRICT, KIND_PROLONG, \
-    KIND_JACOBI, KIND_BLOCK_APPLY, KIND_OTHER = range(9)
+    KIND_JACOBI, KIND_BLOCK_APPLY, KIND_COARSE = range(9)
 KIND_NAMES = ["fused_down", "fused_up", "smooth", "residual", "restrict", "prolong", "jacobi",
-              "block_apply", "other"]
+              "block_apply", "coarse"]
+COARSE_HOST_BANDED, COARSE_DEVICE_CR, COARSE_AUTO = 0, 1, 2
 
 
 class AggmgError(RuntimeError):
@@ -90,6 +91,7 @@ SYMBOLS = {
     "aggmg_hier_free": (c_int, [_P, _P]),
     "aggmg_vcycle": (c_int, [_P, _P, _PD, _PD, c_int, c_int, c_double, _PD]),
     "aggmg_vcycle_dev": (c_int, [_P, _P, _P, _P, c_int, c_int, c_double, _P]),
+    "aggmg_hier_coarse_info": (c_int, [_P, _P, POINTER(c_int), POINTER(c_int), POINTER(c_double)]),
     "aggmg_hier_last_coarse_ms": (c_int, [_P, _P, POINTER(c_double)]),
     "aggmg_profile_enable": (c_int, [_P, c_int]),
     "aggmg_profile_collect": (c_int, [_P, _PD, POINTER(c_int64)]),

@@ -369,7 +369,8 @@ class MeshHierarchy:
     constructor)."""
 
     def __init__(self, mMeshes, mStiffness, mSmoothers, mInterpolation, mBdConds=None,
-                 mGradient=None, mDivergence=None, mC=None, ctx=None, keep_host=True):
+                 mGradient=None, mDivergence=None, mC=None, ctx=None, keep_host=True,
+                 coarse_mode=_lib.COARSE_AUTO):
         n = len(mStiffness)
         if n < 1:
             raise ArgumentError("At least one mesh required.")
@@ -391,17 +392,18 @@ class MeshHierarchy:
         sms = arr(*([s.handle for s in self.mSmoothers] + [None]))
         Ls = arr(*([l.handle for l in self._Ls] + [None]))
         h = ctypes.c_void_p()
-        self.ctx.check(self.ctx.lib.aggmg_hier_create(self.ctx.handle, n, ops, sms, Ls, 0, ctypes.byref(h)))
+        self.ctx.check(self.ctx.lib.aggmg_hier_create(self.ctx.handle, n, ops, sms, Ls, int(coarse_mode), ctypes.byref(h)))
         self.handle = h
         if not keep_host:
             for o in self._ops + self._Ls:
                 o.release_host()
 
     @classmethod
-    def from_reference(cls, H, ctx=None):
+    def from_reference(cls, H, ctx=None, coarse_mode=_lib.COARSE_AUTO):
         return cls(H.mMeshes, H.mStiffness, H.mSmoothers, H.mInterpolation,
                    getattr(H, "mBdConds", None), getattr(H, "mGradient", None),
-                   getattr(H, "mDivergence", None), getattr(H, "mC", None), ctx=ctx)
+                   getattr(H, "mDivergence", None), getattr(H, "mC", None), ctx=ctx,
+                   coarse_mode=coarse_mode)
 
     @property
     def nlevels(self):
@@ -416,6 +418,13 @@ class MeshHierarchy:
         c = self.ctx
         c.check(c.lib.aggmg_vcycle_dev(c.handle, self.handle, _ptr(x0), _ptr(b), int(nPre), int(nPost),
                                        float(alpha), _ptr(x_out)))
+
+    def coarse_info(self):
+        """-> dict(on_device, block_size, cond_est) of the coarsest direct solver"""
+        a, b, c = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_double(0.0)
+        self.ctx.check(self.ctx.lib.aggmg_hier_coarse_info(self.ctx.handle, self.handle, ctypes.byref(a),
+                                                           ctypes.byref(b), ctypes.byref(c)))
+        return dict(on_device=bool(a.value), block_size=b.value, cond_est=c.value)
 
     def last_coarse_ms(self):
         ms = ctypes.c_double(0.0)

@@ -59,15 +59,8 @@ struct HostCsr {
   std::vector<double> vals;
 };
 
-struct aggmg_op {
-  int64_t m = 0, n = 0, nnz = 0;
-  int kind = AGGMG_OP_STIFFNESS;
-  CsrDev csr;   // row-gather form of the matrix
-  CsrDev csrT;  // row-gather form of its transpose (transfers only)
-  HostCsr host; // host CSR kept for smoother / structure set-up until released
-  bool host_valid = false;
-};
-
+// index-free block-tridiagonal form of an operator + its block-Jacobi smoother; shared by the
+// smoother that built it and the operator it describes (so aggmg_residual can use it too)
 struct BtdDev {
   int m = 0;
   int64_t ne = 0;
@@ -75,6 +68,20 @@ struct BtdDev {
   int c_sub = 0, r_sup = 0;
   double *binv = nullptr, *dblk = nullptr, *scol = nullptr, *pcol = nullptr, *qrow = nullptr;
   double *sub = nullptr, *sup = nullptr, *P = nullptr, *Q = nullptr;
+  ~BtdDev() {
+    for (double* p : {binv, dblk, scol, pcol, qrow, sub, sup, P, Q})
+      if (p) (void)hipFree(p);
+  }
+};
+
+struct aggmg_op {
+  int64_t m = 0, n = 0, nnz = 0;
+  int kind = AGGMG_OP_STIFFNESS;
+  CsrDev csr;   // row-gather form of the matrix
+  CsrDev csrT;  // row-gather form of its transpose (transfers only)
+  HostCsr host; // host CSR kept for smoother / structure set-up until released
+  bool host_valid = false;
+  std::shared_ptr<BtdDev> btd;  // set when a block-Jacobi smoother recognised the structure
 };
 
 struct aggmg_smoother {
@@ -87,7 +94,7 @@ struct aggmg_smoother {
   double* counts = nullptr;    // hybrid Schwarz
   bool overlapping = false;
   bool contiguous = false;
-  std::unique_ptr<BtdDev> btd;  // structured fused form, or null
+  std::shared_ptr<BtdDev> btd;  // structured fused form, or null
 };
 
 struct TransferBtd {
@@ -111,10 +118,26 @@ struct BandedLU {
   std::vector<int32_t> ipiv;
 };
 
+// block cyclic reduction of the coarsest operator, factored once (device-resident)
+struct CrDev {
+  bool valid = false;
+  int m = 0;
+  int64_t n0 = 0, N = 0;
+  std::vector<CrLevel> lv;      // all reducing levels (device pointers)
+  std::vector<void*> owned;     // every device allocation, for free
+  const double* lu_last = nullptr;
+  const int32_t* perm_last = nullptr;
+  int nglobal = 0;              // levels run as their own launches; the rest go to the tail kernel
+  std::vector<double*> d, x;    // per-level vectors for levels 0..nglobal
+  size_t tail_lds = 0;
+  double cond_est = 0.0;
+};
+
 struct aggmg_hier {
   std::vector<Level> lv;
   int coarse_mode = 0;
   BandedLU coarse;
+  CrDev cr;
   std::vector<double> h_coarse;
   double last_coarse_ms = 0.0;
 };
@@ -505,11 +528,6 @@ static double host_entry(const HostCsr& h, int64_t r, int64_t c) {
 // ---------------------------------------------------------------------------------------------
 // smoothers
 // ---------------------------------------------------------------------------------------------
-static void free_btd(BtdDev* b) {
-  for (double* p : {b->binv, b->dblk, b->scol, b->pcol, b->qrow, b->sub, b->sup, b->P, b->Q})
-    if (p) (void)hipFree(p);
-}
-
 static bool btd_supported(int m, bool cmp) {
   if (cmp) return m >= 2 && m <= 9;
   return m >= 1 && m <= 5;
@@ -562,7 +580,7 @@ static int build_btd(aggmg_ctx* ctx, aggmg_smoother* sm, const std::vector<doubl
   if (cmp && !btd_supported(m, true)) cmp = false;
   if (!cmp && !btd_supported(m, false)) return AGGMG_OK;  // generic path
 
-  auto b = std::make_unique<BtdDev>();
+  auto b = std::make_shared<BtdDev>();
   b->m = m;
   b->ne = ne;
   b->cmp = cmp;
@@ -604,11 +622,9 @@ static int build_btd(aggmg_ctx* ctx, aggmg_smoother* sm, const std::vector<doubl
     if (st == AGGMG_OK) st = dev_upload(ctx, P, &b->P);
     if (st == AGGMG_OK) st = dev_upload(ctx, Q, &b->Q);
   }
-  if (st != AGGMG_OK) {
-    free_btd(b.get());
-    return st;
-  }
-  sm->btd = std::move(b);
+  if (st != AGGMG_OK) return st;
+  sm->btd = b;
+  sm->A->btd = b;
   return AGGMG_OK;
 }
 
@@ -688,7 +704,6 @@ extern "C" int aggmg_smoother_free(aggmg_ctx* ctx, aggmg_smoother* sm) {
   HIPCHK(hipStreamSynchronize(ctx->stream));
   for (void* p : {(void*)sm->diag, (void*)sm->binv, (void*)sm->inds, (void*)sm->counts})
     if (p) (void)hipFree(p);
-  if (sm->btd) free_btd(sm->btd.get());
   delete sm;
   return AGGMG_OK;
 }
@@ -939,6 +954,14 @@ extern "C" int aggmg_residual_dev(aggmg_ctx* ctx, aggmg_op* A, const double* u, 
   if (!ctx) return AGGMG_ERR_ARGUMENT;
   if (!A || !u || !b || !r_out) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_residual: NULL argument");
   ProfScope ps(ctx, AGGMG_KIND_RESIDUAL, 0);
+  if (A->btd && r_out != u && r_out != b) {  // index-free block-tridiagonal form, one fused pass
+    FusedArgs a = btd_args(*A->btd);
+    a.u_in = u;
+    a.b = b;
+    a.do_residual = 1;
+    a.r_out = r_out;
+    return launch_btd(ctx, *A->btd, a, 1);
+  }
   return launch_csr<kResidual>(ctx, A->csr, u, b, nullptr, 0.0, r_out);
 }
 
@@ -1150,6 +1173,310 @@ static void banded_solve(const BandedLU& f, double* b) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// coarsest-level direct solve on the device: block cyclic reduction (factor once, solve per cycle)
+// ---------------------------------------------------------------------------------------------
+static double norm1(int m, const double* A) {
+  double best = 0.0;
+  for (int j = 0; j < m; ++j) {
+    double s = 0.0;
+    for (int i = 0; i < m; ++i) s += std::fabs(A[i * m + j]);
+    best = std::max(best, s);
+  }
+  return best;
+}
+
+// LU with partial pivoting of an m x m row-major block, stored as the factors of the
+// row-permuted matrix (perm[k] = original row that ends up in position k).  false if singular.
+static bool lu_perm(int m, const double* b, double* lu, int32_t* perm) {
+  std::copy(b, b + m * m, lu);
+  for (int k = 0; k < m; ++k) perm[k] = k;
+  for (int k = 0; k < m; ++k) {
+    int p = k;
+    double best = std::fabs(lu[k * m + k]);
+    for (int i = k + 1; i < m; ++i)
+      if (std::fabs(lu[i * m + k]) > best) {
+        best = std::fabs(lu[i * m + k]);
+        p = i;
+      }
+    if (lu[p * m + k] == 0.0) return false;
+    if (p != k) {
+      for (int j = 0; j < m; ++j) std::swap(lu[k * m + j], lu[p * m + j]);
+      std::swap(perm[k], perm[p]);
+    }
+    const double rp = 1.0 / lu[k * m + k];
+    for (int i = k + 1; i < m; ++i) lu[i * m + k] *= rp;
+    for (int i = k + 1; i < m; ++i) {
+      const double l = lu[i * m + k];
+      for (int j = k + 1; j < m; ++j) lu[i * m + j] -= l * lu[k * m + j];
+    }
+  }
+  return true;
+}
+
+// X = b \ R for an m x ncols row-major right-hand side (host mirror of cr_lu_solve)
+static void lu_perm_solve(int m, const double* lu, const int32_t* perm, const double* R, int ncols, double* X) {
+  std::vector<double> y(m);
+  for (int c = 0; c < ncols; ++c) {
+    for (int k = 0; k < m; ++k) y[k] = R[perm[k] * ncols + c];
+    for (int i = 1; i < m; ++i) {
+      double s = y[i];
+      for (int j = 0; j < i; ++j) s -= lu[i * m + j] * y[j];
+      y[i] = s;
+    }
+    for (int i = m - 1; i >= 0; --i) {
+      double s = y[i];
+      for (int j = i + 1; j < m; ++j) s -= lu[i * m + j] * y[j];
+      y[i] = s / lu[i * m + i];
+    }
+    for (int k = 0; k < m; ++k) X[k * ncols + c] = y[k];
+  }
+}
+
+static void free_cr(CrDev* c) {
+  for (void* p : c->owned)
+    if (p) (void)hipFree(p);
+  *c = CrDev();
+}
+
+// Returns AGGMG_OK and sets cr->valid when the operator is block-tridiagonal for some block size
+// m <= 8 and every pivot block is comfortably invertible; leaves cr->valid == false otherwise
+// (the caller then keeps the host banded solver).
+static int cr_setup(aggmg_ctx* ctx, const HostCsr& h, int64_t N, int hint_m, CrDev* cr) {
+  cr->valid = false;
+  if (N == 0) return AGGMG_OK;
+  int kl = 0, ku = 0;
+  for (int64_t i = 0; i < N; ++i)
+    for (int32_t p = h.rowptr[i]; p < h.rowptr[i + 1]; ++p) {
+      kl = std::max<int64_t>(kl, i - h.colind[p]);
+      ku = std::max<int64_t>(ku, h.colind[p] - i);
+    }
+  int m = 0;
+  auto fits = [&](int mm_) {
+    for (int64_t i = 0; i < N; ++i) {
+      const int64_t e = i / mm_;
+      for (int32_t p = h.rowptr[i]; p < h.rowptr[i + 1]; ++p) {
+        const int64_t ce = h.colind[p] / mm_;
+        if (ce < e - 1 || ce > e + 1) return false;
+      }
+    }
+    return true;
+  };
+  if (hint_m >= 1 && hint_m <= 8 && fits(hint_m)) m = hint_m;
+  if (!m) {
+    const int bw = std::max(1, std::max(kl, ku));
+    if (bw <= 8) m = bw;  // bandwidth <= m  =>  block-tridiagonal with m-blocks
+  }
+  if (!m) return AGGMG_OK;
+  const int mm2 = m * m;
+  int64_t n = (N + m - 1) / m;
+  std::vector<double> a((size_t)n * mm2, 0.0), b((size_t)n * mm2, 0.0), c((size_t)n * mm2, 0.0);
+  for (int64_t i = 0; i < N; ++i) {
+    const int64_t e = i / m;
+    const int li = (int)(i - e * m);
+    for (int32_t p = h.rowptr[i]; p < h.rowptr[i + 1]; ++p) {
+      const int64_t cj = h.colind[p];
+      const int64_t ce = cj / m;
+      const int lj = (int)(cj - ce * m);
+      double* dst = ce == e ? b.data() : (ce == e - 1 ? a.data() : c.data());
+      dst[e * mm2 + li * m + lj] = h.vals[p];
+    }
+  }
+  for (int64_t i = N; i < n * m; ++i) b[(i / m) * mm2 + (i % m) * m + (i % m)] = 1.0;  // identity padding
+  cr->m = m;
+  cr->n0 = n;
+  cr->N = N;
+  std::vector<double> blk(mm2), inv, za(mm2), zc(mm2);
+  std::vector<int> piv;
+  double cond = 0.0;
+  auto upd = [&](const std::vector<double>& v, const double** out) -> int {
+    double* d = nullptr;
+    CHECK(dev_upload(ctx, v, &d));
+    cr->owned.push_back(d);
+    *out = d;
+    return AGGMG_OK;
+  };
+  auto upi = [&](const std::vector<int32_t>& v, const int32_t** out) -> int {
+    int32_t* d = nullptr;
+    CHECK(dev_upload(ctx, v, &d));
+    cr->owned.push_back(d);
+    *out = d;
+    return AGGMG_OK;
+  };
+  auto pivot_cond = [&](const double* bb) -> bool {  // monitor only
+    std::copy(bb, bb + mm2, blk.begin());
+    const double nb = norm1(m, blk.data());
+    if (!invert_block(m, blk, inv, piv)) return false;
+    cond = std::max(cond, nb * norm1(m, inv.data()));
+    return true;
+  };
+  while (n > 1) {
+    const int64_t ne = (n + 1) / 2, no = n / 2;
+    std::vector<double> lu((size_t)no * mm2);
+    std::vector<int32_t> perm((size_t)no * m);
+    std::vector<double> Za((size_t)no * mm2), Zc((size_t)no * mm2);  // b_odd \ a_odd, b_odd \ c_odd
+    std::vector<double> a2((size_t)ne * mm2, 0.0), b2((size_t)ne * mm2, 0.0), c2((size_t)ne * mm2, 0.0);
+    for (int64_t j = 0; j < no; ++j) {
+      const int64_t i = 2 * j + 1;
+      if (!pivot_cond(&b[i * mm2]) || !lu_perm(m, &b[i * mm2], &lu[j * mm2], &perm[j * m])) {
+        free_cr(cr);
+        return AGGMG_OK;
+      }
+      lu_perm_solve(m, &lu[j * mm2], &perm[j * m], &a[i * mm2], m, &Za[j * mm2]);
+      lu_perm_solve(m, &lu[j * mm2], &perm[j * m], &c[i * mm2], m, &Zc[j * mm2]);
+    }
+    for (int64_t j = 0; j < ne; ++j) {
+      const int64_t i = 2 * j;
+      double* B2 = &b2[j * mm2];
+      std::copy(b.begin() + i * mm2, b.begin() + (i + 1) * mm2, B2);
+      if (j > 0) {  // eliminate x_{i-1}: -a_i (b_{i-1} \ [a_{i-1} | c_{i-1}])
+        const double* A = &a[i * mm2];
+        const double* ZA = &Za[(j - 1) * mm2];
+        const double* ZC = &Zc[(j - 1) * mm2];
+        for (int r = 0; r < m; ++r)
+          for (int q = 0; q < m; ++q) {
+            double s1 = 0.0, s2 = 0.0;
+            for (int k = 0; k < m; ++k) {
+              s1 += A[r * m + k] * ZA[k * m + q];
+              s2 += A[r * m + k] * ZC[k * m + q];
+            }
+            a2[j * mm2 + r * m + q] = -s1;
+            B2[r * m + q] -= s2;
+          }
+      }
+      if (i + 1 < n) {  // eliminate x_{i+1}: -c_i (b_{i+1} \ [a_{i+1} | c_{i+1}])
+        const double* C = &c[i * mm2];
+        const double* ZA = &Za[j * mm2];
+        const double* ZC = &Zc[j * mm2];
+        for (int r = 0; r < m; ++r)
+          for (int q = 0; q < m; ++q) {
+            double s1 = 0.0, s2 = 0.0;
+            for (int k = 0; k < m; ++k) {
+              s1 += C[r * m + k] * ZA[k * m + q];
+              s2 += C[r * m + k] * ZC[k * m + q];
+            }
+            B2[r * m + q] -= s1;
+            c2[j * mm2 + r * m + q] = -s2;
+          }
+      }
+    }
+    CrLevel L;
+    L.n = n;
+    L.n_even = ne;
+    L.n_odd = no;
+    int st = upd(a, &L.a);
+    if (st == AGGMG_OK) st = upd(c, &L.c);
+    if (st == AGGMG_OK) st = upd(lu, &L.lu);
+    if (st == AGGMG_OK) st = upi(perm, &L.perm);
+    if (st != AGGMG_OK) {
+      free_cr(cr);
+      return st;
+    }
+    cr->lv.push_back(L);
+    a.swap(a2);
+    b.swap(b2);
+    c.swap(c2);
+    n = ne;
+    if ((int)cr->lv.size() > kCrMaxLevels) {
+      free_cr(cr);
+      return AGGMG_OK;
+    }
+  }
+  {
+    std::vector<double> lu(mm2);
+    std::vector<int32_t> perm(m);
+    if (!pivot_cond(&b[0]) || !lu_perm(m, &b[0], lu.data(), perm.data())) {
+      free_cr(cr);
+      return AGGMG_OK;
+    }
+    const double* p = nullptr;
+    const int32_t* q = nullptr;
+    int st = upd(lu, &p);
+    if (st == AGGMG_OK) st = upi(perm, &q);
+    if (st != AGGMG_OK) {
+      free_cr(cr);
+      return st;
+    }
+    cr->lu_last = p;
+    cr->perm_last = q;
+  }
+  cr->cond_est = cond;
+  if (!(cond < 1e13)) {  // a pivot block is close to singular: elimination without pivoting across
+    free_cr(cr);         // blocks is not trustworthy here, keep the pivoted banded LU
+    return AGGMG_OK;
+  }
+  // split: per-level launches while a level has more than kCrTailRows rows, one LDS kernel after
+  const int nl = (int)cr->lv.size();
+  int g = 0;
+  while (g < nl && cr->lv[g].n * m > kCrTailRows) ++g;
+  if (nl - g > 16) {
+    free_cr(cr);
+    return AGGMG_OK;
+  }
+  cr->nglobal = g;
+  int64_t rows = 0;
+  for (int l = g; l < nl; ++l) rows += cr->lv[l].n * m;
+  cr->tail_lds = (size_t)(rows + m) * sizeof(double);
+  for (int l = 0; l <= g; ++l) {
+    const int64_t len = (l < nl ? cr->lv[l].n : 1) * m;
+    double *dd = nullptr, *xx = nullptr;
+    HIPCHK(hipMalloc((void**)&dd, len * sizeof(double)));
+    cr->owned.push_back(dd);
+    HIPCHK(hipMalloc((void**)&xx, len * sizeof(double)));
+    cr->owned.push_back(xx);
+    cr->d.push_back(dd);
+    cr->x.push_back(xx);
+  }
+  cr->valid = true;
+  return AGGMG_OK;
+}
+
+template <int M>
+static int cr_solve_t(aggmg_ctx* ctx, CrDev& cr, const double* rhs, double* out) {
+  const int nl = (int)cr.lv.size();
+  const int64_t Npad = cr.n0 * M;
+  if (Npad > cr.N) HIPCHK(hipMemsetAsync(cr.d[0] + cr.N, 0, (Npad - cr.N) * sizeof(double), ctx->stream));
+  HIPCHK(hipMemcpyAsync(cr.d[0], rhs, cr.N * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+  for (int l = 0; l < cr.nglobal; ++l) {
+    const int64_t nt = cr.lv[l].n_even;
+    hipLaunchKernelGGL((cr_forward_kernel<M>), dim3((unsigned)((nt + kThreads - 1) / kThreads)), dim3(kThreads), 0,
+                       ctx->stream, cr.lv[l], (const double*)cr.d[l], cr.d[l + 1]);
+  }
+  {
+    CrTail T;
+    std::memset(&T, 0, sizeof(T));
+    T.nlev = nl - cr.nglobal;
+    for (int l = 0; l < T.nlev; ++l) T.lv[l] = cr.lv[cr.nglobal + l];
+    T.lu_last = cr.lu_last;
+    T.perm_last = cr.perm_last;
+    hipLaunchKernelGGL((cr_tail_kernel<M>), dim3(1), dim3(1024), cr.tail_lds, ctx->stream, T,
+                       (const double*)cr.d[cr.nglobal], cr.x[cr.nglobal]);
+  }
+  for (int l = cr.nglobal - 1; l >= 0; --l) {
+    const int64_t nt = cr.lv[l].n;
+    hipLaunchKernelGGL((cr_backward_kernel<M>), dim3((unsigned)((nt + kThreads - 1) / kThreads)), dim3(kThreads), 0,
+                       ctx->stream, cr.lv[l], (const double*)cr.d[l], (const double*)cr.x[l + 1], cr.x[l]);
+  }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(out, cr.x[0], cr.N * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+  return AGGMG_OK;
+}
+
+static int cr_solve(aggmg_ctx* ctx, CrDev& cr, const double* rhs, double* out, int level) {
+  ProfScope ps(ctx, AGGMG_KIND_COARSE, level);
+  switch (cr.m) {
+    case 1: return cr_solve_t<1>(ctx, cr, rhs, out);
+    case 2: return cr_solve_t<2>(ctx, cr, rhs, out);
+    case 3: return cr_solve_t<3>(ctx, cr, rhs, out);
+    case 4: return cr_solve_t<4>(ctx, cr, rhs, out);
+    case 5: return cr_solve_t<5>(ctx, cr, rhs, out);
+    case 6: return cr_solve_t<6>(ctx, cr, rhs, out);
+    case 7: return cr_solve_t<7>(ctx, cr, rhs, out);
+    case 8: return cr_solve_t<8>(ctx, cr, rhs, out);
+  }
+  return fail(ctx, AGGMG_ERR_UNSUPPORTED, "cyclic reduction block size not instantiated");
+}
+
+// ---------------------------------------------------------------------------------------------
 // hierarchy + V-cycle
 // ---------------------------------------------------------------------------------------------
 // structured transfer: every fine row's stored columns lie in the mc modes of coarse element
@@ -1201,6 +1528,7 @@ extern "C" int aggmg_hier_free(aggmg_ctx* ctx, aggmg_hier* h) {
       if (p) (void)hipFree(p);
     if (l.tb && l.tb->lf) (void)hipFree(l.tb->lf);
   }
+  free_cr(&h->cr);
   delete h;
   return AGGMG_OK;
 }
@@ -1213,7 +1541,8 @@ extern "C" int aggmg_hier_create(aggmg_ctx* ctx, int nlevels, aggmg_op* const* s
   if (nlevels < 1 || nlevels > 16) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_hier_create: nlevels must be in 1..16");
   if (nlevels > 1 && (!smoothers || !interpolation))
     return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_hier_create: smoothers / interpolation missing");
-  if (coarse_mode != AGGMG_COARSE_HOST_BANDED) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_hier_create: unknown coarse_mode");
+  if (coarse_mode != AGGMG_COARSE_HOST_BANDED && coarse_mode != AGGMG_COARSE_DEVICE_CR && coarse_mode != AGGMG_COARSE_AUTO)
+    return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_hier_create: unknown coarse_mode");
   HIPCHK(hipSetDevice(ctx->device));
   std::unique_ptr<aggmg_hier> h(new aggmg_hier());
   h->coarse_mode = coarse_mode;
@@ -1250,14 +1579,26 @@ extern "C" int aggmg_hier_create(aggmg_ctx* ctx, int nlevels, aggmg_op* const* s
   {
     const aggmg_op* Ac = h->lv[nlevels - 1].A;
     if (!Ac->host_valid) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_hier_create: host copy of the coarsest operator was released");
-    CHECK(banded_factor(ctx, Ac->host, Ac->m, &h->coarse));
-    h->h_coarse.assign(Ac->m, 0.0);
+    if (coarse_mode != AGGMG_COARSE_HOST_BANDED) {
+      int hint = 0;
+      if (nlevels >= 2 && h->lv[nlevels - 2].tb) hint = h->lv[nlevels - 2].tb->mc;
+      CHECK(cr_setup(ctx, Ac->host, Ac->m, hint, &h->cr));
+      if (!h->cr.valid && coarse_mode == AGGMG_COARSE_DEVICE_CR)
+        return fail(ctx, AGGMG_ERR_UNSUPPORTED,
+                    "aggmg_hier_create: coarsest operator is not block-tridiagonal with well-conditioned pivot "
+                    "blocks; device cyclic reduction not applicable");
+    }
+    if (!h->cr.valid) {
+      CHECK(banded_factor(ctx, Ac->host, Ac->m, &h->coarse));
+      h->h_coarse.assign(Ac->m, 0.0);
+    }
   }
   *out = h.release();
   return AGGMG_OK;
 }
 
 static int coarse_solve(aggmg_ctx* ctx, aggmg_hier* h, const double* rhs_dev, double* u_dev) {
+  if (h->cr.valid) return cr_solve(ctx, h->cr, rhs_dev, u_dev, (int)h->lv.size() - 1);
   const int64_t n = h->coarse.n;
   HIPCHK(hipMemcpyAsync(h->h_coarse.data(), rhs_dev, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -1401,6 +1742,15 @@ extern "C" int aggmg_vcycle(aggmg_ctx* ctx, aggmg_hier* h, const double* x0, con
   CHECK(dout.alloc(N, nullptr));
   CHECK(aggmg_vcycle_dev(ctx, h, dx.p, db.p, nPre, nPost, alpha, dout.p));
   return dout.fetch(N, x_out);
+}
+
+extern "C" int aggmg_hier_coarse_info(aggmg_ctx* ctx, const aggmg_hier* h, int* on_device, int* block_size,
+                                      double* cond_est) {
+  if (!ctx || !h) return AGGMG_ERR_ARGUMENT;
+  if (on_device) *on_device = h->cr.valid ? 1 : 0;
+  if (block_size) *block_size = h->cr.valid ? h->cr.m : 0;
+  if (cond_est) *cond_est = h->cr.valid ? h->cr.cond_est : 0.0;
+  return AGGMG_OK;
 }
 
 extern "C" int aggmg_hier_last_coarse_ms(aggmg_ctx* ctx, const aggmg_hier* h, double* ms) {

@@ -210,7 +210,8 @@ def main():
                    "fine_dofs": N, "level_dofs": level_sizes, "nPre": nPre, "nPost": nPost,
                    "parallelism": "single GPU"},
         "achieved_algorithmic_GBs_vcycle": vcycle_bytes * args.steps / dt / 1e9,
-        "coarse_solve_ms_per_step": coarse_ms / args.steps,
+        "coarse_solve": H.coarse_info(),
+        "coarse_solve_host_ms_per_step": coarse_ms / args.steps,
         "value_excl_coarse_solve": N * (nPre + nPost) / max(1e-3 * (ms_per_step - coarse_ms / args.steps), 1e-12),
         "roofline": {"bound": "hbm", "kernel": f"btd_fused_kernel<{args.p + 1},cmp> {dkind} level {dlevel + 1}",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

@@ -115,7 +115,12 @@ int aggmg_restrict_dev(aggmg_ctx* ctx, aggmg_op* L, const double* r, double* rc_
 int aggmg_prolong_add_dev(aggmg_ctx* ctx, aggmg_op* L, const double* uc, double* u_inout);
 
 /* ---- hierarchy: MeshHierarchy + multigrid_v_cycle ------------------------------------------- */
-#define AGGMG_COARSE_HOST_BANDED 0 /* factor once on the host (banded LU, partial pivoting) */
+/* Coarsest level `u[n] = A_n \\ rhs[n]` (src/solvers.jl:39; UMFPACK re-factorises per cycle in the
+ * reference, here the factorisation is done once at aggmg_hier_create). */
+#define AGGMG_COARSE_HOST_BANDED 0 /* banded LU with partial pivoting on the host (D2H, solve, H2D) */
+#define AGGMG_COARSE_DEVICE_CR 1   /* block cyclic reduction on the device; error if not applicable */
+#define AGGMG_COARSE_AUTO 2        /* device cyclic reduction when the operator is block-tridiagonal
+                                      with well-conditioned pivot blocks, host banded LU otherwise */
 /* Mirrors the operator vectors of `struct MeshHierarchy` src/mesh_heirarchy.jl:17-28:
  * stiffness[nlevels], smoothers[nlevels-1] (the coarsest level is solved directly,
  * src/solvers.jl:39), interpolation[nlevels-1] with interpolation[k]: level k+1 -> level k.
@@ -130,6 +135,10 @@ int aggmg_vcycle(aggmg_ctx* ctx, aggmg_hier* h, const double* x0, const double* 
                  int nPost, double alpha, double* x_out);
 int aggmg_vcycle_dev(aggmg_ctx* ctx, aggmg_hier* h, const double* x0, const double* b, int nPre,
                      int nPost, double alpha, double* x_out);
+/* Which coarsest solver a hierarchy uses: on_device (1 = cyclic reduction), its block size and the
+ * largest pivot-block condition estimate met while factoring (0 for the host solver). */
+int aggmg_hier_coarse_info(aggmg_ctx* ctx, const aggmg_hier* h, int* on_device, int* block_size,
+                           double* cond_est);
 /* Milliseconds the last aggmg_vcycle* call spent in the coarsest direct solve (host path:
  * D2H + solve + H2D, measured with the host clock). */
 int aggmg_hier_last_coarse_ms(aggmg_ctx* ctx, const aggmg_hier* h, double* ms);
@@ -148,7 +157,7 @@ int aggmg_hier_last_coarse_ms(aggmg_ctx* ctx, const aggmg_hier* h, double* ms);
 #define AGGMG_KIND_PROLONG 5
 #define AGGMG_KIND_JACOBI 6      /* generic CSR fused point-Jacobi sweep */
 #define AGGMG_KIND_BLOCK_APPLY 7 /* generic gather block apply */
-#define AGGMG_KIND_OTHER 8
+#define AGGMG_KIND_COARSE 8      /* device coarsest solve (all its launches) */
 int aggmg_profile_enable(aggmg_ctx* ctx, int on);
 int aggmg_profile_collect(aggmg_ctx* ctx, double* total_ms, int64_t* counts);
 
