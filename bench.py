@@ -178,7 +178,8 @@ def main():
     value = N * (nPre + nPost) * args.steps / dt
     vcycle_bytes = sum(l['vcycle'] for l in bytes_model)
     # dominant kernel by total event time
-    dom = max(prof.items(), key=lambda kv: kv[1][0])
+    cand = {k: v for k, v in prof.items() if k[0] in ("fused_down", "fused_up", "smooth") and k[1] < len(bytes_model)}
+    dom = max(cand.items(), key=lambda kv: kv[1][0])
     (dkind, dlevel), (dms, dcnt) = dom
     lm = bytes_model[dlevel]
     per_launch = {"fused_down": nPre * lm['sweep'] + lm['residual'] + lm['restrict'],
