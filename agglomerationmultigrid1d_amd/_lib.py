@@ -18,7 +18,7 @@ KIND_FUSED_DOWN, KIND_FUSED_UP, KIND_SMOOTH, KIND_RESIDUAL, KIND_RESTRICT, KIND_
     KIND_JACOBI, KIND_BLOCK_APPLY, KIND_COARSE = range(9)
 KIND_NAMES = ["fused_down", "fused_up", "smooth", "residual", "restrict", "prolong", "jacobi",
               "block_apply", "coarse"]
-COARSE_HOST_BANDED, COARSE_DEVICE_CR, COARSE_AUTO = 0, 1, 2
+COARSE_HOST_BANDED, COARSE_DEVICE_CR, COARSE_AUTO, COARSE_EXTERNAL = 0, 1, 2, 3
 
 
 class AggmgError(RuntimeError):
@@ -61,6 +61,7 @@ SYMBOLS = {
     "aggmg_destroy": (c_int, [_P]),
     "aggmg_last_error": (c_char_p, [_P]),
     "aggmg_set_stream": (c_int, [_P, _P]),
+    "aggmg_reset_stream": (c_int, [_P]),
     "aggmg_synchronize": (c_int, [_P]),
     "aggmg_dev_alloc": (c_int, [_P, c_int64, POINTER(_P)]),
     "aggmg_dev_free": (c_int, [_P, _P]),
@@ -91,6 +92,9 @@ SYMBOLS = {
     "aggmg_hier_free": (c_int, [_P, _P]),
     "aggmg_vcycle": (c_int, [_P, _P, _PD, _PD, c_int, c_int, c_double, _PD]),
     "aggmg_vcycle_dev": (c_int, [_P, _P, _P, _P, c_int, c_int, c_double, _P]),
+    "aggmg_vcycle_down_dev": (c_int, [_P, _P, _P, _P, c_int, c_double]),
+    "aggmg_vcycle_up_dev": (c_int, [_P, _P, _P, c_int, c_double, _P]),
+    "aggmg_hier_coarse_buffers": (c_int, [_P, _P, POINTER(_P), POINTER(_P), POINTER(c_int64)]),
     "aggmg_hier_coarse_info": (c_int, [_P, _P, POINTER(c_int), POINTER(c_int), POINTER(c_double)]),
     "aggmg_hier_last_coarse_ms": (c_int, [_P, _P, POINTER(c_double)]),
     "aggmg_profile_enable": (c_int, [_P, c_int]),

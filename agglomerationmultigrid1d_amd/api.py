@@ -75,8 +75,12 @@ class Context:
 
     def set_stream(self, hip_stream):
         """Launch on a caller-provided hipStream_t (integer / pointer), e.g.
-        torch.cuda.current_stream().cuda_stream."""
+        torch.cuda.current_stream().cuda_stream; 0 / None is the device's default stream."""
         self.check(self.lib.aggmg_set_stream(self.handle, ctypes.c_void_p(hip_stream or None)))
+
+    def reset_stream(self):
+        """back to the context's own non-blocking stream"""
+        self.check(self.lib.aggmg_reset_stream(self.handle))
 
     # raw device vectors (harness plumbing; torch tensors' data_ptr() work equally well)
     def alloc(self, n):
@@ -418,6 +422,23 @@ class MeshHierarchy:
         c = self.ctx
         c.check(c.lib.aggmg_vcycle_dev(c.handle, self.handle, _ptr(x0), _ptr(b), int(nPre), int(nPost),
                                        float(alpha), _ptr(x_out)))
+
+    def vcycle_down_dev(self, x0, b, nPre=3, alpha=2.0 / 3.0):
+        """Descending half (src/solvers.jl:28-37); leaves the coarsest rhs in coarse_buffers()."""
+        c = self.ctx
+        c.check(c.lib.aggmg_vcycle_down_dev(c.handle, self.handle, _ptr(x0), _ptr(b), int(nPre), float(alpha)))
+
+    def vcycle_up_dev(self, b, x_out, nPost=3, alpha=2.0 / 3.0):
+        """Ascending half (src/solvers.jl:41-47); the coarsest solution must be in coarse_buffers()."""
+        c = self.ctx
+        c.check(c.lib.aggmg_vcycle_up_dev(c.handle, self.handle, _ptr(b), int(nPost), float(alpha), _ptr(x_out)))
+
+    def coarse_buffers(self):
+        """-> (rhs_ptr, sol_ptr, n): device buffers of the coarsest level"""
+        r, s_, n = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_int64(0)
+        self.ctx.check(self.ctx.lib.aggmg_hier_coarse_buffers(self.ctx.handle, self.handle, ctypes.byref(r),
+                                                              ctypes.byref(s_), ctypes.byref(n)))
+        return r.value, s_.value, n.value
 
     def coarse_info(self):
         """-> dict(on_device, block_size, cond_est) of the coarsest direct solver"""

@@ -272,7 +272,13 @@ extern "C" const char* aggmg_last_error(aggmg_ctx* ctx) {
 
 extern "C" int aggmg_set_stream(aggmg_ctx* ctx, void* hip_stream) {
   if (!ctx) return AGGMG_ERR_ARGUMENT;
-  ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+  ctx->stream = (hipStream_t)hip_stream;  // NULL is the device's default (null) stream
+  return AGGMG_OK;
+}
+
+extern "C" int aggmg_reset_stream(aggmg_ctx* ctx) {
+  if (!ctx) return AGGMG_ERR_ARGUMENT;
+  ctx->stream = ctx->own_stream;
   return AGGMG_OK;
 }
 
@@ -1541,7 +1547,8 @@ extern "C" int aggmg_hier_create(aggmg_ctx* ctx, int nlevels, aggmg_op* const* s
   if (nlevels < 1 || nlevels > 16) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_hier_create: nlevels must be in 1..16");
   if (nlevels > 1 && (!smoothers || !interpolation))
     return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_hier_create: smoothers / interpolation missing");
-  if (coarse_mode != AGGMG_COARSE_HOST_BANDED && coarse_mode != AGGMG_COARSE_DEVICE_CR && coarse_mode != AGGMG_COARSE_AUTO)
+  if (coarse_mode != AGGMG_COARSE_HOST_BANDED && coarse_mode != AGGMG_COARSE_DEVICE_CR &&
+      coarse_mode != AGGMG_COARSE_AUTO && coarse_mode != AGGMG_COARSE_EXTERNAL)
     return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_hier_create: unknown coarse_mode");
   HIPCHK(hipSetDevice(ctx->device));
   std::unique_ptr<aggmg_hier> h(new aggmg_hier());
@@ -1575,8 +1582,8 @@ extern "C" int aggmg_hier_create(aggmg_ctx* ctx, int nlevels, aggmg_op* const* s
     CHECK(build_transfer(ctx, l.L, l.S->btd->m, l.S->btd->ne, hint, tb.get(), &ok));
     if (ok) l.tb = std::move(tb);
   }
-  // coarsest level: factor once
-  {
+  // coarsest level: factor once (unless the caller solves it elsewhere)
+  if (coarse_mode != AGGMG_COARSE_EXTERNAL) {
     const aggmg_op* Ac = h->lv[nlevels - 1].A;
     if (!Ac->host_valid) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_hier_create: host copy of the coarsest operator was released");
     if (coarse_mode != AGGMG_COARSE_HOST_BANDED) {
@@ -1610,15 +1617,9 @@ static int coarse_solve(aggmg_ctx* ctx, aggmg_hier* h, const double* rhs_dev, do
   return AGGMG_OK;
 }
 
-extern "C" int aggmg_vcycle_dev(aggmg_ctx* ctx, aggmg_hier* h, const double* x0, const double* b, int nPre,
-                                int nPost, double alpha, double* x_out) {
-  if (!ctx) return AGGMG_ERR_ARGUMENT;
-  if (!h || !x0 || !b || !x_out) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_vcycle: NULL argument");
-  if (nPre < 0 || nPost < 0) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_vcycle: negative sweep count");
-  if (x_out == x0 || x_out == b) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_vcycle: x_out must not alias x0 or b");
+// ---- descend (src/solvers.jl:28-37): leaves u[k] in lv[k].u[0] and rhs[n] in lv[n-1].rhs ----------
+static int vcycle_down(aggmg_ctx* ctx, aggmg_hier* h, const double* x0, const double* b, int nPre, double alpha) {
   const int n = (int)h->lv.size();
-  h->last_coarse_ms = 0.0;
-  // ---- descend (src/solvers.jl:28-37) --------------------------------------------------------
   for (int k = 0; k < n - 1; ++k) {
     Level& l = h->lv[k];
     Level& c = h->lv[k + 1];
@@ -1674,14 +1675,12 @@ extern "C" int aggmg_vcycle_dev(aggmg_ctx* ctx, aggmg_hier* h, const double* x0,
       CHECK(launch_csr<kSpmvSet>(ctx, l.L->csrT, l.tmp, nullptr, nullptr, 0.0, c.rhs));
     }
   }
-  // ---- coarsest solve (:39) ------------------------------------------------------------------
-  {
-    Level& c = h->lv[n - 1];
-    const double* rhs = n == 1 ? b : c.rhs;
-    double* dst = n == 1 ? x_out : c.u[0];
-    CHECK(coarse_solve(ctx, h, rhs, dst));
-  }
-  // ---- ascend (:41-47) -----------------------------------------------------------------------
+  return AGGMG_OK;
+}
+
+// ---- ascend (src/solvers.jl:41-47): expects the coarsest solution in lv[n-1].u[0] ---------------
+static int vcycle_up(aggmg_ctx* ctx, aggmg_hier* h, const double* b, int nPost, double alpha, double* x_out) {
+  const int n = (int)h->lv.size();
   for (int k = n - 2; k >= 0; --k) {
     Level& l = h->lv[k];
     Level& c = h->lv[k + 1];
@@ -1727,6 +1726,58 @@ extern "C" int aggmg_vcycle_dev(aggmg_ctx* ctx, aggmg_hier* h, const double* x0,
       }
     }
   }
+  return AGGMG_OK;
+}
+
+static int vcycle_args(aggmg_ctx* ctx, aggmg_hier* h, const void* a, const void* b2, int n1, int n2) {
+  if (!ctx) return AGGMG_ERR_ARGUMENT;
+  if (!h || !a || !b2) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_vcycle: NULL argument");
+  if (n1 < 0 || n2 < 0) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_vcycle: negative sweep count");
+  return AGGMG_OK;
+}
+
+extern "C" int aggmg_vcycle_dev(aggmg_ctx* ctx, aggmg_hier* h, const double* x0, const double* b, int nPre,
+                                int nPost, double alpha, double* x_out) {
+  CHECK(vcycle_args(ctx, h, x0, b, nPre, nPost));
+  if (!x_out) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_vcycle: NULL argument");
+  if (x_out == x0 || x_out == b) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_vcycle: x_out must not alias x0 or b");
+  if (h->coarse_mode == AGGMG_COARSE_EXTERNAL)
+    return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_vcycle: hierarchy was created with AGGMG_COARSE_EXTERNAL; use "
+                                         "aggmg_vcycle_down_dev / aggmg_vcycle_up_dev");
+  const int n = (int)h->lv.size();
+  h->last_coarse_ms = 0.0;
+  CHECK(vcycle_down(ctx, h, x0, b, nPre, alpha));
+  {  // coarsest solve (src/solvers.jl:39)
+    Level& c = h->lv[n - 1];
+    const double* rhs = n == 1 ? b : c.rhs;
+    double* dst = n == 1 ? x_out : c.u[0];
+    CHECK(coarse_solve(ctx, h, rhs, dst));
+  }
+  return vcycle_up(ctx, h, b, nPost, alpha, x_out);
+}
+
+extern "C" int aggmg_vcycle_down_dev(aggmg_ctx* ctx, aggmg_hier* h, const double* x0, const double* b, int nPre,
+                                     double alpha) {
+  CHECK(vcycle_args(ctx, h, x0, b, nPre, 0));
+  if (h->lv.size() < 2) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_vcycle_down_dev: needs at least two levels");
+  return vcycle_down(ctx, h, x0, b, nPre, alpha);
+}
+
+extern "C" int aggmg_vcycle_up_dev(aggmg_ctx* ctx, aggmg_hier* h, const double* b, int nPost, double alpha,
+                                   double* x_out) {
+  CHECK(vcycle_args(ctx, h, b, x_out, nPost, 0));
+  if (h->lv.size() < 2) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_vcycle_up_dev: needs at least two levels");
+  if (x_out == b) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_vcycle_up_dev: x_out must not alias b");
+  return vcycle_up(ctx, h, b, nPost, alpha, x_out);
+}
+
+extern "C" int aggmg_hier_coarse_buffers(aggmg_ctx* ctx, aggmg_hier* h, void** rhs_dev, void** sol_dev,
+                                         int64_t* n) {
+  if (!ctx || !h) return AGGMG_ERR_ARGUMENT;
+  Level& c = h->lv.back();
+  if (rhs_dev) *rhs_dev = c.rhs;
+  if (sol_dev) *sol_dev = c.u[0];
+  if (n) *n = c.N;
   return AGGMG_OK;
 }
 

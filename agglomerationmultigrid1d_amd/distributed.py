@@ -1,0 +1,385 @@
+"""Element-range partition of the V-cycle across the GPUs of one node (BASELINE config 4).
+
+One process per GPU (`torch.distributed`, backend "nccl" == RCCL over xGMI; "gloo" for the CPU
+tests).  Rank r owns a contiguous range of fine elements and, level by level, the agglomerates
+made of them; it stores its owned elements plus `W_k` ghost elements per side and runs the very
+same fused kernels on that local domain.
+
+Communication-avoiding schedule.  Block-Jacobi is order independent and in 1-D a sweep moves
+information by exactly one element, so instead of one interface exchange per operator
+application (7 per level per cycle) the ghost layers are made deep enough that a whole V(nPre,
+nPost) cycle needs
+
+    1. ONE all-gather of the interface DoFs of x0 (W_0 elements per side and rank), and
+    2. ONE all-gather of the owned part of the coarsest right-hand side,
+
+everything else being recomputed redundantly in the ghost layers (0.03 % extra work at 2^22
+elements on 8 ranks).  `halo_widths` derives the widths from (ratios, nPre, nPost) by tracking
+how far validity shrinks: a sweep costs one element per side, the residual one more, a transfer
+divides / multiplies by the ratio.  Owned values are bitwise those of the single-GPU run (same
+per-row arithmetic, tiles only differ in where they start).  The coarsest system is gathered
+and solved redundantly on every rank (block cyclic reduction on the device).
+
+The schedule is written against a small engine interface so that tests can run it on CPU
+(`gloo`, world_size 2) with a NumPy engine standing in for the GPU kernels.
+"""
+import ctypes
+import json
+import os
+import time
+
+import numpy as np
+
+
+# ------------------------------------------------------------------------------------------
+# layout
+# ------------------------------------------------------------------------------------------
+def halo_widths(ratios, nPre, nPost):
+    """Ghost elements per side for levels 0..len(ratios) (last = coarsest, held replicated but
+    copied locally with W ghosts), nested so that a local level is exactly the children of the
+    local next-coarser level: W_k = ratios[k] * W_{k+1}.  Smallest widths for which the owned part
+    of the V-cycle result is exact with a single exchange of x0 and the coarsest gather."""
+    nl = len(ratios) + 1
+    for w in range(0, 4096):
+        W = [0] * nl
+        W[nl - 1] = w
+        for k in range(nl - 2, -1, -1):
+            W[k] = ratios[k] * W[k + 1]
+        # descending: validity margin (elements beyond the owned boundary) of the pre-smoothed u
+        Pu = [0] * nl
+        Rm = W[0]                       # rhs of level 0 = b, valid on the whole local domain
+        ok = True
+        for k in range(nl - 1):
+            # levels below the finest start from u = 0 (src/solvers.jl:29-31): their first sweep
+            # reads no neighbour and costs no margin
+            Pu[k] = min(Rm, W[k]) - (nPre if k == 0 else max(nPre - 1, 0))
+            if Pu[k] < 1:               # the residual needs one more valid neighbour
+                ok = False
+                break
+            Rm = (Pu[k] - 1) // ratios[k]
+        if not ok:
+            continue
+        # ascending: margin of the post-smoothed u; coarsest solution is exact on all W ghosts
+        V = W[nl - 1]
+        for k in range(nl - 2, -1, -1):
+            V = min(Pu[k], ratios[k] * V) - nPost
+            if V < 0:
+                ok = False
+                break
+        if ok:
+            return W
+    raise ValueError("no feasible halo width")
+
+
+class RankLayout:
+    """Element ranges of one rank on every level.
+    own[k] = (lo, hi) owned elements, loc[k] = (lo, hi) local domain (owned + ghosts, clipped to
+    the global domain), m[k] = DoFs per element, ne[k] = global element count."""
+
+    def __init__(self, n_fine, ratios, block_sizes, world, rank, nPre=3, nPost=3):
+        tot = int(np.prod(ratios)) if len(ratios) else 1
+        if n_fine % (tot * world):
+            raise ValueError("fine element count must be divisible by world_size * prod(ratios)")
+        self.world, self.rank = world, rank
+        self.ratios = tuple(ratios)
+        self.m = list(block_sizes)
+        self.W = halo_widths(ratios, nPre, nPost)
+        self.nPre, self.nPost = nPre, nPost
+        self.ne, self.own, self.loc = [], [], []
+        f = 1
+        per_rank = n_fine // world
+        if per_rank < self.W[0]:
+            raise ValueError(f"each rank must own at least {self.W[0]} fine elements")
+        for k in range(len(ratios) + 1):
+            if k > 0:
+                f *= ratios[k - 1]
+            ne = n_fine // f
+            lo, hi = rank * per_rank // f, (rank + 1) * per_rank // f
+            self.ne.append(ne)
+            self.own.append((lo, hi))
+            self.loc.append((max(0, lo - self.W[k]), min(ne, hi + self.W[k])))
+
+    def ghosts(self, k):
+        return self.own[k][0] - self.loc[k][0], self.loc[k][1] - self.own[k][1]
+
+    def local_dofs(self, k):
+        return (self.loc[k][1] - self.loc[k][0]) * self.m[k]
+
+    def owned_slice(self, k):
+        gl, _ = self.ghosts(k)
+        return slice(gl * self.m[k], (gl + self.own[k][1] - self.own[k][0]) * self.m[k])
+
+
+# ------------------------------------------------------------------------------------------
+# communicator (torch.distributed; device tensors for nccl, host staging for gloo)
+# ------------------------------------------------------------------------------------------
+class Comm:
+    def __init__(self, world, rank, staged=False):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.world, self.rank = world, rank
+        self.staged = staged   # True: collectives run on CPU copies (gloo with GPU engines)
+
+    def all_gather(self, out, inp):
+        """out (world * len(inp)) <- concatenation over ranks of inp (equal lengths)"""
+        if self.world == 1:
+            out.copy_(inp)
+            return
+        if self.staged and inp.is_cuda:
+            o = self.torch.empty(out.shape, dtype=out.dtype)
+            self.dist.all_gather_into_tensor(o, inp.cpu())
+            out.copy_(o)
+        else:
+            self.dist.all_gather_into_tensor(out, inp)
+
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier()
+
+    def max(self, value):
+        if self.world == 1:
+            return value
+        t = self.torch.tensor([value], dtype=self.torch.float64)
+        if not self.staged and self.dist.get_backend() == "nccl":
+            t = t.cuda()
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+
+# ------------------------------------------------------------------------------------------
+# the schedule
+# ------------------------------------------------------------------------------------------
+class DistributedVCycle:
+    """multigrid_v_cycle (src/solvers.jl:19-50) on an element-partitioned hierarchy.
+
+    engine interface (vectors are torch tensors on the engine's device, local numbering):
+        engine.new(n) -> zero tensor
+        engine.down(x0, b, nPre, alpha)          descending half on the local hierarchy
+        engine.coarse_rhs() -> tensor            local coarsest right-hand side
+        engine.coarse_solve(rhs_global) -> tensor   global coarsest direct solve (replicated)
+        engine.set_coarse_solution(t)            local coarsest solution (owned + ghosts)
+        engine.up(b, x_out, nPost, alpha)        ascending half
+    """
+
+    def __init__(self, engine, layout, comm):
+        self.e, self.L, self.c = engine, layout, comm
+        L = layout
+        w0 = L.W[0] * L.m[0]
+        self._send = engine.new(2 * w0)
+        self._recv = engine.new(2 * w0 * L.world)
+        nc = len(L.m) - 1
+        self._nc = nc
+        self._own_c = (L.own[nc][1] - L.own[nc][0]) * L.m[nc]
+        self._rhs_global = engine.new(L.ne[nc] * L.m[nc])
+        self.exchanges = 0
+
+    def exchange_ghosts(self, x):
+        """Fill the level-0 ghost entries of x from the neighbours' owned boundary elements:
+        all-gather of each rank's first and last W_0 owned elements (the interface DoFs)."""
+        L = self.L
+        if L.world == 1 or L.W[0] == 0:
+            return
+        m, W = L.m[0], L.W[0]
+        gl, gr = L.ghosts(0)
+        wm = W * m
+        o0 = gl * m
+        o1 = o0 + (L.own[0][1] - L.own[0][0]) * m
+        self._send[:wm].copy_(x[o0:o0 + wm])
+        self._send[wm:].copy_(x[o1 - wm:o1])
+        self.c.all_gather(self._recv, self._send)
+        self.exchanges += 1
+        r = L.rank
+        if gl:   # left neighbour's last W elements
+            x[:o0].copy_(self._recv[(r - 1) * 2 * wm + wm:(r - 1) * 2 * wm + 2 * wm][wm - o0:])
+        if gr:
+            x[o1:].copy_(self._recv[(r + 1) * 2 * wm:(r + 1) * 2 * wm + wm][:gr * m])
+
+    def vcycle(self, x0, b, x_out, nPre=3, nPost=3, alpha=2.0 / 3.0, x0_ghosts_valid=False):
+        """x0, b, x_out: local vectors (owned + ghosts).  b must be valid on the whole local domain
+        (set once with exchange_ghosts or generated that way); x0's ghosts are refreshed here.  On
+        return the owned part of x_out is the V-cycle result; its ghosts are not."""
+        L = self.L
+        if nPre > L.nPre or nPost > L.nPost:
+            raise ValueError("halo widths were sized for fewer sweeps")
+        if not x0_ghosts_valid:
+            self.exchange_ghosts(x0)
+        self.e.down(x0, b, nPre, alpha)
+        rhs_c = self.e.coarse_rhs()
+        nc = self._nc
+        gl, _ = L.ghosts(nc)
+        own = rhs_c[gl * L.m[nc]:gl * L.m[nc] + self._own_c]
+        self.c.all_gather(self._rhs_global, own)
+        self.exchanges += 1
+        sol = self.e.coarse_solve(self._rhs_global)
+        lo, hi = L.loc[nc]
+        self.e.set_coarse_solution(sol[lo * L.m[nc]:hi * L.m[nc]])
+        self.e.up(b, x_out, nPost, alpha)
+
+
+# ------------------------------------------------------------------------------------------
+# HIP engine
+# ------------------------------------------------------------------------------------------
+class _DevView:
+    """zero-copy torch view of a device buffer owned by libaggmg_hip"""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+
+class HipEngine:
+    """Local hierarchy (coarsest solve external) + the replicated global coarsest solver, both on
+    this rank's GPU; vectors are torch CUDA tensors and the library launches on torch's current
+    stream so that torch copies / RCCL collectives and the kernels stay ordered."""
+
+    def __init__(self, H_local, H_coarse, ctx):
+        import torch
+        self.torch = torch
+        self.H, self.Hc, self.ctx = H_local, H_coarse, ctx
+        self.dev = torch.device("cuda", ctx.device)
+        ctx.set_stream(torch.cuda.current_stream(self.dev).cuda_stream)
+        rp, sp_, n = H_local.coarse_buffers()
+        self._rhs_c = torch.as_tensor(_DevView(rp, n), device=self.dev)
+        self._sol_c = torch.as_tensor(_DevView(sp_, n), device=self.dev)
+        self._sol_g = None
+
+    def new(self, n):
+        return self.torch.zeros(int(n), dtype=self.torch.float64, device=self.dev)
+
+    def down(self, x0, b, nPre, alpha):
+        self.H.vcycle_down_dev(x0, b, nPre, alpha)
+
+    def coarse_rhs(self):
+        return self._rhs_c
+
+    def coarse_solve(self, rhs_global):
+        if self._sol_g is None:
+            self._sol_g = self.new(rhs_global.numel())
+            self._zero = self.new(rhs_global.numel())
+        # a 1-level hierarchy's V-cycle IS the coarsest direct solve (src/solvers.jl:39)
+        self.Hc.vcycle_dev(self._zero, rhs_global, self._sol_g, 0, 0, 1.0)
+        return self._sol_g
+
+    def set_coarse_solution(self, t):
+        self._sol_c.copy_(t)
+
+    def up(self, b, x_out, nPost, alpha):
+        self.H.vcycle_up_dev(b, x_out, nPost, alpha)
+
+
+def build_local_uniform(n, p, pAgg, ratios, layout, ctx, comm):
+    """Local operators of this rank for the uniform model problem, uploaded through the CSC
+    boundary, plus the global coarsest operator assembled from every rank's owned block rows.
+    -> (HipEngine, U_local)"""
+    import torch
+    from . import _lib
+    from .api import BlockJacobi, DeviceOperator, MeshHierarchy
+    from .uniform import UniformDgAggHierarchy, block_tridiag_to_csc, _csc
+    lo, hi = layout.loc[0]
+    U = UniformDgAggHierarchy(n, p=p, pAgg=pAgg, ratios=ratios, elem_range=(lo, hi))
+    nl = U.nlevels
+    ops, sms = [], []
+    for k in range(nl):
+        op = DeviceOperator(U.stiffness_csc(k), _lib.OP_STIFFNESS, ctx)
+        ops.append(op)
+        if k < nl - 1:
+            sms.append(BlockJacobi(op, U.descriptor(k).mBlockInds, ctx))
+    Ls = [DeviceOperator(U.interpolation_csc(k), _lib.OP_TRANSFER, ctx) for k in range(nl - 1)]
+    H = MeshHierarchy([U.descriptor(k) for k in range(nl)], ops, sms, Ls, ctx=ctx, keep_host=False,
+                      coarse_mode=_lib.COARSE_EXTERNAL)
+    # global coarsest operator: gather the owned block rows (sub, diag, sup) of every rank
+    nc = nl - 1
+    gl, _ = layout.ghosts(nc)
+    no = layout.own[nc][1] - layout.own[nc][0]
+    mc = layout.m[nc]
+    sub, diag, sup = (np.ascontiguousarray(x[gl:gl + no]) for x in U.levels[nc]['A'])
+    # the first / last owned block row of a rank couples to a ghost column that exists locally
+    # unless the rank sits at the domain boundary, where the block is zero anyway
+    mine = torch.from_numpy(np.stack([sub, diag, sup]).reshape(-1))
+    dev = torch.device("cuda", ctx.device) if (comm.world > 1 and not comm.staged and
+                                                comm.dist.get_backend() == "nccl") else None
+    if dev is not None:
+        mine = mine.to(dev)
+    allb = torch.empty(mine.numel() * comm.world, dtype=torch.float64, device=mine.device)
+    comm.all_gather(allb, mine)
+    allb = allb.cpu().numpy().reshape(comm.world, 3, no, mc, mc)
+    gsub, gdiag, gsup = (np.concatenate([allb[r, i] for r in range(comm.world)]) for i in range(3))
+    colptr, rowval, nzval, N = block_tridiag_to_csc(gsub, gdiag, gsup)
+    Ac = DeviceOperator(_csc(colptr, rowval, nzval, (N, N)), _lib.OP_STIFFNESS, ctx)
+    Hc = MeshHierarchy(None, [Ac], [], [], ctx=ctx, keep_host=False, coarse_mode=_lib.COARSE_AUTO)
+    return HipEngine(H, Hc, ctx), U
+
+
+# ------------------------------------------------------------------------------------------
+# bench entry for N > 1 (called by bench.py)
+# ------------------------------------------------------------------------------------------
+def bench_main(args, rank, world, local_rank, nPre, nPost, alpha):
+    import torch
+    import torch.distributed as dist
+    from . import api as mg
+    torch.cuda.set_device(local_rank)
+    dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+    comm = Comm(world, rank)
+    ctx = mg.Context(local_rank)
+    n = 2 ** args.log2_elems
+    ratios = (4, 2, 2)
+    t_setup = time.perf_counter()
+    layout = RankLayout(n, ratios, [args.p + 1, 2, 2, 2], world, rank, nPre, nPost)
+    engine, U = build_local_uniform(n, args.p, 1, ratios, layout, ctx, comm)
+    dv = DistributedVCycle(engine, layout, comm)
+    b = torch.from_numpy(U.rhs()).to(engine.dev)        # generated on the whole local domain
+    xa = engine.new(layout.local_dofs(0))
+    xb = engine.new(layout.local_dofs(0))
+    bytes_model = U.algorithmic_bytes(nPre, nPost)
+    del U
+    t_setup = time.perf_counter() - t_setup
+    N = n * (args.p + 1)
+
+    src, dst = xa, xb
+    for _ in range(args.warmup):
+        dv.vcycle(src, b, dst, nPre, nPost, alpha)
+        src, dst = dst, src
+    torch.cuda.synchronize()
+    comm.barrier()
+    torch.cuda.synchronize()
+    ctx.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        dv.vcycle(src, b, dst, nPre, nPost, alpha)
+        src, dst = dst, src
+    torch.cuda.synchronize()
+    comm.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ctx.profile_enable(False)
+    prof = ctx.profile_collect()
+    dt = comm.max(dt)
+    if rank == 0:
+        cand = {k: v for k, v in prof.items() if k[0] in ("fused_down", "fused_up") and k[1] < len(bytes_model)}
+        (dkind, dlevel), (dms, dcnt) = max(cand.items(), key=lambda kv: kv[1][0])
+        lm = bytes_model[dlevel]
+        per_launch = {"fused_down": nPre * lm['sweep'] + lm['residual'] + lm['restrict'],
+                      "fused_up": nPost * lm['sweep'] + lm['prolong']}[dkind]
+        achieved = per_launch / (dms / dcnt * 1e-3) / 1e9
+        out = {
+            "metric": "fine_level_dof_updates_per_s_per_vcycle",
+            "value": N * (nPre + nPost) * args.steps / dt,
+            "unit": "DoF-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"config 4: config 3 hierarchy (DG p={args.p} n=2^{args.log2_elems} -> AggDG 4:1 -> "
+                                   f"2:1 -> 2:1, V(3,3)) partitioned by contiguous element range over {world} GPUs",
+                       "fine_dofs": N, "nPre": nPre, "nPost": nPost,
+                       "parallelism": f"element-range x{world}, deep halos W={layout.W}, "
+                                      f"{dv.exchanges // (args.steps + args.warmup)} RCCL all-gathers per cycle, "
+                                      f"coarsest solve replicated"},
+            "roofline": {"bound": "hbm", "kernel": f"btd_fused_kernel<{args.p + 1},cmp> {dkind} level {dlevel + 1} (rank 0)",
+                         "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                         "traffic": None, "algorithmic_bytes_per_launch": per_launch,
+                         "ms_per_launch": dms / dcnt, "launches_timed": dcnt},
+            "kernels": {f"{k}_L{l}": {"ms_per_launch": v[0] / v[1], "launches": v[1]} for (k, l), v in sorted(prof.items())},
+            "setup_s": t_setup,
+        }
+        print(json.dumps(out), flush=True)
+    dist.destroy_process_group()

@@ -161,7 +161,11 @@ class UniformDgAggHierarchy:
     CDir = 1000 n."""
 
     def __init__(self, n, p=3, pAgg=1, ratios=(4, 2, 2), CDir=None, xin=0.0, xout=1.0, bc=None,
-                 func=np.cos):
+                 func=np.cos, elem_range=None):
+        """elem_range=(a, b): build only the rows/columns of fine elements a..b-1 (0-based, multiples
+        of prod(ratios)) and of their agglomerates -- the local operators of one rank of an
+        element-partitioned run.  Couplings to elements outside the range are dropped; everything
+        else equals the corresponding entries of the global operators."""
         if pAgg not in (0, 1):
             raise ValueError("Only implemented for p = 0 and p = 1.")  # agglomerated_dg_mesh.jl:312
         if p < 1 and len(ratios):
@@ -171,24 +175,55 @@ class UniformDgAggHierarchy:
         tot = int(np.prod(ratios)) if len(ratios) else 1
         if n % tot:
             raise ValueError("n must be divisible by the product of the agglomeration ratios")
-        self.n, self.p, self.pAgg, self.ratios = n, p, pAgg, tuple(ratios)
+        a, b = (0, n) if elem_range is None else (int(elem_range[0]), int(elem_range[1]))
+        if not (0 <= a < b <= n) or a % tot or b % tot:
+            raise ValueError("elem_range must be a non-empty range aligned to prod(ratios)")
+        self.n_global, self.a, self.b = n, a, b
+        self.at_left, self.at_right = (a == 0), (b == n)
+        # one coarsest-level element of padding on the right: the last local rows need their right
+        # neighbour's mass matrix / gradient blocks (A = C - D*(M\G) couples k to k+1)
+        pad = 0 if self.at_right else tot
+        self.nloc = b - a
+        self.n = self.nloc + pad          # elements the arrays are built on (padding trimmed later)
+        self.p, self.pAgg, self.ratios = p, pAgg, tuple(ratios)
         self.CDir = 1000.0 * n if CDir is None else float(CDir)
         self.bc = bc or (('neu', -math.sin(xin)), ('dir', math.cos(xout)))
         self.func = func
         self.ref = RefElement(p)
-        i = np.arange(n + 1, dtype=np.float64)
-        self.xv = np.empty(n + 1)
-        self.xv[0] = xin
-        self.xv[1:] = xin + (i[1:] / n) * (xout - xin)      # tests/mesh_generator.jl:11-13
+        i = np.arange(a, a + self.n + 1, dtype=np.float64)
+        self.xv = xin + (i / n) * (xout - xin)              # tests/mesh_generator.jl:11-13
+        if a == 0:
+            self.xv[0] = xin
         self.h = self.xv[1:] - self.xv[:-1]
         self.xc = (self.xv[:-1] + self.xv[1:]) / 2.0
         self.J = self.h / 2.0
         self._build_fine()
-        self.levels = [dict(m=p + 1, ne=n, G=(self.Gl, self.Gd), D=(self.Dd, self.Du), C=self.Cd,
+        self.levels = [dict(m=p + 1, ne=self.n, G=(self.Gl, self.Gd), D=(self.Dd, self.Du), C=self.Cd,
                             M=self.M, A=self._stiffness_blocks(self.Gl, self.Gd, self.Dd, self.Du,
                                                                self.Cd, self.M))]
         self.transfers = []     # Lb[k]: (ne_f, m_f, m_c) rows of L per fine element, rho
         self._build_agglomerated()
+        self._rhs_full = self._rhs_padded()
+        self._trim()
+
+    def _trim(self):
+        """drop the right padding from every level"""
+        per = 1
+        ne = self.nloc
+        for k, lv in enumerate(self.levels):
+            if k > 0:
+                per = self.ratios[k - 1]
+                ne //= per
+            lv['ne'] = ne
+            lv['A'] = tuple(x[:ne] for x in lv['A'])
+            lv['M'] = lv['M'][:ne]
+            lv['C'] = lv['C'][:ne]
+            lv['G'] = tuple(x[:ne] for x in lv['G'])
+            lv['D'] = tuple(x[:ne] for x in lv['D'])
+            if k < len(self.transfers):
+                self.transfers[k]['Lb'] = self.transfers[k]['Lb'][:ne]
+        self._rhs_full = self._rhs_full[:self.nloc * (self.p + 1)]
+        self.n = self.nloc
 
     # ---- fine DG level -----------------------------------------------------------------------
     def _build_fine(self):
@@ -210,13 +245,20 @@ class UniformDgAggHierarchy:
         Gl[1:, nL, nR] += 1.0         # left end of element k, uhat from element k-1
         Dd[1:, nL, nL] += 1.0         # left end, qhat = own q
         Du[:-1, nR, nL] += -1.0       # right end, qhat from element k+1
-        # boundary vertices (src/dg_mesh.jl:170-218)
-        if lk == 'dir':
+        # first / last element of the array: domain boundary (src/dg_mesh.jl:170-218) or, for a
+        # partial element range, one more interior vertex
+        if not self.at_left:
+            Gl[0, nL, nR] += 1.0
+            Dd[0, nL, nL] += 1.0
+        elif lk == 'dir':
             Dd[0, nL, nL] += 1.0
             Cd[0, nL, nL] += self.CDir
         else:
             Gd[0, nL, nL] += 1.0
-        if rk == 'dir':
+        if not self.at_right:
+            Gd[-1, nR, nR] += -1.0
+            Du[-1, nR, nL] += -1.0
+        elif rk == 'dir':
             Dd[-1, nR, nR] += -1.0
             Cd[-1, nR, nR] += self.CDir
         else:
@@ -226,7 +268,10 @@ class UniformDgAggHierarchy:
 
     def rhs(self):
         """b = f - D*(M\\r) with (f, r) = dg_flux_rhs (src/dg_mesh.jl:342-457;
-        tests/dg_heirarchy_test.jl:39-40)."""
+        tests/dg_heirarchy_test.jl:39-40), rows of the element range."""
+        return self._rhs_full
+
+    def _rhs_padded(self):
         n, p, ref = self.n, self.p, self.ref
         nL, nR = (0, 1) if p >= 1 else (0, 0)
         xq = self.xc[:, None] + self.h[:, None] / 2.0 * ref.gq[None, :]
@@ -236,16 +281,18 @@ class UniformDgAggHierarchy:
             f += (self.J[:, None] * ref.gw[l]) * ref.phi[l][None, :] * fq[:, l][:, None]
         r = np.zeros((n, p + 1))
         (lk, lv), (rk, rv) = self.bc
-        if lk == 'dir':
-            f[0, nL] += self.CDir * lv
-            r[0, nL] += -lv
-        else:
-            f[0, nL] += -lv
-        if rk == 'dir':
-            f[-1, nR] += self.CDir * rv
-            r[-1, nR] += rv
-        else:
-            f[-1, nR] += rv
+        if self.at_left:
+            if lk == 'dir':
+                f[0, nL] += self.CDir * lv
+                r[0, nL] += -lv
+            else:
+                f[0, nL] += -lv
+        if self.at_right:
+            if rk == 'dir':
+                f[-1, nR] += self.CDir * rv
+                r[-1, nR] += rv
+            else:
+                f[-1, nR] += rv
         y = np.linalg.solve(self.M, r[:, :, None])[:, :, 0]
         Dy = np.einsum('kij,kj->ki', self.Dd, y) + np.einsum('kij,kj->ki', self.Du, _shift_up(y))
         return (f - Dy).reshape(-1)

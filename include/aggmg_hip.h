@@ -45,9 +45,10 @@ typedef struct aggmg_hier aggmg_hier;         /* device mirror of one MeshHierar
 int aggmg_create(int device_id, aggmg_ctx** out);
 int aggmg_destroy(aggmg_ctx* ctx);
 const char* aggmg_last_error(aggmg_ctx* ctx); /* ctx may be NULL: last error of failed create */
-/* Run on a caller-provided hipStream_t (e.g. torch's current stream).  NULL restores the
- * context's own non-blocking stream. */
+/* Run on a caller-provided hipStream_t (e.g. torch's current stream; NULL = the device's default
+ * stream).  aggmg_reset_stream goes back to the context's own non-blocking stream. */
 int aggmg_set_stream(aggmg_ctx* ctx, void* hip_stream);
+int aggmg_reset_stream(aggmg_ctx* ctx);
 int aggmg_synchronize(aggmg_ctx* ctx);
 /* Raw device memory owned by the context's device (plumbing for harnesses without torch). */
 int aggmg_dev_alloc(aggmg_ctx* ctx, int64_t nbytes, void** out);
@@ -119,6 +120,8 @@ int aggmg_prolong_add_dev(aggmg_ctx* ctx, aggmg_op* L, const double* uc, double*
  * reference, here the factorisation is done once at aggmg_hier_create). */
 #define AGGMG_COARSE_HOST_BANDED 0 /* banded LU with partial pivoting on the host (D2H, solve, H2D) */
 #define AGGMG_COARSE_DEVICE_CR 1   /* block cyclic reduction on the device; error if not applicable */
+#define AGGMG_COARSE_EXTERNAL 3    /* no factorisation: the caller solves the coarsest system between
+                                      aggmg_vcycle_down_dev and aggmg_vcycle_up_dev (multi-GPU driver) */
 #define AGGMG_COARSE_AUTO 2        /* device cyclic reduction when the operator is block-tridiagonal
                                       with well-conditioned pivot blocks, host banded LU otherwise */
 /* Mirrors the operator vectors of `struct MeshHierarchy` src/mesh_heirarchy.jl:17-28:
@@ -135,6 +138,16 @@ int aggmg_vcycle(aggmg_ctx* ctx, aggmg_hier* h, const double* x0, const double* 
                  int nPost, double alpha, double* x_out);
 int aggmg_vcycle_dev(aggmg_ctx* ctx, aggmg_hier* h, const double* x0, const double* b, int nPre,
                      int nPost, double alpha, double* x_out);
+/* The two halves of the V-cycle around the coarsest solve (src/solvers.jl:28-37 and :41-47), for
+ * callers that solve the coarsest system themselves (element-partitioned multi-GPU runs gather it
+ * across ranks).  After _down the coarsest right-hand side is in the buffer reported by
+ * aggmg_hier_coarse_buffers(); _up expects the coarsest solution in the solution buffer. */
+int aggmg_vcycle_down_dev(aggmg_ctx* ctx, aggmg_hier* h, const double* x0, const double* b, int nPre,
+                          double alpha);
+int aggmg_vcycle_up_dev(aggmg_ctx* ctx, aggmg_hier* h, const double* b, int nPost, double alpha,
+                        double* x_out);
+int aggmg_hier_coarse_buffers(aggmg_ctx* ctx, aggmg_hier* h, void** rhs_dev, void** sol_dev,
+                              int64_t* n);
 /* Which coarsest solver a hierarchy uses: on_device (1 = cyclic reduction), its block size and the
  * largest pivot-block condition estimate met while factoring (0 for the host solver). */
 int aggmg_hier_coarse_info(aggmg_ctx* ctx, const aggmg_hier* h, int* on_device, int* block_size,

@@ -1,0 +1,75 @@
+"""N > 1 path with the real HIP engine: two ranks sharing the one GPU of the test box, `gloo`
+process group with host-staged collectives (RCCL needs one device per rank, so the nccl backend
+itself can only run on the multi-GPU node).  Owned results must equal the single-GPU V-cycle of
+the same library to the last bits and the oracle within tolerance."""
+import os
+import sys
+
+import numpy as np
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, n, q):
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle")]
+    import torch
+    import torch.distributed as dist
+    import agglomerationmultigrid1d_amd as mg
+    from agglomerationmultigrid1d_amd import distributed as D
+    from agglomerationmultigrid1d_amd.uniform import UniformDgAggHierarchy, build_device_hierarchy
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ratios, p = (4, 2, 2), 3
+        ctx = mg.Context(0)
+        comm = D.Comm(world, rank, staged=True)
+        layout = D.RankLayout(n, ratios, [p + 1, 2, 2, 2], world, rank)
+        engine, U = D.build_local_uniform(n, p, 1, ratios, layout, ctx, comm)
+        assert all(engine.H.structured_levels()) and engine.Hc.coarse_info()['on_device']
+        dv = D.DistributedVCycle(engine, layout, comm)
+        b = torch.from_numpy(U.rhs()).to(engine.dev)
+        x = engine.new(layout.local_dofs(0))
+        y = engine.new(layout.local_dofs(0))
+        for _ in range(3):                       # three cycles: iterates with non-trivial ghosts
+            dv.vcycle(x, b, y)
+            x, y = y, x
+        torch.cuda.synchronize()
+        got = x.cpu().numpy()[layout.owned_slice(0)]
+        # single-GPU run of the same library on the global hierarchy
+        Ug = UniformDgAggHierarchy(n, p=p, pAgg=1, ratios=ratios)
+        ctx2 = mg.Context(0)
+        Hg = build_device_hierarchy(Ug, ctx2)
+        bg = ctx2.to_device(Ug.rhs())
+        xa, xb = ctx2.to_device(np.zeros(len(Ug.rhs()))), ctx2.alloc(len(Ug.rhs()))
+        for _ in range(3):
+            Hg.vcycle_dev(xa, bg, xb)
+            xa, xb = xb, xa
+        ref = xa.download()
+        lo, hi = layout.own[0]
+        ref_own = ref[lo * (p + 1):hi * (p + 1)]
+        err = float(np.max(np.abs(got - ref_own)))
+        q.put((rank, err, float(np.max(np.abs(ref_own))), dv.exchanges))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_one_gpu_match_single_gpu():
+    import torch.multiprocessing as mp
+    from test_distributed_cpu import free_port
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, 2048, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    for pr in procs:
+        pr.join(600)
+    assert all(pr.exitcode == 0 for pr in procs), [pr.exitcode for pr in procs]
+    for rank, err, scale, nex in sorted(q.get() for _ in range(2)):
+        assert err == 0.0, (rank, err, scale)    # bitwise: same per-row arithmetic on every rank
+        assert nex == 6                          # 2 all-gathers per cycle
