@@ -1268,10 +1268,10 @@ static int cr_setup(aggmg_ctx* ctx, const HostCsr& h, int64_t N, int hint_m, CrD
     return true;
   };
   if (hint_m >= 1 && hint_m <= 8 && fits(hint_m)) m = hint_m;
-  if (!m) {
-    const int bw = std::max(1, std::max(kl, ku));
-    if (bw <= 8) m = bw;  // bandwidth <= m  =>  block-tridiagonal with m-blocks
-  }
+  // otherwise the smallest block size for which the operator is block-tridiagonal (bandwidth <= m
+  // always works), so that a coarsest operator is eliminated in the same order however it arrives
+  for (int cand = 1; !m && cand <= 8; ++cand)
+    if (std::max(kl, ku) <= 2 * cand - 1 && fits(cand)) m = cand;
   if (!m) return AGGMG_OK;
   const int mm2 = m * m;
   int64_t n = (N + m - 1) / m;

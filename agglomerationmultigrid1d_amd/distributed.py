@@ -318,10 +318,15 @@ def bench_main(args, rank, world, local_rank, nPre, nPost, alpha):
     import torch
     import torch.distributed as dist
     from . import api as mg
-    torch.cuda.set_device(local_rank)
-    dist.init_process_group(backend="nccl", rank=rank, world_size=world)
-    comm = Comm(world, rank)
-    ctx = mg.Context(local_rank)
+    # AGGMG_DIST_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks
+    # (host-staged collectives, ranks share devices); the driver's runs use nccl == RCCL.
+    backend = os.environ.get("AGGMG_DIST_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    device = local_rank % max(ndev, 1)
+    torch.cuda.set_device(device)
+    dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    comm = Comm(world, rank, staged=(backend != "nccl"))
+    ctx = mg.Context(device)
     n = 2 ** args.log2_elems
     ratios = (4, 2, 2)
     t_setup = time.perf_counter()
@@ -371,6 +376,7 @@ def bench_main(args, rank, world, local_rank, nPre, nPost, alpha):
             "config": {"workload": f"config 4: config 3 hierarchy (DG p={args.p} n=2^{args.log2_elems} -> AggDG 4:1 -> "
                                    f"2:1 -> 2:1, V(3,3)) partitioned by contiguous element range over {world} GPUs",
                        "fine_dofs": N, "nPre": nPre, "nPost": nPost,
+                       "backend": backend,
                        "parallelism": f"element-range x{world}, deep halos W={layout.W}, "
                                       f"{dv.exchanges // (args.steps + args.warmup)} RCCL all-gathers per cycle, "
                                       f"coarsest solve replicated"},
