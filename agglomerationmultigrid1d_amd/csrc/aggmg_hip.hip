@@ -99,7 +99,8 @@ struct aggmg_smoother {
 
 struct TransferBtd {
   int mc = 0, rho = 0;
-  double* lf = nullptr;  // [N_f][mc]
+  double* lf = nullptr;  // [N_f][mc]  rows of L
+  double* ld = nullptr;  // [N_f][mc]  rows of (L_e' D_e)': restriction of the preconditioned residual
 };
 
 struct Level {
@@ -759,7 +760,7 @@ struct BtdTile {
 template <int M, bool CMP>
 static int launch_btd_t(aggmg_ctx* ctx, FusedArgs a, int halo) {
   using T = BtdTile<M, CMP>;
-  const int align = a.lf_out ? a.rho_out : 1;
+  const int align = (a.lf_out || a.ld_out) ? a.rho_out : 1;
   int owned = ((T::TE - 2 * halo) / align) * align;
   if (owned <= 0) return fail(ctx, AGGMG_ERR_UNSUPPORTED, "fused tile too small for the requested halo");
   a.owned = owned;
@@ -1487,8 +1488,8 @@ static int cr_solve(aggmg_ctx* ctx, CrDev& cr, const double* rhs, double* out, i
 // ---------------------------------------------------------------------------------------------
 // structured transfer: every fine row's stored columns lie in the mc modes of coarse element
 // J = (fine element) / rho
-static int build_transfer(aggmg_ctx* ctx, const aggmg_op* L, int mf, int64_t nef, int hint_mc, TransferBtd* out,
-                          bool* ok) {
+static int build_transfer(aggmg_ctx* ctx, const aggmg_op* L, const aggmg_op* A, int mf, int64_t nef, int hint_mc,
+                          TransferBtd* out, bool* ok) {
   *ok = false;
   if (!L->host_valid) return AGGMG_OK;
   const HostCsr& h = L->host;
@@ -1517,6 +1518,21 @@ static int build_transfer(aggmg_ctx* ctx, const aggmg_op* L, int mf, int64_t nef
       for (int32_t p = h.rowptr[r]; p < h.rowptr[r + 1]; ++p) lf[r * mc + (h.colind[p] - J * mc)] = h.vals[p];
     }
     CHECK(dev_upload(ctx, lf, &out->lf));
+    if (A && A->host_valid) {
+      // ld[(e,j)][c] = sum_i L[(e,i)][c] * D_e[i][j]  so that  L' r = sum_rows ld * (B^{-1} r)
+      std::vector<double> ld((size_t)Nf * mc, 0.0), D((size_t)mf * mf);
+      for (int64_t e = 0; e < nef; ++e) {
+        for (int i = 0; i < mf; ++i)
+          for (int j = 0; j < mf; ++j) D[i * mf + j] = host_entry(A->host, e * mf + i, e * mf + j);
+        for (int j = 0; j < mf; ++j)
+          for (int c = 0; c < mc; ++c) {
+            double acc = 0.0;
+            for (int i = 0; i < mf; ++i) acc += lf[(e * mf + i) * mc + c] * D[i * mf + j];
+            ld[(e * mf + j) * mc + c] = acc;
+          }
+      }
+      CHECK(dev_upload(ctx, ld, &out->ld));
+    }
     out->mc = mc;
     out->rho = (int)rho;
     *ok = true;
@@ -1533,6 +1549,7 @@ extern "C" int aggmg_hier_free(aggmg_ctx* ctx, aggmg_hier* h) {
     for (double* p : {l.u[0], l.u[1], l.rhs, l.tmp})
       if (p) (void)hipFree(p);
     if (l.tb && l.tb->lf) (void)hipFree(l.tb->lf);
+    if (l.tb && l.tb->ld) (void)hipFree(l.tb->ld);
   }
   free_cr(&h->cr);
   delete h;
@@ -1579,7 +1596,7 @@ extern "C" int aggmg_hier_create(aggmg_ctx* ctx, int nlevels, aggmg_op* const* s
     if (k + 2 < nlevels && h->lv[k + 1].S && h->lv[k + 1].S->btd) hint = h->lv[k + 1].S->btd->m;
     auto tb = std::make_unique<TransferBtd>();
     bool ok = false;
-    CHECK(build_transfer(ctx, l.L, l.S->btd->m, l.S->btd->ne, hint, tb.get(), &ok));
+    CHECK(build_transfer(ctx, l.L, l.A, l.S->btd->m, l.S->btd->ne, hint, tb.get(), &ok));
     if (ok) l.tb = std::move(tb);
   }
   // coarsest level: factor once (unless the caller solves it elsewhere)
@@ -1634,7 +1651,10 @@ static int vcycle_down(aggmg_ctx* ctx, aggmg_hier* h, const double* x0, const do
       a.alpha = alpha;
       a.nsweeps = nPre;
       a.do_residual = 1;
-      a.lf_out = l.tb->lf;
+      if (l.tb->ld)
+        a.ld_out = l.tb->ld;  // restrict B^{-1} r with (L'D): the kernel then reads neither D nor L
+      else
+        a.lf_out = l.tb->lf;
       a.rc_out = c.rhs;
       a.mc_out = l.tb->mc;
       a.rho_out = l.tb->rho;

@@ -137,16 +137,33 @@ struct FusedArgs {
   // optional residual after the sweeps (src/solvers.jl:36), stored and/or restricted
   int do_residual;
   double* r_out;         // may be nullptr
-  const double* lf_out;  // [N][mc_out]; nullptr: no restriction
-  double* rc_out;        // rc = L' r
+  const double* lf_out;  // [N][mc_out] rows of L: rc = L' r from the explicit residual
+  const double* ld_out;  // [N][mc_out] rows of (L_e' D_e)': rc = (L'D) w, w = B^{-1} r -- no D, no L read
+  double* rc_out;        // restricted residual
   int mc_out, rho_out;
   // tiling
   int owned;      // owned elements per tile (multiple of rho_out)
   int halo_left;  // elements of halo on the left of the owned range
 };
 
+// sum / broadcast inside the group of W consecutive lanes holding one element's rows (W = 2^k):
+// DPP / permute cross-lane moves, no LDS traffic, no barrier
+template <int W>
+__device__ __forceinline__ double group_sum(double v) {
+#pragma unroll
+  for (int off = W / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, W);
+  return v;
+}
+template <int W>
+__device__ __forceinline__ double group_bcast(double v, int j) {
+  return __shfl(v, j, W);
+}
+
 template <int M, bool CMP, int NS>
 __global__ __launch_bounds__(kThreads) void btd_fused_kernel(FusedArgs a) {
+  // GRP: the rows of one element sit in M = 2^k adjacent lanes, so element-wide sums and
+  // broadcasts (q.u+, B^{-1} b) go through cross-lane moves instead of LDS round trips
+  constexpr bool GRP = CMP && (M == 2 || M == 4 || M == 8);
   constexpr int EPS = kThreads / M;  // elements per slab
   constexpr int TE = EPS * NS;       // elements per tile (owned + halos)
   extern __shared__ double lds[];
@@ -169,9 +186,11 @@ __global__ __launch_bounds__(kThreads) void btd_fused_kernel(FusedArgs a) {
     buf1[TE * M + tid] = 0.0;
   }
 
+  // the stencil form (B^{-1} rows, P, Q) is only needed when something is swept or restricted
+  const bool need_g = a.nsweeps > 0 || a.ld_out != nullptr;
   double g[NS], bb[NS], uu[NS];
   double bi[NS][M];                              // B^{-1} rows, dead after g is formed
-  double binv_r[NS], sc[NS], pc[NS], qv[NS][M];  // CMP
+  double binv_r[NS], pc[NS], qv[NS][GRP ? 1 : M];  // CMP (GRP: own entry of the q row only)
   double Pr[NS][M], Qr[NS][M];                   // dense
   bool valid[NS];
 
@@ -187,34 +206,45 @@ __global__ __launch_bounds__(kThreads) void btd_fused_kernel(FusedArgs a) {
 #pragma unroll
     for (int j = 0; j < M; ++j) bi[s][j] = 0.0;
     if (valid[s]) {
+      if (need_g) {
 #pragma unroll
-      for (int j = 0; j < M; ++j) bi[s][j] = a.lv.binv[row * M + j];
+        for (int j = 0; j < M; ++j) bi[s][j] = a.lv.binv[row * M + j];
+      }
       bb[s] = a.b[row];
       if (a.u_in) uu[s] = a.u_in[row];
       if (CMP) {
-        sc[s] = a.lv.scol[row];
-        pc[s] = a.lv.pcol[row];
+        pc[s] = need_g ? a.lv.pcol[row] : 0.0;
+        if (GRP) {
+          qv[s][0] = a.lv.qrow[e * M + i];
+        } else {
 #pragma unroll
-        for (int j = 0; j < M; ++j) qv[s][j] = a.lv.qrow[e * M + j];
+          for (int j = 0; j < (GRP ? 1 : M); ++j) qv[s][j] = a.lv.qrow[e * M + j];
+        }
       } else {
 #pragma unroll
         for (int j = 0; j < M; ++j) {
-          Pr[s][j] = a.lv.P[row * M + j];
-          Qr[s][j] = a.lv.Q[row * M + j];
+          Pr[s][j] = need_g ? a.lv.P[row * M + j] : 0.0;
+          Qr[s][j] = need_g ? a.lv.Q[row * M + j] : 0.0;
         }
       }
       if (a.lf_in) {  // u += L uc : J = e / rho, ascending mode order (CSC scatter order)
         const int64_t J = e / a.rho_in;
         double add = 0.0;
-        for (int c = 0; c < a.mc_in; ++c) add += a.lf_in[row * a.mc_in + c] * a.uc[J * a.mc_in + c];
+        if (a.mc_in == 2) {  // one 16-byte load each for the L row and the coarse pair
+          const double2 l2 = *reinterpret_cast<const double2*>(a.lf_in + row * 2);
+          const double2 u2 = *reinterpret_cast<const double2*>(a.uc + J * 2);
+          add = l2.x * u2.x;
+          add += l2.y * u2.y;
+        } else {
+          for (int c = 0; c < a.mc_in; ++c) add += a.lf_in[row * a.mc_in + c] * a.uc[J * a.mc_in + c];
+        }
         uu[s] += add;
       }
     } else {
       if (CMP) {
-        sc[s] = 0.0;
         pc[s] = 0.0;
 #pragma unroll
-        for (int j = 0; j < M; ++j) qv[s][j] = 0.0;
+        for (int j = 0; j < (GRP ? 1 : M); ++j) qv[s][j] = 0.0;
       } else {
 #pragma unroll
         for (int j = 0; j < M; ++j) {
@@ -229,23 +259,35 @@ __global__ __launch_bounds__(kThreads) void btd_fused_kernel(FusedArgs a) {
       if (j == a.lv.r_sup) binv_r[s] = bi[s][j];
     if (active) {
       buf0[x * M + i] = uu[s];
-      buf1[x * M + i] = bb[s];
+      if (!GRP) buf1[x * M + i] = bb[s];
     }
   }
-  __syncthreads();
-  // g = B^{-1} b  (the element's whole b_e is read back from LDS)
+  if (GRP) {
+    // g = B^{-1} b with the element's b_e broadcast across its lane group
 #pragma unroll
-  for (int s = 0; s < NS; ++s) {
-    const int x = s * EPS + le;
-    g[s] = 0.0;
-    if (active) {
+    for (int s = 0; s < NS; ++s) {
       double acc = 0.0;
 #pragma unroll
-      for (int j = 0; j < M; ++j) acc += bi[s][j] * buf1[x * M + j];
+      for (int j = 0; j < M; ++j) acc += bi[s][j] * group_bcast<M>(bb[s], j);
       g[s] = acc;
     }
+    __syncthreads();
+  } else {
+    __syncthreads();
+    // g = B^{-1} b  (the element's whole b_e is read back from LDS)
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const int x = s * EPS + le;
+      g[s] = 0.0;
+      if (active) {
+        double acc = 0.0;
+#pragma unroll
+        for (int j = 0; j < M; ++j) acc += bi[s][j] * buf1[x * M + j];
+        g[s] = acc;
+      }
+    }
+    __syncthreads();
   }
-  __syncthreads();
 
   // ---- sweeps: LDS ping-pong ---------------------------------------------------------------
   double* cur = buf0;
@@ -261,8 +303,12 @@ __global__ __launch_bounds__(kThreads) void btd_fused_kernel(FusedArgs a) {
         if (CMP) {
           acc -= pc[s] * um[a.lv.c_sub];
           double dot = 0.0;
+          if (GRP) {
+            dot = group_sum<M>(qv[s][0] * up[i]);
+          } else {
 #pragma unroll
-          for (int j = 0; j < M; ++j) dot += qv[s][j] * up[j];
+            for (int j = 0; j < (GRP ? 1 : M); ++j) dot += qv[s][j] * up[j];
+          }
           acc -= binv_r[s] * dot;
         } else {
 #pragma unroll
@@ -294,40 +340,78 @@ __global__ __launch_bounds__(kThreads) void btd_fused_kernel(FusedArgs a) {
 
   if (!a.do_residual) return;
 
-  // ---- residual r = b - A u on the owned elements, ascending column order -------------------
   double rr[NS];
+  const double* lfo = a.lf_out;
+  if (a.r_out || a.lf_out) {
+    // ---- explicit residual r = b - A u on the owned elements, ascending column order ---------
 #pragma unroll
-  for (int s = 0; s < NS; ++s) {
-    const int x = s * EPS + le;
-    rr[s] = 0.0;
-    if (valid[s] && x >= xo0 && x < xo1) {
-      const int64_t e = e0 + x;
-      const int64_t row = e * M + i;
-      const double* um = cur + (x - 1) * M;
-      const double* ux = cur + x * M;
-      const double* up = cur + (x + 1) * M;
-      double t = 0.0;
-      if (CMP) {
-        t += sc[s] * um[a.lv.c_sub];
+    for (int s = 0; s < NS; ++s) {
+      const int x = s * EPS + le;
+      rr[s] = 0.0;
+      if (valid[s] && x >= xo0 && x < xo1) {
+        const int64_t e = e0 + x;
+        const int64_t row = e * M + i;
+        const double* um = cur + (x - 1) * M;
+        const double* ux = cur + x * M;
+        const double* up = cur + (x + 1) * M;
+        double t = 0.0;
+        if (CMP) {
+          t += a.lv.scol[row] * um[a.lv.c_sub];
 #pragma unroll
-        for (int j = 0; j < M; ++j) t += a.lv.dblk[row * M + j] * ux[j];
-        if (i == a.lv.r_sup) {
+          for (int j = 0; j < M; ++j) t += a.lv.dblk[row * M + j] * ux[j];
+          if (GRP) {
+            const double d = group_sum<M>(qv[s][0] * up[i]);
+            if (i == a.lv.r_sup) t += d;
+          } else if (i == a.lv.r_sup) {
 #pragma unroll
-          for (int j = 0; j < M; ++j) t += qv[s][j] * up[j];
+            for (int j = 0; j < (GRP ? 1 : M); ++j) t += qv[s][j] * up[j];
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < M; ++j) t += a.lv.sub[row * M + j] * um[j];
+#pragma unroll
+          for (int j = 0; j < M; ++j) t += a.lv.dblk[row * M + j] * ux[j];
+#pragma unroll
+          for (int j = 0; j < M; ++j) t += a.lv.sup[row * M + j] * up[j];
         }
-      } else {
-#pragma unroll
-        for (int j = 0; j < M; ++j) t += a.lv.sub[row * M + j] * um[j];
-#pragma unroll
-        for (int j = 0; j < M; ++j) t += a.lv.dblk[row * M + j] * ux[j];
-#pragma unroll
-        for (int j = 0; j < M; ++j) t += a.lv.sup[row * M + j] * up[j];
+        rr[s] = bb[s] - t;
+        if (a.r_out) a.r_out[row] = rr[s];
       }
-      rr[s] = bb[s] - t;
-      if (a.r_out) a.r_out[row] = rr[s];
+    }
+  } else if (a.ld_out) {
+    // ---- preconditioned residual w = B^{-1}(b - A u) = g - P u- - u - Q u+ : what one more
+    // sweep would add (before alpha); restricted with the precomputed (L'D) rows, so neither the
+    // diagonal blocks nor L are read
+    lfo = a.ld_out;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const int x = s * EPS + le;
+      rr[s] = 0.0;
+      if (valid[s] && x >= xo0 && x < xo1) {
+        const double* um = cur + (x - 1) * M;
+        const double* up = cur + (x + 1) * M;
+        double acc = g[s];
+        if (CMP) {
+          acc -= pc[s] * um[a.lv.c_sub];
+          double dot = 0.0;
+          if (GRP) {
+            dot = group_sum<M>(qv[s][0] * up[i]);
+          } else {
+#pragma unroll
+            for (int j = 0; j < (GRP ? 1 : M); ++j) dot += qv[s][j] * up[j];
+          }
+          acc -= binv_r[s] * dot;
+        } else {
+#pragma unroll
+          for (int j = 0; j < M; ++j) acc -= Pr[s][j] * um[j];
+#pragma unroll
+          for (int j = 0; j < M; ++j) acc -= Qr[s][j] * up[j];
+        }
+        rr[s] = acc - uu[s];
+      }
     }
   }
-  if (!a.lf_out) return;
+  if (!lfo) return;
 
   // ---- restriction rc = L' r: r through LDS (the idle buffer), one thread per (J, mode) -----
 #pragma unroll
@@ -347,7 +431,7 @@ __global__ __launch_bounds__(kThreads) void btd_fused_kernel(FusedArgs a) {
     const int xb = a.halo_left + Jl * rho;       // first fine element (tile-local)
     const int64_t rowb = (e0 + xb) * (int64_t)M;  // first fine row (global)
     double acc = 0.0;
-    for (int k = 0; k < rho * M; ++k) acc += a.lf_out[(rowb + k) * mc + c] * nxt[xb * M + k];
+    for (int k = 0; k < rho * M; ++k) acc += lfo[(rowb + k) * mc + c] * nxt[xb * M + k];
     a.rc_out[J * mc + c] = acc;
   }
 }
