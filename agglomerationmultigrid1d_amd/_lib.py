@@ -8,7 +8,8 @@ import os
 from ctypes import POINTER, c_char_p, c_double, c_int, c_int32, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libaggmg_hip.so")
+# AGGMG_HIP_LIB points at an alternative build of the same library (kernel tuning experiments)
+LIB_PATH = os.environ.get("AGGMG_HIP_LIB") or os.path.join(_HERE, "libaggmg_hip.so")
 
 AGGMG_OK = 0
 ERR_ARGUMENT, ERR_DIMENSION, ERR_SINGULAR, ERR_HIP, ERR_UNSUPPORTED = -1, -2, -3, -4, -5

@@ -128,9 +128,11 @@ struct CrDev {
   std::vector<void*> owned;     // every device allocation, for free
   const double* lu_last = nullptr;
   const int32_t* perm_last = nullptr;
-  int nglobal = 0;              // levels run as their own launches; the rest go to the tail kernel
+  int nglobal = 0;              // leading levels run as their own launches (only for very large systems)
+  int q = 0;                    // next q levels run chunk-wise in LDS (one launch forward, one backward)
   std::vector<double*> d, x;    // per-level vectors for levels 0..nglobal
-  size_t tail_lds = 0;
+  double *partR = nullptr, *partL = nullptr, *xq = nullptr;  // chunk-boundary vectors (level nglobal+q)
+  size_t tail_lds = 0, chunk_lds = 0;
   double cond_est = 0.0;
 };
 
@@ -752,7 +754,13 @@ template <int M, bool CMP>
 struct BtdTile {
   // slabs per tile: sized so a tile is ~256 elements while the per-thread register arrays
   // (NS x (2..3) x M doubles) stay well under the 128-VGPR / 4-waves-per-SIMD step
-  static constexpr int NS = (M <= 2) ? 2 : (M == 3) ? 3 : (M == 4) ? 4 : (M <= 7) ? 3 : 2;
+#ifndef AGGMG_NS4
+#define AGGMG_NS4 4
+#endif
+#ifndef AGGMG_NS2
+#define AGGMG_NS2 2
+#endif
+  static constexpr int NS = (M == 1) ? 2 : (M == 2) ? AGGMG_NS2 : (M == 3) ? 3 : (M == 4) ? AGGMG_NS4 : (M <= 7) ? 3 : 2;
   static constexpr int EPS = kThreads / M;
   static constexpr int TE = EPS * NS;
 };
@@ -1411,28 +1419,53 @@ static int cr_setup(aggmg_ctx* ctx, const HostCsr& h, int64_t N, int hint_m, CrD
     free_cr(cr);         // blocks is not trustworthy here, keep the pivoted banded LU
     return AGGMG_OK;
   }
-  // split: per-level launches while a level has more than kCrTailRows rows, one LDS kernel after
+  // plan: [g per-level launches, only if a chunk would not fit in LDS] -> q chunk levels (one
+  // forward and one backward launch, every workgroup reducing 2^q + 1 blocks in LDS) -> the tail
+  // (all remaining levels, <= kCrTailRows rows, one workgroup)
   const int nl = (int)cr->lv.size();
-  int g = 0;
-  while (g < nl && cr->lv[g].n * m > kCrTailRows) ++g;
-  if (nl - g > 16) {
+  auto level_n = [&](int l) -> int64_t { return l < nl ? cr->lv[l].n : 1; };
+  int g = 0, q = 0;
+  for (;; ++g) {
+    q = 0;
+    while (g + q < nl && level_n(g + q) * m > kCrTailRows) ++q;
+    const size_t lds = ((size_t)(2 << q) + q + 2) * m * sizeof(double);
+    if (q <= kCrMaxChunkLevels && lds <= 48 * 1024) break;
+    if (g >= nl) break;
+  }
+  if (nl - (g + q) > 16) {
     free_cr(cr);
     return AGGMG_OK;
   }
   cr->nglobal = g;
+  cr->q = q;
+  {
+    size_t o = 0;
+    for (int l = 0; l <= q; ++l) o += ((size_t)(1 << (q - l)) + 1) * m;
+    cr->chunk_lds = o * sizeof(double);
+  }
   int64_t rows = 0;
-  for (int l = g; l < nl; ++l) rows += cr->lv[l].n * m;
+  for (int l = g + q; l < nl; ++l) rows += cr->lv[l].n * m;
   cr->tail_lds = (size_t)(rows + m) * sizeof(double);
+  auto dalloc = [&](int64_t len, double** out) -> int {
+    HIPCHK(hipMalloc((void**)out, (size_t)std::max<int64_t>(len, 1) * sizeof(double)));
+    HIPCHK(hipMemsetAsync(*out, 0, (size_t)std::max<int64_t>(len, 1) * sizeof(double), ctx->stream));
+    cr->owned.push_back(*out);
+    return AGGMG_OK;
+  };
   for (int l = 0; l <= g; ++l) {
-    const int64_t len = (l < nl ? cr->lv[l].n : 1) * m;
     double *dd = nullptr, *xx = nullptr;
-    HIPCHK(hipMalloc((void**)&dd, len * sizeof(double)));
-    cr->owned.push_back(dd);
-    HIPCHK(hipMalloc((void**)&xx, len * sizeof(double)));
-    cr->owned.push_back(xx);
+    CHECK(dalloc(level_n(l) * m, &dd));
+    CHECK(dalloc(level_n(l) * m, &xx));
     cr->d.push_back(dd);
     cr->x.push_back(xx);
   }
+  if (q > 0) {
+    const int64_t nq = level_n(g + q) * m;
+    CHECK(dalloc(nq, &cr->partR));
+    CHECK(dalloc(nq, &cr->partL));  // partL[0] is never written: stays zero
+    CHECK(dalloc(nq, &cr->xq));
+  }
+  HIPCHK(hipStreamSynchronize(ctx->stream));
   cr->valid = true;
   return AGGMG_OK;
 }
@@ -1440,31 +1473,54 @@ static int cr_setup(aggmg_ctx* ctx, const HostCsr& h, int64_t N, int hint_m, CrD
 template <int M>
 static int cr_solve_t(aggmg_ctx* ctx, CrDev& cr, const double* rhs, double* out) {
   const int nl = (int)cr.lv.size();
+  const int g = cr.nglobal, q = cr.q;
   const int64_t Npad = cr.n0 * M;
-  if (Npad > cr.N) HIPCHK(hipMemsetAsync(cr.d[0] + cr.N, 0, (Npad - cr.N) * sizeof(double), ctx->stream));
-  HIPCHK(hipMemcpyAsync(cr.d[0], rhs, cr.N * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
-  for (int l = 0; l < cr.nglobal; ++l) {
+  // without padding the caller's vectors are used in place (no staging copies)
+  const bool direct = (Npad == cr.N) && rhs != out;
+  const double* d0 = direct ? rhs : cr.d[0];
+  double* x0 = direct ? out : cr.x[0];
+  if (!direct) {
+    if (Npad > cr.N) HIPCHK(hipMemsetAsync(cr.d[0] + cr.N, 0, (Npad - cr.N) * sizeof(double), ctx->stream));
+    HIPCHK(hipMemcpyAsync(cr.d[0], rhs, cr.N * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+  }
+  auto dl = [&](int l) -> const double* { return l == 0 ? d0 : cr.d[l]; };
+  auto xl = [&](int l) -> double* { return l == 0 ? x0 : cr.x[l]; };
+  for (int l = 0; l < g; ++l) {
     const int64_t nt = cr.lv[l].n_even;
     hipLaunchKernelGGL((cr_forward_kernel<M>), dim3((unsigned)((nt + kThreads - 1) / kThreads)), dim3(kThreads), 0,
-                       ctx->stream, cr.lv[l], (const double*)cr.d[l], cr.d[l + 1]);
+                       ctx->stream, cr.lv[l], dl(l), cr.d[l + 1]);
   }
-  {
-    CrTail T;
-    std::memset(&T, 0, sizeof(T));
-    T.nlev = nl - cr.nglobal;
-    for (int l = 0; l < T.nlev; ++l) T.lv[l] = cr.lv[cr.nglobal + l];
-    T.lu_last = cr.lu_last;
-    T.perm_last = cr.perm_last;
+  CrTail T;
+  std::memset(&T, 0, sizeof(T));
+  T.nlev = nl - (g + q);
+  for (int l = 0; l < T.nlev; ++l) T.lv[l] = cr.lv[g + q + l];
+  T.lu_last = cr.lu_last;
+  T.perm_last = cr.perm_last;
+  if (q > 0) {
+    CrChunk C;
+    std::memset(&C, 0, sizeof(C));
+    C.q = q;
+    for (int l = 0; l < q; ++l) C.lv[l] = cr.lv[g + l];
+    C.nq = g + q < nl ? cr.lv[g + q].n : 1;
+    // one workgroup per block surviving the chunk levels: chunk c = blocks [c 2^q, (c+1) 2^q]
+    const unsigned grid = (unsigned)C.nq;
+    hipLaunchKernelGGL((cr_chunk_forward_kernel<M>), dim3(std::max(grid, 1u)), dim3(kThreads), cr.chunk_lds,
+                       ctx->stream, C, dl(g), cr.partR, cr.partL);
     hipLaunchKernelGGL((cr_tail_kernel<M>), dim3(1), dim3(1024), cr.tail_lds, ctx->stream, T,
-                       (const double*)cr.d[cr.nglobal], cr.x[cr.nglobal]);
+                       (const double*)cr.partR, (const double*)cr.partL, cr.xq);
+    hipLaunchKernelGGL((cr_chunk_backward_kernel<M>), dim3(std::max(grid, 1u)), dim3(kThreads), cr.chunk_lds,
+                       ctx->stream, C, dl(g), (const double*)cr.xq, xl(g));
+  } else {
+    hipLaunchKernelGGL((cr_tail_kernel<M>), dim3(1), dim3(1024), cr.tail_lds, ctx->stream, T, dl(g),
+                       (const double*)nullptr, xl(g));
   }
-  for (int l = cr.nglobal - 1; l >= 0; --l) {
+  for (int l = g - 1; l >= 0; --l) {
     const int64_t nt = cr.lv[l].n;
     hipLaunchKernelGGL((cr_backward_kernel<M>), dim3((unsigned)((nt + kThreads - 1) / kThreads)), dim3(kThreads), 0,
-                       ctx->stream, cr.lv[l], (const double*)cr.d[l], (const double*)cr.x[l + 1], cr.x[l]);
+                       ctx->stream, cr.lv[l], dl(l), (const double*)cr.x[l + 1], xl(l));
   }
   HIPCHK(hipGetLastError());
-  HIPCHK(hipMemcpyAsync(out, cr.x[0], cr.N * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+  if (!direct) HIPCHK(hipMemcpyAsync(out, cr.x[0], cr.N * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
   return AGGMG_OK;
 }
 

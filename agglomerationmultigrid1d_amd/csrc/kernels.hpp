@@ -146,6 +146,24 @@ struct FusedArgs {
   int halo_left;  // elements of halo on the left of the owned range
 };
 
+// streaming (read-once) operator data: optionally non-temporal so it does not displace the
+// re-read halo / coarse vectors in L2
+// AGGMG_NT bit 0: non-temporal loads of the read-once operator streams; bit 1: non-temporal
+// stores of the iterate (tuning knobs, see tools/exp_fused.py)
+#ifndef AGGMG_NT
+#define AGGMG_NT 2  // measured: non-temporal iterate stores -2.6 % per V-cycle, NT operator loads no gain
+#endif
+#if AGGMG_NT & 1
+#define AGGMG_LD(p) __builtin_nontemporal_load(&(p))
+#else
+#define AGGMG_LD(p) (p)
+#endif
+#if AGGMG_NT & 2
+#define AGGMG_ST(p, v) __builtin_nontemporal_store((v), &(p))
+#else
+#define AGGMG_ST(p, v) ((p) = (v))
+#endif
+
 // sum / broadcast inside the group of W consecutive lanes holding one element's rows (W = 2^k):
 // DPP / permute cross-lane moves, no LDS traffic, no barrier
 template <int W>
@@ -208,14 +226,14 @@ __global__ __launch_bounds__(kThreads) void btd_fused_kernel(FusedArgs a) {
     if (valid[s]) {
       if (need_g) {
 #pragma unroll
-        for (int j = 0; j < M; ++j) bi[s][j] = a.lv.binv[row * M + j];
+        for (int j = 0; j < M; ++j) bi[s][j] = AGGMG_LD(a.lv.binv[row * M + j]);
       }
       bb[s] = a.b[row];
       if (a.u_in) uu[s] = a.u_in[row];
       if (CMP) {
-        pc[s] = need_g ? a.lv.pcol[row] : 0.0;
+        pc[s] = need_g ? AGGMG_LD(a.lv.pcol[row]) : 0.0;
         if (GRP) {
-          qv[s][0] = a.lv.qrow[e * M + i];
+          qv[s][0] = AGGMG_LD(a.lv.qrow[e * M + i]);
         } else {
 #pragma unroll
           for (int j = 0; j < (GRP ? 1 : M); ++j) qv[s][j] = a.lv.qrow[e * M + j];
@@ -223,15 +241,19 @@ __global__ __launch_bounds__(kThreads) void btd_fused_kernel(FusedArgs a) {
       } else {
 #pragma unroll
         for (int j = 0; j < M; ++j) {
-          Pr[s][j] = need_g ? a.lv.P[row * M + j] : 0.0;
-          Qr[s][j] = need_g ? a.lv.Q[row * M + j] : 0.0;
+          Pr[s][j] = need_g ? AGGMG_LD(a.lv.P[row * M + j]) : 0.0;
+          Qr[s][j] = need_g ? AGGMG_LD(a.lv.Q[row * M + j]) : 0.0;
         }
       }
       if (a.lf_in) {  // u += L uc : J = e / rho, ascending mode order (CSC scatter order)
         const int64_t J = e / a.rho_in;
         double add = 0.0;
         if (a.mc_in == 2) {  // one 16-byte load each for the L row and the coarse pair
-          const double2 l2 = *reinterpret_cast<const double2*>(a.lf_in + row * 2);
+          typedef double v2d __attribute__((ext_vector_type(2)));
+          const v2d lv2 = AGGMG_LD(*reinterpret_cast<const v2d*>(a.lf_in + row * 2));
+          double2 l2;
+          l2.x = lv2.x;
+          l2.y = lv2.y;
           const double2 u2 = *reinterpret_cast<const double2*>(a.uc + J * 2);
           add = l2.x * u2.x;
           add += l2.y * u2.y;
@@ -334,7 +356,7 @@ __global__ __launch_bounds__(kThreads) void btd_fused_kernel(FusedArgs a) {
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
       const int x = s * EPS + le;
-      if (valid[s] && x >= xo0 && x < xo1) a.u_out[(e0 + x) * M + i] = uu[s];
+      if (valid[s] && x >= xo0 && x < xo1) AGGMG_ST(a.u_out[(e0 + x) * M + i], uu[s]);
     }
   }
 
@@ -475,12 +497,16 @@ __device__ __forceinline__ void cr_lu_solve(const double* __restrict__ lu, const
   }
 }
 
+// d'_j of the next level from this level's vector d (indexable by level-local block index);
+// neighbours outside [lo, hi] are skipped (domain ends, or chunk ends whose terms another
+// workgroup accounts for)
 template <int M>
-__device__ __forceinline__ void cr_forward_block(const CrLevel& L, int64_t j, const double* d, double* dn) {
+__device__ __forceinline__ void cr_forward_block_range(const CrLevel& L, int64_t j, const double* d, double* dn,
+                                                       int64_t lo, int64_t hi) {
   double acc[M], y[M];
 #pragma unroll
   for (int i = 0; i < M; ++i) acc[i] = d[(2 * j) * M + i];
-  if (j > 0) {
+  if (2 * j - 1 >= lo) {
     cr_lu_solve<M>(L.lu + (j - 1) * M * M, L.perm + (j - 1) * M, d + (2 * j - 1) * M, y);
     const double* A = L.a + (2 * j) * M * M;
 #pragma unroll
@@ -488,7 +514,7 @@ __device__ __forceinline__ void cr_forward_block(const CrLevel& L, int64_t j, co
 #pragma unroll
       for (int k = 0; k < M; ++k) acc[i] -= A[i * M + k] * y[k];
   }
-  if (2 * j + 1 < L.n) {
+  if (2 * j + 1 <= hi) {
     cr_lu_solve<M>(L.lu + j * M * M, L.perm + j * M, d + (2 * j + 1) * M, y);
     const double* C = L.c + (2 * j) * M * M;
 #pragma unroll
@@ -498,6 +524,11 @@ __device__ __forceinline__ void cr_forward_block(const CrLevel& L, int64_t j, co
   }
 #pragma unroll
   for (int i = 0; i < M; ++i) dn[j * M + i] = acc[i];
+}
+
+template <int M>
+__device__ __forceinline__ void cr_forward_block(const CrLevel& L, int64_t j, const double* d, double* dn) {
+  cr_forward_block_range<M>(L, j, d, dn, 0, L.n - 1);
 }
 
 // x of block row r (odd) given the coarser solution xn; rhs assembled in a small local array
@@ -588,6 +619,7 @@ struct CrTail {
 
 template <int M>
 __global__ __launch_bounds__(1024) void cr_tail_kernel(CrTail T, const double* __restrict__ d0,
+                                                       const double* __restrict__ d0b,
                                                        double* __restrict__ x0) {
   extern __shared__ double sh[];
   // d of every tail level stacked (level l at off[l]); x overwrites d in place on the way back
@@ -603,7 +635,7 @@ __global__ __launch_bounds__(1024) void cr_tail_kernel(CrTail T, const double* _
   }
   __syncthreads();
   const int n0 = (int)(T.nlev ? T.lv[0].n : 1) * M;
-  for (int t = tid; t < n0; t += blockDim.x) sh[t] = d0[t];
+  for (int t = tid; t < n0; t += blockDim.x) sh[t] = d0b ? d0[t] + d0b[t] : d0[t];
   __syncthreads();
   for (int l = 0; l < T.nlev; ++l) {
     const CrLevel L = T.lv[l];
@@ -637,6 +669,114 @@ __global__ __launch_bounds__(1024) void cr_tail_kernel(CrTail T, const double* _
     __syncthreads();
   }
   for (int t = tid; t < n0; t += blockDim.x) x0[t] = sh[t];
+}
+
+// Chunked levels: the first q levels of the reduction only couple blocks less than 2^q apart, so a
+// workgroup can run them for the 2^q + 1 blocks [c 2^q, (c+1) 2^q] of its chunk entirely in LDS.
+// Chunk-boundary blocks stay even on all q levels; each of the two chunks sharing one adds its own
+// side's terms (partR: the right-hand chunk incl. d itself, partL: the left-hand chunk), the tail
+// kernel sums the two.  The back substitution recomputes the chunk's forward pass (interior values
+// do not depend on the boundary blocks) instead of storing q levels of vectors.
+constexpr int kCrMaxChunkLevels = 12;
+struct CrChunk {
+  CrLevel lv[kCrMaxChunkLevels];
+  int q;
+  int64_t nq;  // blocks left after the q chunk levels
+};
+
+template <int M>
+__device__ __forceinline__ void cr_chunk_forward(const CrChunk& C, int64_t c, const double* __restrict__ d0,
+                                                 double* sh, const int* off, int64_t* lo, int64_t* hi) {
+  const int tid = threadIdx.x;
+  const int q = C.q;
+  for (int l = 0; l <= q; ++l) {
+    const int64_t nl = l < q ? C.lv[l].n : C.nq;
+    lo[l] = c << (q - l);
+    const int64_t h = (c + 1) << (q - l);
+    hi[l] = h < nl - 1 ? h : nl - 1;
+  }
+  const bool shared_right = ((c + 1) << q) <= C.lv[0].n - 1;
+  const int cnt0 = (int)(hi[0] - lo[0] + 1) * M;
+  for (int t = tid; t < cnt0; t += blockDim.x) {
+    const bool rb = shared_right && t >= cnt0 - M;  // the right boundary's own d belongs to the next chunk
+    sh[off[0] + t] = rb ? 0.0 : d0[lo[0] * M + t];
+  }
+  __syncthreads();
+  for (int l = 0; l < q; ++l) {
+    const double* d = sh + off[l] - lo[l] * M;
+    double* dn = sh + off[l + 1] - lo[l + 1] * M;
+    for (int64_t j = lo[l + 1] + tid; j <= hi[l + 1]; j += blockDim.x)
+      cr_forward_block_range<M>(C.lv[l], j, d, dn, lo[l], hi[l]);
+    __syncthreads();
+  }
+}
+
+template <int M>
+__global__ __launch_bounds__(kThreads) void cr_chunk_forward_kernel(CrChunk C, const double* __restrict__ d0,
+                                                                    double* __restrict__ partR,
+                                                                    double* __restrict__ partL) {
+  extern __shared__ double sh[];
+  __shared__ int off[kCrMaxChunkLevels + 2];
+  int64_t lo[kCrMaxChunkLevels + 1], hi[kCrMaxChunkLevels + 1];
+  if (threadIdx.x == 0) {
+    int o = 0;
+    for (int l = 0; l <= C.q; ++l) {
+      off[l] = o;
+      o += ((1 << (C.q - l)) + 1) * M;
+    }
+  }
+  __syncthreads();
+  const int64_t c = blockIdx.x;
+  cr_chunk_forward<M>(C, c, d0, sh, off, lo, hi);
+  const int q = C.q;
+  if (threadIdx.x < M) {
+    partR[c * M + threadIdx.x] = sh[off[q] + threadIdx.x];  // left boundary of this chunk (block c of level q)
+    if (hi[q] > lo[q]) partL[(c + 1) * M + threadIdx.x] = sh[off[q] + M + threadIdx.x];
+  }
+}
+
+template <int M>
+__global__ __launch_bounds__(kThreads) void cr_chunk_backward_kernel(CrChunk C, const double* __restrict__ d0,
+                                                                     const double* __restrict__ xq,
+                                                                     double* __restrict__ x0) {
+  extern __shared__ double sh[];
+  __shared__ int off[kCrMaxChunkLevels + 2];
+  int64_t lo[kCrMaxChunkLevels + 1], hi[kCrMaxChunkLevels + 1];
+  const int tid = threadIdx.x;
+  if (tid == 0) {
+    int o = 0;
+    for (int l = 0; l <= C.q; ++l) {
+      off[l] = o;
+      o += ((1 << (C.q - l)) + 1) * M;
+    }
+  }
+  __syncthreads();
+  const int64_t c = blockIdx.x;
+  cr_chunk_forward<M>(C, c, d0, sh, off, lo, hi);
+  const int q = C.q;
+  const int cntq = (int)(hi[q] - lo[q] + 1) * M;
+  for (int t = tid; t < cntq; t += blockDim.x) sh[off[q] + t] = xq[lo[q] * M + t];
+  __syncthreads();
+  for (int l = q - 1; l >= 0; --l) {
+    const CrLevel& L = C.lv[l];
+    double* d = sh + off[l] - lo[l] * M;  // becomes x of this level
+    const double* xn = sh + off[l + 1] - lo[l + 1] * M;
+    for (int64_t r = lo[l] + tid; r <= hi[l]; r += blockDim.x) {
+      double xv[M];
+      if (r & 1) {
+        cr_backward_block<M>(L, r, d, xn, xv);
+      } else {
+#pragma unroll
+        for (int i = 0; i < M; ++i) xv[i] = xn[(r >> 1) * M + i];
+      }
+#pragma unroll
+      for (int i = 0; i < M; ++i) d[r * M + i] = xv[i];
+    }
+    __syncthreads();
+  }
+  const bool shared_right = ((c + 1) << q) <= C.lv[0].n - 1;
+  const int cnt0 = (int)(hi[0] - lo[0] + 1 - (shared_right ? 1 : 0)) * M;
+  for (int t = tid; t < cnt0; t += blockDim.x) x0[lo[0] * M + t] = sh[off[0] + t];
 }
 
 }  // namespace aggmg

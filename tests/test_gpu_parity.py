@@ -269,8 +269,8 @@ def test_coarse_solver_modes(oracle, mg):
         assert rel(x, xr) < 1e-9
         xs[mode] = x
     assert rel(xs[_lib.COARSE_DEVICE_CR], xs[_lib.COARSE_HOST_BANDED]) < 1e-9
-    # odd block counts / tail-only / scalar tridiagonal coarsest operators
-    for n, nAgg in ((48, 2), (16, 1), (6000, 1)):
+    # odd block counts / tail-only / scalar tridiagonal / chunked (coarsest > 2048 rows) operators
+    for n, nAgg in ((48, 2), (16, 1), (6000, 1), (10000, 1), (16386, 1)):
         Ho, b = o.build_dg_agg_hierarchy(n, p=2, pAgg=0, nAgg=nAgg, first=2)
         H = mg.MeshHierarchy.from_reference(Ho, coarse_mode=_lib.COARSE_DEVICE_CR)
         x = mg.multigrid_v_cycle(H, np.zeros(len(b)), b)
