@@ -16,9 +16,9 @@ ERR_ARGUMENT, ERR_DIMENSION, ERR_SINGULAR, ERR_HIP, ERR_UNSUPPORTED = -1, -2, -3
 OP_STIFFNESS, OP_TRANSFER = 0, 1
 PROFILE_NTAGS = 256
 KIND_FUSED_DOWN, KIND_FUSED_UP, KIND_SMOOTH, KIND_RESIDUAL, KIND_RESTRICT, KIND_PROLONG, \
-    KIND_JACOBI, KIND_BLOCK_APPLY, KIND_COARSE = range(9)
+    KIND_JACOBI, KIND_BLOCK_APPLY, KIND_COARSE, KIND_FUSED_MID = range(10)
 KIND_NAMES = ["fused_down", "fused_up", "smooth", "residual", "restrict", "prolong", "jacobi",
-              "block_apply", "coarse"]
+              "block_apply", "coarse", "fused_mid"]
 COARSE_HOST_BANDED, COARSE_DEVICE_CR, COARSE_AUTO, COARSE_EXTERNAL = 0, 1, 2, 3
 
 
@@ -93,6 +93,7 @@ SYMBOLS = {
     "aggmg_hier_free": (c_int, [_P, _P]),
     "aggmg_vcycle": (c_int, [_P, _P, _PD, _PD, c_int, c_int, c_double, _PD]),
     "aggmg_vcycle_dev": (c_int, [_P, _P, _P, _P, c_int, c_int, c_double, _P]),
+    "aggmg_vcycles_dev": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_double, _P]),
     "aggmg_vcycle_down_dev": (c_int, [_P, _P, _P, _P, c_int, c_double]),
     "aggmg_vcycle_up_dev": (c_int, [_P, _P, _P, c_int, c_double, _P]),
     "aggmg_hier_coarse_buffers": (c_int, [_P, _P, POINTER(_P), POINTER(_P), POINTER(c_int64)]),

@@ -423,6 +423,14 @@ class MeshHierarchy:
         c.check(c.lib.aggmg_vcycle_dev(c.handle, self.handle, _ptr(x0), _ptr(b), int(nPre), int(nPost),
                                        float(alpha), _ptr(x_out)))
 
+    def vcycles_dev(self, x0, b, x_out, ncycles, nPre=3, nPost=3, alpha=2.0 / 3.0):
+        """ncycles device-resident V-cycles back to back (x <- V(x, b)), the loop body of
+        multigrid (src/solvers.jl:124-126); between cycles the fine level's post- and pre-smoothing
+        share one fused launch."""
+        c = self.ctx
+        c.check(c.lib.aggmg_vcycles_dev(c.handle, self.handle, _ptr(x0), _ptr(b), int(ncycles), int(nPre),
+                                        int(nPost), float(alpha), _ptr(x_out)))
+
     def vcycle_down_dev(self, x0, b, nPre=3, alpha=2.0 / 3.0):
         """Descending half (src/solvers.jl:28-37); leaves the coarsest rhs in coarse_buffers()."""
         c = self.ctx
@@ -504,26 +512,43 @@ def _device_residual_norm(H_or_op, x, b):
     return np.linalg.norm(r, 2)
 
 
-def multigrid(H, x0, b, maxiter, tol, exact=True):
+def multigrid(H, x0, b, maxiter, tol, exact=True, check_every=1):
     """multigrid(H, x0, b, maxiter, tol) -> (x, iter, res, err)  (src/solvers.jl:116-139).
     The reference solves the fine system directly for the error history (:120); pass
     exact=False to skip that at sizes where a fine-level direct solve is not wanted (err is
-    then empty)."""
+    then empty).  check_every = c > 1 runs c cycles per residual check in one device-resident
+    call (fused across cycles); res / err then have one entry per check and `iter` counts cycles."""
     x0 = _f64(x0)
     b = _f64(b)
     x = np.zeros(len(x0))
     u_exact = spla.spsolve(sp.csc_matrix(H.mStiffness[0]), b) if exact else None
     err, res = [], []
     nb = np.linalg.norm(b, 2)
-    for i in range(int(maxiter)):
-        x = multigrid_v_cycle(H, x0, b)
-        x0 = x
+    if check_every <= 1:
+        for i in range(int(maxiter)):
+            x = multigrid_v_cycle(H, x0, b)
+            x0 = x
+            if exact:
+                err.append(np.linalg.norm(x - u_exact, 2))
+            res.append(_device_residual_norm(H._ops[0], x, b))
+            if res[i] < tol * nb:
+                break
+        return x, len(res), res, err
+    c = H.ctx
+    db, dx, dy = c.to_device(b), c.to_device(x0), c.alloc(len(b))
+    done = 0
+    while done < int(maxiter):
+        k = min(int(check_every), int(maxiter) - done)
+        H.vcycles_dev(dx, db, dy, k)
+        dx, dy = dy, dx
+        done += k
+        x = dx.download()
         if exact:
             err.append(np.linalg.norm(x - u_exact, 2))
         res.append(_device_residual_norm(H._ops[0], x, b))
-        if res[i] < tol * nb:
+        if res[-1] < tol * nb:
             break
-    return x, len(res), res, err
+    return x, done, res, err
 
 
 def iterative_smoother_solve(A, smoother, x0, b, maxiter=1000, tol=1e-6, alpha=1.0, exact=True):

@@ -141,6 +141,7 @@ struct aggmg_hier {
   int coarse_mode = 0;
   BandedLU coarse;
   CrDev cr;
+  double* cyc[2] = {nullptr, nullptr};  // iterate ping-pong for multi-cycle calls (lazy)
   std::vector<double> h_coarse;
   double last_coarse_ms = 0.0;
 };
@@ -1608,6 +1609,8 @@ extern "C" int aggmg_hier_free(aggmg_ctx* ctx, aggmg_hier* h) {
     if (l.tb && l.tb->ld) (void)hipFree(l.tb->ld);
   }
   free_cr(&h->cr);
+  for (double* p : h->cyc)
+    if (p) (void)hipFree(p);
   delete h;
   return AGGMG_OK;
 }
@@ -1691,9 +1694,10 @@ static int coarse_solve(aggmg_ctx* ctx, aggmg_hier* h, const double* rhs_dev, do
 }
 
 // ---- descend (src/solvers.jl:28-37): leaves u[k] in lv[k].u[0] and rhs[n] in lv[n-1].rhs ----------
-static int vcycle_down(aggmg_ctx* ctx, aggmg_hier* h, const double* x0, const double* b, int nPre, double alpha) {
+static int vcycle_down(aggmg_ctx* ctx, aggmg_hier* h, const double* x0, const double* b, int nPre, double alpha,
+                       int k_first = 0) {
   const int n = (int)h->lv.size();
-  for (int k = 0; k < n - 1; ++k) {
+  for (int k = k_first; k < n - 1; ++k) {
     Level& l = h->lv[k];
     Level& c = h->lv[k + 1];
     const double* rhs = k == 0 ? b : l.rhs;
@@ -1755,9 +1759,10 @@ static int vcycle_down(aggmg_ctx* ctx, aggmg_hier* h, const double* x0, const do
 }
 
 // ---- ascend (src/solvers.jl:41-47): expects the coarsest solution in lv[n-1].u[0] ---------------
-static int vcycle_up(aggmg_ctx* ctx, aggmg_hier* h, const double* b, int nPost, double alpha, double* x_out) {
+static int vcycle_up(aggmg_ctx* ctx, aggmg_hier* h, const double* b, int nPost, double alpha, double* x_out,
+                     int k_last = 0) {
   const int n = (int)h->lv.size();
-  for (int k = n - 2; k >= 0; --k) {
+  for (int k = n - 2; k >= k_last; --k) {
     Level& l = h->lv[k];
     Level& c = h->lv[k + 1];
     const double* rhs = k == 0 ? b : l.rhs;
@@ -1830,6 +1835,95 @@ extern "C" int aggmg_vcycle_dev(aggmg_ctx* ctx, aggmg_hier* h, const double* x0,
     CHECK(coarse_solve(ctx, h, rhs, dst));
   }
   return vcycle_up(ctx, h, b, nPost, alpha, x_out);
+}
+
+// ncycles V-cycles back to back, x <- V(x, b): the hot loop of multigrid() (src/solvers.jl:124-126).
+// Between two cycles the fine level runs post-smoothing of cycle i and pre-smoothing of cycle i+1
+// on the same iterate with the same right-hand side, so both go into ONE fused launch
+// (prolongation-add -> nPost + nPre sweeps -> restriction): the fine operator is read once per
+// cycle instead of twice and the intermediate iterates never travel to HBM.  The arithmetic is
+// that of ncycles separate aggmg_vcycle_dev calls.
+extern "C" int aggmg_vcycles_dev(aggmg_ctx* ctx, aggmg_hier* h, const double* x0, const double* b, int ncycles,
+                                 int nPre, int nPost, double alpha, double* x_out) {
+  CHECK(vcycle_args(ctx, h, x0, b, nPre, nPost));
+  if (!x_out || ncycles < 1) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_vcycles: bad argument");
+  if (x_out == x0 || x_out == b) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_vcycles: x_out must not alias x0 or b");
+  if (h->coarse_mode == AGGMG_COARSE_EXTERNAL)
+    return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_vcycles: hierarchy was created with AGGMG_COARSE_EXTERNAL");
+  const int n = (int)h->lv.size();
+  Level& l0 = h->lv[0];
+  const bool fusable = n >= 2 && l0.S && l0.S->btd && l0.S->A == l0.A && l0.tb && l0.tb->ld &&
+                       nPre + nPost + 1 <= btd_max_sweeps(*l0.S->btd, 0);
+  if (!fusable || ncycles == 1) {
+    // plain sequence; intermediate iterates ping-pong between two vectors owned by the hierarchy
+    if (ncycles > 1)
+      for (double*& p : h->cyc)
+        if (!p) HIPCHK(hipMalloc((void**)&p, (size_t)std::max<int64_t>(l0.N, 1) * sizeof(double)));
+    const double* src = x0;
+    for (int c = 0; c < ncycles; ++c) {
+      double* dst = (c == ncycles - 1) ? x_out : h->cyc[c & 1];
+      CHECK(aggmg_vcycle_dev(ctx, h, src, b, nPre, nPost, alpha, dst));
+      src = dst;
+    }
+    return AGGMG_OK;
+  }
+  h->last_coarse_ms = 0.0;
+  Level& c1 = h->lv[1];
+  auto coarse_part = [&]() -> int {  // levels 1.. of one cycle: rhs_1 is in c1.rhs, result u_1
+    CHECK(vcycle_down(ctx, h, nullptr, b, nPre, alpha, 1));
+    Level& c = h->lv[n - 1];
+    CHECK(coarse_solve(ctx, h, c.rhs, c.u[0]));
+    if (n > 2) CHECK(vcycle_up(ctx, h, b, nPost, alpha, nullptr, 1));
+    return AGGMG_OK;
+  };
+  const double* uc = (1 == n - 1) ? c1.u[0] : c1.u[1];
+  CHECK(vcycle_down(ctx, h, x0, b, nPre, alpha, 0));  // cycle 1, level 0 .. then levels >= 1 below
+  // (vcycle_down with k_first = 0 already descended all levels)
+  {
+    Level& c = h->lv[n - 1];
+    CHECK(coarse_solve(ctx, h, c.rhs, c.u[0]));
+    if (n > 2) CHECK(vcycle_up(ctx, h, b, nPost, alpha, nullptr, 1));
+  }
+  double* cur = l0.u[0];  // pre-smoothed fine iterate of the current cycle
+  double* alt = l0.u[1];
+  for (int cyc = 1; cyc < ncycles; ++cyc) {
+    FusedArgs a = btd_args(*l0.S->btd);
+    a.u_in = cur;
+    a.b = b;
+    a.u_out = alt;
+    a.alpha = alpha;
+    a.nsweeps = nPost + nPre;
+    a.lf_in = l0.tb->lf;
+    a.uc = uc;
+    a.mc_in = l0.tb->mc;
+    a.rho_in = l0.tb->rho;
+    a.do_residual = 1;
+    a.ld_out = l0.tb->ld;
+    a.rc_out = c1.rhs;
+    a.mc_out = l0.tb->mc;
+    a.rho_out = l0.tb->rho;
+    {
+      ProfScope ps(ctx, AGGMG_KIND_FUSED_MID, 0);
+      CHECK(launch_btd(ctx, *l0.S->btd, a, nPost + nPre + 1));
+    }
+    std::swap(cur, alt);
+    CHECK(coarse_part());
+  }
+  {  // last ascent on the fine level
+    FusedArgs a = btd_args(*l0.S->btd);
+    a.u_in = cur;
+    a.b = b;
+    a.u_out = x_out;
+    a.alpha = alpha;
+    a.nsweeps = nPost;
+    a.lf_in = l0.tb->lf;
+    a.uc = uc;
+    a.mc_in = l0.tb->mc;
+    a.rho_in = l0.tb->rho;
+    ProfScope ps(ctx, AGGMG_KIND_FUSED_UP, 0);
+    CHECK(launch_btd(ctx, *l0.S->btd, a, nPost));
+  }
+  return AGGMG_OK;
 }
 
 extern "C" int aggmg_vcycle_down_dev(aggmg_ctx* ctx, aggmg_hier* h, const double* x0, const double* b, int nPre,

@@ -138,6 +138,12 @@ int aggmg_vcycle(aggmg_ctx* ctx, aggmg_hier* h, const double* x0, const double* 
                  int nPost, double alpha, double* x_out);
 int aggmg_vcycle_dev(aggmg_ctx* ctx, aggmg_hier* h, const double* x0, const double* b, int nPre,
                      int nPost, double alpha, double* x_out);
+/* ncycles V-cycles back to back, x <- multigrid_v_cycle(H, x, b): the hot loop of multigrid()
+ * (src/solvers.jl:124-126), same arithmetic as ncycles aggmg_vcycle_dev calls.  On block-
+ * tridiagonal fine levels the post-smoothing of one cycle and the pre-smoothing of the next run in
+ * one fused launch, so the fine operator is read once per cycle instead of twice. */
+int aggmg_vcycles_dev(aggmg_ctx* ctx, aggmg_hier* h, const double* x0, const double* b, int ncycles,
+                      int nPre, int nPost, double alpha, double* x_out);
 /* The two halves of the V-cycle around the coarsest solve (src/solvers.jl:28-37 and :41-47), for
  * callers that solve the coarsest system themselves (element-partitioned multi-GPU runs gather it
  * across ranks).  After _down the coarsest right-hand side is in the buffer reported by
@@ -171,6 +177,7 @@ int aggmg_hier_last_coarse_ms(aggmg_ctx* ctx, const aggmg_hier* h, double* ms);
 #define AGGMG_KIND_JACOBI 6      /* generic CSR fused point-Jacobi sweep */
 #define AGGMG_KIND_BLOCK_APPLY 7 /* generic gather block apply */
 #define AGGMG_KIND_COARSE 8      /* device coarsest solve (all its launches) */
+#define AGGMG_KIND_FUSED_MID 9   /* prolong-add -> nPost + nPre sweeps -> restriction (between cycles) */
 int aggmg_profile_enable(aggmg_ctx* ctx, int on);
 int aggmg_profile_collect(aggmg_ctx* ctx, double* total_ms, int64_t* counts);
 

@@ -349,6 +349,53 @@ def test_multigrid_and_ldiv(oracle, mg):
     assert np.linalg.norm(Ho.mStiffness[0] @ (y - yo)) <= TOL * np.linalg.norm(b)
 
 
+def test_vcycles_fused_across_cycles(oracle, mg):
+    """aggmg_vcycles_dev: K cycles back to back with the fine level's post- and pre-smoothing in
+    one launch == K separate V-cycles (bitwise: same per-row arithmetic) == the oracle's K cycles."""
+    o = oracle
+    Ho, b = o.build_dg_agg_hierarchy(992, p=3, pAgg=1, nAgg=3, first=4)
+    H = mg.MeshHierarchy.from_reference(Ho)
+    ctx = H.ctx
+    x0 = rand_vec(o, len(b), 0)
+    db = ctx.to_device(b)
+    for K in (1, 2, 5):
+        dx, dy, dz = ctx.to_device(x0), ctx.alloc(len(b)), ctx.alloc(len(b))
+        H.vcycles_dev(dx, db, dz, K)
+        fused = dz.download()
+        for _ in range(K):
+            H.vcycle_dev(dx, db, dy)
+            dx, dy = dy, dx
+        sep = dx.download()
+        assert np.array_equal(fused, sep), K
+        xr = x0
+        for _ in range(K):
+            xr = o.multigrid_v_cycle(Ho, xr, b)
+        A = Ho.mStiffness[0]
+        assert np.linalg.norm(A @ (fused - xr)) <= TOL * np.linalg.norm(b - A @ x0)
+    # other sweep counts, incl. one too deep to fuse (falls back to separate launches)
+    for nPre, nPost in ((1, 2), (4, 4)):
+        dx, dz = ctx.to_device(x0), ctx.alloc(len(b))
+        H.vcycles_dev(dx, db, dz, 3, nPre=nPre, nPost=nPost)
+        xr = x0
+        for _ in range(3):
+            xr = o.multigrid_v_cycle(Ho, xr, b, nPre=nPre, nPost=nPost)
+        assert np.linalg.norm(Ho.mStiffness[0] @ (dz.download() - xr)) <= TOL * np.linalg.norm(b - Ho.mStiffness[0] @ x0)
+    # generic (CG) hierarchy: plain sequence path
+    Hc, bc = o.build_cg_hierarchy(64, ps=(4, 2, 1), nDG=1, pDG=0)
+    Hg = mg.MeshHierarchy.from_reference(Hc)
+    dx, dz = ctx.to_device(np.zeros(len(bc))), ctx.alloc(len(bc))
+    Hg.vcycles_dev(dx, ctx.to_device(bc), dz, 3)
+    xr = np.zeros(len(bc))
+    for _ in range(3):
+        xr = o.multigrid_v_cycle(Hc, xr, bc)
+    assert np.linalg.norm(Hc.mStiffness[0] @ (dz.download() - xr)) <= TOL * np.linalg.norm(bc)
+    # multigrid with a residual check every 3 cycles: same iterate after the same number of cycles
+    xo, ito, reso, erro = o.multigrid(Ho, np.zeros(len(b)), b, 200, 1e-10)
+    xg, itg, resg, errg = mg.multigrid(H, np.zeros(len(b)), b, 200, 1e-10, check_every=3)
+    assert ito <= itg <= ito + 2 and len(resg) == (itg + 2) // 3
+    assert resg[-1] < 1e-10 * np.linalg.norm(b)
+
+
 def test_error_behaviour(oracle, mg):
     o = oracle
     A = sp.csc_matrix(np.array([[0.0, 0.0, 0.0, 0.0], [0.0, 0.0, 0.0, 0.0], [0, 0, 1.0, 0], [0, 0, 0, 1.0]]))

@@ -48,4 +48,16 @@ out["vcycle_us"] = round(1e6 * (time.perf_counter() - t0) / 20, 1)
 ctx.profile_enable(False)
 for (k, l), (ms, c) in sorted(ctx.profile_collect().items()):
     out[f"{k}_L{l}_us"] = round(1e3 * ms / c, 1)
+for _ in range(2):
+    H.vcycles_dev(xa, b, xb, 20)
+ctx.synchronize()
+ctx.profile_enable(True)
+t0 = time.perf_counter()
+H.vcycles_dev(xa, b, xb, 20)
+ctx.synchronize()
+out["vcycles20_us_per_cycle"] = round(1e6 * (time.perf_counter() - t0) / 20, 1)
+ctx.profile_enable(False)
+for (k, l), (ms, c) in sorted(ctx.profile_collect().items()):
+    if k == "fused_mid":
+        out[f"{k}_L{l}_us"] = round(1e3 * ms / c, 1)
 print(json.dumps(out))
