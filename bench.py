@@ -65,7 +65,25 @@ def cpu_baseline(args, nPre, nPost, alpha):
         tot += dt
         coarse += cs
     N = len(b)
+    # same cycle, OpenMP row-gather variant on the cores this box gives one GPU job
+    import ctypes
+    nthreads = min(16, os.cpu_count() or 1)
+    try:
+        omp = ctypes.CDLL("libgomp.so.1")
+        omp.omp_set_num_threads(nthreads)
+        C.enable_omp([U.stiffness_csc(k) for k in range(U.nlevels)], [U.interpolation_csc(k) for k in range(U.nlevels - 1)])
+        xo = np.zeros(N)
+        xo, _, _ = C.vcycle_omp(xo, b, nPre, nPost, alpha)
+        tomp = 0.0
+        for _ in range(args.cpu_cycles):
+            xo, dto, _ = C.vcycle_omp(xo, b, nPre, nPost, alpha)
+            tomp += dto
+        omp_line = {"value": N * (nPre + nPost) * args.cpu_cycles / tomp, "unit": "DoF-updates/s", "cores": nthreads,
+                    "kind": "port", "sample": "same sample, OpenMP row-gather variant of the C restatement"}
+    except Exception as exc:  # no libgomp: the serial line stands alone
+        omp_line = {"error": str(exc)}
     return {
+        "openmp": omp_line,
         "value": N * (nPre + nPost) * args.cpu_cycles / tot,
         "unit": "DoF-updates/s",
         "cores": 1,
@@ -174,6 +192,16 @@ def main():
     ctx.profile_enable(False)
     prof = ctx.profile_collect()
 
+    # the same K cycles through the multi-cycle entry point (the loop body of multigrid(),
+    # src/solvers.jl:124-126): consecutive cycles share one fused fine-level launch.  Reported
+    # beside `value`, which stays K independent multigrid_v_cycle calls.
+    H.vcycles_dev(src, b, dst, args.steps, nPre, nPost, alpha)
+    ctx.synchronize()
+    t1 = time.perf_counter()
+    H.vcycles_dev(src, b, dst, args.steps, nPre, nPost, alpha)
+    ctx.synchronize()
+    dt_loop = time.perf_counter() - t1
+
     ms_per_step = 1e3 * dt / args.steps
     value = N * (nPre + nPost) * args.steps / dt
     vcycle_bytes = sum(l['vcycle'] for l in bytes_model)
@@ -211,6 +239,11 @@ def main():
                    "fine_dofs": N, "level_dofs": level_sizes, "nPre": nPre, "nPost": nPost,
                    "parallelism": "single GPU"},
         "achieved_algorithmic_GBs_vcycle": vcycle_bytes * args.steps / dt / 1e9,
+        "vcycles_loop": {"value": N * (nPre + nPost) * args.steps / dt_loop, "unit": "DoF-updates/s",
+                         "ms_per_cycle": 1e3 * dt_loop / args.steps,
+                         "note": f"aggmg_vcycles_dev({args.steps} cycles): same arithmetic as {args.steps} separate "
+                                 "V-cycles (bitwise), post-smoothing of cycle i and pre-smoothing of cycle i+1 in one "
+                                 "fine-level launch"},
         "coarse_solve": H.coarse_info(),
         "coarse_solve_host_ms_per_step": coarse_ms / args.steps,
         "value_excl_coarse_solve": N * (nPre + nPost) / max(1e-3 * (ms_per_step - coarse_ms / args.steps), 1e-12),

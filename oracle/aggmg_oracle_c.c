@@ -257,3 +257,91 @@ int oc_vcycle(int nlevels, const csc_t* A, const smoother_t* S, const csc_t* L, 
   memcpy(x_out, u[0], sizeof(double) * (size_t)N0);
   return 0;
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * OpenMP variant of the same cycle ("best CPU" line of BASELINE.md section 5): row-parallel CSR
+ * gathers instead of the serial CSC scatter (the per-row sums run over ascending columns, i.e.
+ * the same order as the scatter accumulates them), blocks / columns / vector entries in
+ * parallel.  Build with -fopenmp; without it the pragmas are ignored and this is a second serial
+ * implementation.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+  int64_t n_rows;
+  const int64_t* rowptr;
+  const int64_t* colind;
+  const double* val;
+} csr_t;
+
+static void csr_residual(const csr_t* A, const double* u, const double* rhs, double* r) {
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < A->n_rows; ++i) {
+    double t = 0.0;
+    for (int64_t p = A->rowptr[i]; p < A->rowptr[i + 1]; ++p) t += A->val[p] * u[A->colind[p]];
+    r[i] = rhs[i] - t;
+  }
+}
+
+static void smoother_update_omp(const smoother_t* S, const double* r, double alpha, double* u, int64_t N) {
+  if (S->kind == 0) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < N; ++i) u[i] = u[i] + alpha * (r[i] / S->diag[i]);
+    return;
+  }
+  const int m = (int)S->m;
+#pragma omp parallel for schedule(static)
+  for (int64_t k = 0; k < S->nb; ++k) {
+    double tmp[64];
+    for (int i = 0; i < m; ++i) tmp[i] = r[k * m + i];
+    block_lu_solve(m, S->lu + k * m * m, S->piv + k * m, tmp);
+    for (int i = 0; i < m; ++i) u[k * m + i] = u[k * m + i] + alpha * tmp[i];
+  }
+}
+
+int oc_vcycle_omp(int nlevels, const csr_t* A, const smoother_t* S, const csc_t* L, const csr_t* Lr,
+                  const banded_t* coarse, const double* x0, const double* b, int nPre, int nPost, double alpha,
+                  double* x_out, double* work, double* coarse_s) {
+  double* u[16]; double* rhs[16]; double* r[16];
+  if (nlevels < 1 || nlevels > 16) return 1;
+  double* w = work;
+  for (int k = 0; k < nlevels; ++k) {
+    const int64_t N = A[k].n_rows;
+    u[k] = w; rhs[k] = w + N; r[k] = w + 2 * N;
+    w += 5 * N;
+  }
+  const int64_t N0 = A[0].n_rows;
+  memcpy(u[0], x0, sizeof(double) * (size_t)N0);
+  memcpy(rhs[0], b, sizeof(double) * (size_t)N0);
+  for (int k = 0; k < nlevels - 1; ++k) {
+    const int64_t N = A[k].n_rows;
+    if (k > 0) memset(u[k], 0, sizeof(double) * (size_t)N);
+    for (int i = 0; i < nPre; ++i) { csr_residual(&A[k], u[k], rhs[k], r[k]); smoother_update_omp(&S[k], r[k], alpha, u[k], N); }
+    csr_residual(&A[k], u[k], rhs[k], r[k]);
+    const csc_t* Lk = &L[k];
+#pragma omp parallel for schedule(static)
+    for (int64_t j = 0; j < Lk->n_cols; ++j) {
+      double acc = 0.0;
+      for (int64_t p = Lk->colptr[j]; p < Lk->colptr[j + 1]; ++p) acc += Lk->nzval[p] * r[k][Lk->rowval[p]];
+      rhs[k + 1][j] = acc;
+    }
+  }
+  {
+    const int k = nlevels - 1;
+    const double t0 = now_s();
+    memcpy(u[k], rhs[k], sizeof(double) * (size_t)A[k].n_rows);
+    oc_banded_solve(coarse, u[k]);
+    if (coarse_s) *coarse_s = now_s() - t0;
+  }
+  for (int k = nlevels - 2; k >= 0; --k) {
+    const int64_t N = A[k].n_rows;
+    const csr_t* P = &Lr[k];
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < N; ++i) {
+      double t = 0.0;
+      for (int64_t p = P->rowptr[i]; p < P->rowptr[i + 1]; ++p) t += P->val[p] * u[k + 1][P->colind[p]];
+      u[k][i] = u[k][i] + t;
+    }
+    for (int i = 0; i < nPost; ++i) { csr_residual(&A[k], u[k], rhs[k], r[k]); smoother_update_omp(&S[k], r[k], alpha, u[k], N); }
+  }
+  memcpy(x_out, u[0], sizeof(double) * (size_t)N0);
+  return 0;
+}

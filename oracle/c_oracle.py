@@ -21,6 +21,10 @@ class smoother_t(Structure):
                 ("piv", c_void_p)]
 
 
+class csr_t(Structure):
+    _fields_ = [("n_rows", c_int64), ("rowptr", c_void_p), ("colind", c_void_p), ("val", c_void_p)]
+
+
 class banded_t(Structure):
     _fields_ = [("n", c_int64), ("kl", c_int), ("ku", c_int), ("ldab", c_int), ("ab", c_void_p),
                 ("ipiv", c_void_p)]
@@ -105,6 +109,41 @@ class COracleHierarchy:
                              x0.ctypes.data_as(c_void_p), b.ctypes.data_as(c_void_p), c_int(nPre), c_int(nPost),
                              c_double(alpha), out.ctypes.data_as(c_void_p), self.work.ctypes.data_as(c_void_p),
                              ctypes.byref(cs))
+        dt = time.perf_counter() - t0
+        assert st == 0
+        return out, dt, cs.value
+
+    def _csr(self, M):
+        M = sp.csr_matrix(M)
+        M.sort_indices()
+        rp = np.ascontiguousarray(M.indptr, dtype=np.int64)
+        ci = np.ascontiguousarray(M.indices, dtype=np.int64)
+        v = np.ascontiguousarray(M.data, dtype=np.float64)
+        self._keep += [rp, ci, v]
+        c = csr_t()
+        c.n_rows = M.shape[0]
+        c.rowptr, c.colind, c.val = rp.ctypes.data, ci.ctypes.data, v.ctypes.data
+        return c
+
+    def enable_omp(self, stiffness, interpolation):
+        """row-gather (CSR) copies for the OpenMP variant"""
+        self.Ar = (csr_t * self.n)()
+        self.Lr = (csr_t * max(self.n - 1, 1))()
+        for k, M in enumerate(stiffness):
+            self.Ar[k] = self._csr(M)
+        for k, M in enumerate(interpolation):
+            self.Lr[k] = self._csr(M)
+
+    def vcycle_omp(self, x0, b, nPre=3, nPost=3, alpha=2.0 / 3.0):
+        x0 = np.ascontiguousarray(x0, dtype=np.float64)
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        out = np.empty(self.N[0])
+        cs = c_double(0.0)
+        t0 = time.perf_counter()
+        st = lib().oc_vcycle_omp(c_int(self.n), self.Ar, self.S, self.Lm, self.Lr, ctypes.byref(self.coarse),
+                                 x0.ctypes.data_as(c_void_p), b.ctypes.data_as(c_void_p), c_int(nPre), c_int(nPost),
+                                 c_double(alpha), out.ctypes.data_as(c_void_p), self.work.ctypes.data_as(c_void_p),
+                                 ctypes.byref(cs))
         dt = time.perf_counter() - t0
         assert st == 0
         return out, dt, cs.value

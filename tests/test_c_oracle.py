@@ -22,3 +22,6 @@ def test_c_oracle_matches_python_oracle(oracle):
         assert np.linalg.norm(A @ (x - xr)) <= 1e-12 * np.linalg.norm(b)
         assert np.linalg.norm(x - xr) <= 1e-9 * np.linalg.norm(xr)
         assert 0.0 <= cs <= dt
+        C.enable_omp(Ho.mStiffness, Ho.mInterpolation)      # OpenMP row-gather variant, same cycle
+        xo, _, _ = C.vcycle_omp(np.zeros(len(b)), b)
+        assert np.linalg.norm(A @ (xo - x)) <= 1e-12 * np.linalg.norm(b)
