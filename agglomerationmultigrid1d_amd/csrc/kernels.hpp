@@ -206,6 +206,11 @@ __global__ __launch_bounds__(kThreads) void btd_fused_kernel(FusedArgs a) {
 
   // the stencil form (B^{-1} rows, P, Q) is only needed when something is swept or restricted
   const bool need_g = a.nsweeps > 0 || a.ld_out != nullptr;
+  // rows of L' (or (L'D)') for the restriction, fetched with the tile's other streams when the
+  // coarse space has two modes per element (one 16-byte load per row)
+  const double* lfo_pre = a.ld_out ? a.ld_out : a.lf_out;
+  const bool pre2 = a.do_residual && lfo_pre && a.mc_out == 2;
+  double l2x[NS], l2y[NS];
   double g[NS], bb[NS], uu[NS];
   double bi[NS][M];                              // B^{-1} rows, dead after g is formed
   double binv_r[NS], pc[NS], qv[NS][GRP ? 1 : M];  // CMP (GRP: own entry of the q row only)
@@ -230,6 +235,11 @@ __global__ __launch_bounds__(kThreads) void btd_fused_kernel(FusedArgs a) {
       }
       bb[s] = a.b[row];
       if (a.u_in) uu[s] = a.u_in[row];
+      if (pre2) {
+        const double2 t2 = *reinterpret_cast<const double2*>(lfo_pre + row * 2);
+        l2x[s] = t2.x;
+        l2y[s] = t2.y;
+      }
       if (CMP) {
         pc[s] = need_g ? AGGMG_LD(a.lv.pcol[row]) : 0.0;
         if (GRP) {
@@ -435,17 +445,42 @@ __global__ __launch_bounds__(kThreads) void btd_fused_kernel(FusedArgs a) {
   }
   if (!lfo) return;
 
-  // ---- restriction rc = L' r: r through LDS (the idle buffer), one thread per (J, mode) -----
+  const int rho = a.rho_out, mc = a.mc_out;
+  const int ncoarse = a.owned / rho;  // owned coarse elements of this tile
+  const int64_t J0 = ((int64_t)blockIdx.x * a.owned) / rho;
+  const int64_t nec = ne / rho;
+  if (pre2) {
+    // ---- restriction, two coarse modes: every row thread forms its two products with the
+    // preloaded L' entries; both iterate buffers are free once all threads are past the residual
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const int x = s * EPS + le;
+      const bool own = valid[s] && x >= xo0 && x < xo1;
+      if (active) {
+        nxt[x * M + i] = own ? l2x[s] * rr[s] : 0.0;
+        cur[x * M + i] = own ? l2y[s] * rr[s] : 0.0;
+      }
+    }
+    __syncthreads();
+    for (int t = tid; t < ncoarse * 2; t += kThreads) {
+      const int Jl = t >> 1, c = t & 1;
+      const int64_t J = J0 + Jl;
+      if (J >= nec) continue;
+      const double* pr = (c ? cur : nxt) + (a.halo_left + Jl * rho) * M;
+      double acc = 0.0;
+      for (int k = 0; k < rho * M; ++k) acc += pr[k];  // ascending fine row, as the column dot of L'
+      a.rc_out[J * 2 + c] = acc;
+    }
+    return;
+  }
+  // ---- restriction rc = L' r, general mode count: r through LDS, one thread per (J, mode) ----
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
     const int x = s * EPS + le;
     if (active) nxt[x * M + i] = rr[s];
   }
   __syncthreads();
-  const int rho = a.rho_out, mc = a.mc_out;
-  const int ncoarse = a.owned / rho;  // owned coarse elements of this tile
-  const int64_t J0 = ((int64_t)blockIdx.x * a.owned) / rho;
-  const int64_t nec = ne / rho;
   for (int t = tid; t < ncoarse * mc; t += kThreads) {
     const int Jl = t / mc, c = t - Jl * mc;
     const int64_t J = J0 + Jl;
