@@ -97,6 +97,10 @@ SYMBOLS = {
     "aggmg_vcycle_down_dev": (c_int, [_P, _P, _P, _P, c_int, c_double]),
     "aggmg_vcycle_up_dev": (c_int, [_P, _P, _P, c_int, c_double, _P]),
     "aggmg_hier_coarse_buffers": (c_int, [_P, _P, POINTER(_P), POINTER(_P), POINTER(c_int64)]),
+    "aggmg_coarse_plan": (c_int, [_P, _P, POINTER(c_int), POINTER(c_int64), POINTER(c_int), POINTER(c_int64)]),
+    "aggmg_coarse_chunk_forward_dev": (c_int, [_P, _P, _P, c_int64, c_int64, _P, _P]),
+    "aggmg_coarse_boundary_solve_dev": (c_int, [_P, _P, _P, _P, _P]),
+    "aggmg_coarse_chunk_backward_dev": (c_int, [_P, _P, _P, c_int64, c_int64, _P, _P]),
     "aggmg_hier_coarse_info": (c_int, [_P, _P, POINTER(c_int), POINTER(c_int), POINTER(c_double)]),
     "aggmg_hier_last_coarse_ms": (c_int, [_P, _P, POINTER(c_double)]),
     "aggmg_profile_enable": (c_int, [_P, c_int]),

@@ -1525,6 +1525,59 @@ static int cr_solve_t(aggmg_ctx* ctx, CrDev& cr, const double* rhs, double* out)
   return AGGMG_OK;
 }
 
+// ---- the three phases of the chunked solve, separately (element-partitioned runs: every rank
+// eliminates / back-substitutes only the chunks of its own block range, the boundary system is
+// gathered and solved redundantly) ------------------------------------------------------------
+template <int M>
+static int cr_phase_t(aggmg_ctx* ctx, CrDev& cr, int phase, const double* d_owned, int64_t blk_lo, int64_t blk_hi,
+                      double* partR, double* partL, const double* xq, double* x_owned) {
+  const int nl = (int)cr.lv.size();
+  const int q = cr.q;
+  CrTail T;
+  std::memset(&T, 0, sizeof(T));
+  T.nlev = nl - q;
+  for (int l = 0; l < T.nlev; ++l) T.lv[l] = cr.lv[q + l];
+  T.lu_last = cr.lu_last;
+  T.perm_last = cr.perm_last;
+  if (phase == 1) {  // boundary system
+    hipLaunchKernelGGL((cr_tail_kernel<M>), dim3(1), dim3(1024), cr.tail_lds, ctx->stream, T, (const double*)partR,
+                       (const double*)partL, const_cast<double*>(xq));
+    HIPCHK(hipGetLastError());
+    return AGGMG_OK;
+  }
+  CrChunk C;
+  std::memset(&C, 0, sizeof(C));
+  C.q = q;
+  for (int l = 0; l < q; ++l) C.lv[l] = cr.lv[l];
+  C.nq = q < nl ? cr.lv[q].n : 1;
+  C.c0 = blk_lo >> q;
+  const int64_t c1 = (blk_hi + ((int64_t)1 << q) - 1) >> q;
+  const unsigned grid = (unsigned)std::max<int64_t>(c1 - C.c0, 0);
+  if (!grid) return AGGMG_OK;
+  const double* d0 = d_owned - blk_lo * M;  // global block indexing; only owned blocks are touched
+  if (phase == 0)
+    hipLaunchKernelGGL((cr_chunk_forward_kernel<M>), dim3(grid), dim3(kThreads), cr.chunk_lds, ctx->stream, C, d0,
+                       partR, partL);
+  else
+    hipLaunchKernelGGL((cr_chunk_backward_kernel<M>), dim3(grid), dim3(kThreads), cr.chunk_lds, ctx->stream, C, d0,
+                       xq, x_owned - blk_lo * M);
+  HIPCHK(hipGetLastError());
+  return AGGMG_OK;
+}
+
+static int cr_phase(aggmg_ctx* ctx, CrDev& cr, int phase, const double* d_owned, int64_t blk_lo, int64_t blk_hi,
+                    double* partR, double* partL, const double* xq, double* x_owned) {
+  ProfScope ps(ctx, AGGMG_KIND_COARSE, 0);
+  switch (cr.m) {
+#define CASE(MM) \
+  case MM:       \
+    return cr_phase_t<MM>(ctx, cr, phase, d_owned, blk_lo, blk_hi, partR, partL, xq, x_owned);
+    CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
+#undef CASE
+  }
+  return fail(ctx, AGGMG_ERR_UNSUPPORTED, "cyclic reduction block size not instantiated");
+}
+
 static int cr_solve(aggmg_ctx* ctx, CrDev& cr, const double* rhs, double* out, int level) {
   ProfScope ps(ctx, AGGMG_KIND_COARSE, level);
   switch (cr.m) {
@@ -1972,6 +2025,52 @@ extern "C" int aggmg_hier_coarse_info(aggmg_ctx* ctx, const aggmg_hier* h, int* 
   if (block_size) *block_size = h->cr.valid ? h->cr.m : 0;
   if (cond_est) *cond_est = h->cr.valid ? h->cr.cond_est : 0.0;
   return AGGMG_OK;
+}
+
+// ---- chunked coarsest solve, phase by phase (multi-GPU driver) --------------------------------
+extern "C" int aggmg_coarse_plan(aggmg_ctx* ctx, const aggmg_hier* h, int* chunk_log2, int64_t* n_boundary,
+                                 int* block_size, int64_t* n_blocks) {
+  if (!ctx || !h) return AGGMG_ERR_ARGUMENT;
+  const CrDev& cr = h->cr;
+  const bool ok = cr.valid && cr.nglobal == 0 && cr.q > 0 && cr.n0 * cr.m == cr.N;
+  if (chunk_log2) *chunk_log2 = ok ? cr.q : -1;
+  if (n_boundary) *n_boundary = ok ? ((int)cr.lv.size() > cr.q ? cr.lv[cr.q].n : 1) : 0;
+  if (block_size) *block_size = cr.valid ? cr.m : 0;
+  if (n_blocks) *n_blocks = cr.valid ? cr.n0 : 0;
+  return AGGMG_OK;
+}
+
+static int coarse_phase_check(aggmg_ctx* ctx, aggmg_hier* h, int64_t blk_lo, int64_t blk_hi) {
+  if (!ctx) return AGGMG_ERR_ARGUMENT;
+  if (!h) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_coarse_*: NULL hierarchy");
+  const CrDev& cr = h->cr;
+  if (!(cr.valid && cr.nglobal == 0 && cr.q > 0 && cr.n0 * cr.m == cr.N))
+    return fail(ctx, AGGMG_ERR_UNSUPPORTED, "aggmg_coarse_*: this hierarchy has no chunked cyclic-reduction plan");
+  const int64_t mask = ((int64_t)1 << cr.q) - 1;
+  if (blk_lo < 0 || blk_hi > cr.n0 || blk_lo > blk_hi || (blk_lo & mask) || ((blk_hi & mask) && blk_hi != cr.n0))
+    return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_coarse_*: block range must be aligned to the chunk size");
+  return AGGMG_OK;
+}
+
+extern "C" int aggmg_coarse_chunk_forward_dev(aggmg_ctx* ctx, aggmg_hier* h, const double* rhs_owned,
+                                              int64_t blk_lo, int64_t blk_hi, double* partR, double* partL) {
+  CHECK(coarse_phase_check(ctx, h, blk_lo, blk_hi));
+  if (!rhs_owned || !partR || !partL) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_coarse_chunk_forward_dev: NULL");
+  return cr_phase(ctx, h->cr, 0, rhs_owned, blk_lo, blk_hi, partR, partL, nullptr, nullptr);
+}
+
+extern "C" int aggmg_coarse_boundary_solve_dev(aggmg_ctx* ctx, aggmg_hier* h, const double* partR,
+                                               const double* partL, double* xq) {
+  CHECK(coarse_phase_check(ctx, h, 0, 0));
+  if (!partR || !partL || !xq) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_coarse_boundary_solve_dev: NULL");
+  return cr_phase(ctx, h->cr, 1, nullptr, 0, 0, const_cast<double*>(partR), const_cast<double*>(partL), xq, nullptr);
+}
+
+extern "C" int aggmg_coarse_chunk_backward_dev(aggmg_ctx* ctx, aggmg_hier* h, const double* rhs_owned,
+                                               int64_t blk_lo, int64_t blk_hi, const double* xq, double* x_owned) {
+  CHECK(coarse_phase_check(ctx, h, blk_lo, blk_hi));
+  if (!rhs_owned || !xq || !x_owned) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_coarse_chunk_backward_dev: NULL");
+  return cr_phase(ctx, h->cr, 2, rhs_owned, blk_lo, blk_hi, nullptr, nullptr, xq, x_owned);
 }
 
 extern "C" int aggmg_hier_last_coarse_ms(aggmg_ctx* ctx, const aggmg_hier* h, double* ms) {

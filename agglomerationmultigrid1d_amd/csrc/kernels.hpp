@@ -717,6 +717,7 @@ struct CrChunk {
   CrLevel lv[kCrMaxChunkLevels];
   int q;
   int64_t nq;  // blocks left after the q chunk levels
+  int64_t c0;  // first chunk of this launch (element-partitioned runs launch a sub-range)
 };
 
 template <int M>
@@ -761,7 +762,7 @@ __global__ __launch_bounds__(kThreads) void cr_chunk_forward_kernel(CrChunk C, c
     }
   }
   __syncthreads();
-  const int64_t c = blockIdx.x;
+  const int64_t c = C.c0 + blockIdx.x;
   cr_chunk_forward<M>(C, c, d0, sh, off, lo, hi);
   const int q = C.q;
   if (threadIdx.x < M) {
@@ -786,7 +787,7 @@ __global__ __launch_bounds__(kThreads) void cr_chunk_backward_kernel(CrChunk C, 
     }
   }
   __syncthreads();
-  const int64_t c = blockIdx.x;
+  const int64_t c = C.c0 + blockIdx.x;
   cr_chunk_forward<M>(C, c, d0, sh, off, lo, hi);
   const int q = C.q;
   const int cntq = (int)(hi[q] - lo[q] + 1) * M;

@@ -165,35 +165,52 @@ class DistributedVCycle:
     def __init__(self, engine, layout, comm):
         self.e, self.L, self.c = engine, layout, comm
         L = layout
-        w0 = L.W[0] * L.m[0]
-        self._send = engine.new(2 * w0)
-        self._recv = engine.new(2 * w0 * L.world)
+        self._bufs = {}
         nc = len(L.m) - 1
         self._nc = nc
         self._own_c = (L.own[nc][1] - L.own[nc][0]) * L.m[nc]
         self._rhs_global = engine.new(L.ne[nc] * L.m[nc])
         self.exchanges = 0
+        # chunked coarsest solve: every rank reduces the chunks of its own block range, only the
+        # chunk-boundary system is gathered (falls back to gather + replicated solve otherwise)
+        self.chunked = False
+        if L.world > 1 and hasattr(engine, "coarse_plan") and os.environ.get("AGGMG_DIST_COARSE", "chunked") == "chunked":
+            q, nq, mblk, nblk = engine.coarse_plan()
+            own_blk = L.own[nc][1] - L.own[nc][0]
+            if q > 0 and mblk == L.m[nc] and nblk == L.ne[nc] and own_blk % (1 << q) == 0 and own_blk >= (1 << q):
+                self.chunked = True
+                self._q, self._nq = q, nq
+                self._cnt = (own_blk >> q) * mblk
+                self._send2 = engine.new(2 * self._cnt)
+                self._recv2 = engine.new(2 * self._cnt * L.world)
 
-    def exchange_ghosts(self, x):
-        """Fill the level-0 ghost entries of x from the neighbours' owned boundary elements:
-        all-gather of each rank's first and last W_0 owned elements (the interface DoFs)."""
+    def exchange_ghosts(self, x, level=0):
+        """Fill the ghost entries of a local level-`level` vector from the neighbours' owned
+        boundary elements: all-gather of each rank's first and last W owned elements (the
+        interface DoFs)."""
         L = self.L
-        if L.world == 1 or L.W[0] == 0:
+        if L.world == 1 or L.W[level] == 0:
             return
-        m, W = L.m[0], L.W[0]
-        gl, gr = L.ghosts(0)
+        m, W = L.m[level], L.W[level]
+        gl, gr = L.ghosts(level)
         wm = W * m
         o0 = gl * m
-        o1 = o0 + (L.own[0][1] - L.own[0][0]) * m
-        self._send[:wm].copy_(x[o0:o0 + wm])
-        self._send[wm:].copy_(x[o1 - wm:o1])
-        self.c.all_gather(self._recv, self._send)
+        o1 = o0 + (L.own[level][1] - L.own[level][0]) * m
+        send, recv = self._xbuf(level)
+        self.c.torch.cat((x[o0:o0 + wm], x[o1 - wm:o1]), out=send)
+        self.c.all_gather(recv, send)
         self.exchanges += 1
         r = L.rank
         if gl:   # left neighbour's last W elements
-            x[:o0].copy_(self._recv[(r - 1) * 2 * wm + wm:(r - 1) * 2 * wm + 2 * wm][wm - o0:])
+            x[:o0].copy_(recv[(r - 1) * 2 * wm + wm:(r - 1) * 2 * wm + 2 * wm])
         if gr:
-            x[o1:].copy_(self._recv[(r + 1) * 2 * wm:(r + 1) * 2 * wm + wm][:gr * m])
+            x[o1:].copy_(recv[(r + 1) * 2 * wm:(r + 1) * 2 * wm + wm])
+
+    def _xbuf(self, level):
+        if level not in self._bufs:
+            wm = self.L.W[level] * self.L.m[level]
+            self._bufs[level] = (self.e.new(2 * wm), self.e.new(2 * wm * self.L.world))
+        return self._bufs[level]
 
     def vcycle(self, x0, b, x_out, nPre=3, nPost=3, alpha=2.0 / 3.0, x0_ghosts_valid=False):
         """x0, b, x_out: local vectors (owned + ghosts).  b must be valid on the whole local domain
@@ -207,13 +224,30 @@ class DistributedVCycle:
         self.e.down(x0, b, nPre, alpha)
         rhs_c = self.e.coarse_rhs()
         nc = self._nc
+        mc = L.m[nc]
         gl, _ = L.ghosts(nc)
-        own = rhs_c[gl * L.m[nc]:gl * L.m[nc] + self._own_c]
-        self.c.all_gather(self._rhs_global, own)
-        self.exchanges += 1
-        sol = self.e.coarse_solve(self._rhs_global)
-        lo, hi = L.loc[nc]
-        self.e.set_coarse_solution(sol[lo * L.m[nc]:hi * L.m[nc]])
+        own = rhs_c[gl * mc:gl * mc + self._own_c]
+        if self.chunked:
+            e, cnt, P = self.e, self._cnt, L.world
+            blo, bhi = L.own[nc]
+            clo = blo >> self._q
+            partR, partL = e.coarse_forward(own, blo, bhi)
+            self.c.torch.cat((partR[clo * mc:clo * mc + cnt], partL[(clo + 1) * mc:(clo + 1) * mc + cnt]), out=self._send2)
+            self.c.all_gather(self._recv2, self._send2)
+            self.exchanges += 1
+            rv = self._recv2.view(P, 2, cnt)
+            partR[:P * cnt].view(P, cnt).copy_(rv[:, 0])
+            partL[mc:mc + P * cnt].view(P, cnt).copy_(rv[:, 1])
+            e.coarse_boundary_solve()
+            sol_c = e.coarse_solution()
+            e.coarse_backward(own, blo, bhi, sol_c[gl * mc:gl * mc + self._own_c])
+            self.exchange_ghosts(sol_c, nc)
+        else:
+            self.c.all_gather(self._rhs_global, own)
+            self.exchanges += 1
+            sol = self.e.coarse_solve(self._rhs_global)
+            lo, hi = L.loc[nc]
+            self.e.set_coarse_solution(sol[lo * mc:hi * mc])
         self.e.up(b, x_out, nPost, alpha)
 
 
@@ -226,6 +260,10 @@ class _DevView:
     def __init__(self, ptr, n):
         self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (int(ptr), False),
                                          "version": 2, "strides": None}
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr())
 
 
 class HipEngine:
@@ -243,6 +281,7 @@ class HipEngine:
         self._rhs_c = torch.as_tensor(_DevView(rp, n), device=self.dev)
         self._sol_c = torch.as_tensor(_DevView(sp_, n), device=self.dev)
         self._sol_g = None
+        self._partR = self._partL = self._xq = None
 
     def new(self, n):
         return self.torch.zeros(int(n), dtype=self.torch.float64, device=self.dev)
@@ -263,6 +302,37 @@ class HipEngine:
 
     def set_coarse_solution(self, t):
         self._sol_c.copy_(t)
+
+    def coarse_solution(self):
+        return self._sol_c
+
+    # chunked coarsest solve (aggmg_coarse_* entry points)
+    def coarse_plan(self):
+        c = self.ctx
+        q, nq, m, nb = ctypes.c_int(0), ctypes.c_int64(0), ctypes.c_int(0), ctypes.c_int64(0)
+        c.check(c.lib.aggmg_coarse_plan(c.handle, self.Hc.handle, ctypes.byref(q), ctypes.byref(nq),
+                                        ctypes.byref(m), ctypes.byref(nb)))
+        if q.value > 0 and self._partR is None:
+            self._partR = self.new((nq.value + 1) * m.value)
+            self._partL = self.new((nq.value + 1) * m.value)
+            self._xq = self.new((nq.value + 1) * m.value)
+        return q.value, nq.value, m.value, nb.value
+
+    def coarse_forward(self, rhs_owned, blk_lo, blk_hi):
+        c = self.ctx
+        c.check(c.lib.aggmg_coarse_chunk_forward_dev(c.handle, self.Hc.handle, _p(rhs_owned), blk_lo, blk_hi,
+                                                     _p(self._partR), _p(self._partL)))
+        return self._partR, self._partL
+
+    def coarse_boundary_solve(self):
+        c = self.ctx
+        c.check(c.lib.aggmg_coarse_boundary_solve_dev(c.handle, self.Hc.handle, _p(self._partR), _p(self._partL),
+                                                      _p(self._xq)))
+
+    def coarse_backward(self, rhs_owned, blk_lo, blk_hi, x_owned):
+        c = self.ctx
+        c.check(c.lib.aggmg_coarse_chunk_backward_dev(c.handle, self.Hc.handle, _p(rhs_owned), blk_lo, blk_hi,
+                                                      _p(self._xq), _p(x_owned)))
 
     def up(self, b, x_out, nPost, alpha):
         self.H.vcycle_up_dev(b, x_out, nPost, alpha)

@@ -154,6 +154,21 @@ int aggmg_vcycle_up_dev(aggmg_ctx* ctx, aggmg_hier* h, const double* b, int nPos
                         double* x_out);
 int aggmg_hier_coarse_buffers(aggmg_ctx* ctx, aggmg_hier* h, void** rhs_dev, void** sol_dev,
                               int64_t* n);
+/* The device coarsest solve phase by phase, for element-partitioned runs: block cyclic reduction
+ * eliminates the first `chunk_log2` levels independently per chunk of 2^chunk_log2 block rows, so
+ * every rank runs `chunk_forward` on the chunks of its own block range [blk_lo, blk_hi) (aligned to
+ * the chunk size) from its owned right-hand side, the ranks exchange their slices of the two
+ * boundary vectors partR / partL (n_boundary * block_size values each, written at global positions),
+ * every rank solves the small boundary system, and `chunk_backward` produces the owned solution.
+ * aggmg_coarse_plan reports chunk_log2 = -1 when the hierarchy's coarsest solver has no such plan. */
+int aggmg_coarse_plan(aggmg_ctx* ctx, const aggmg_hier* h, int* chunk_log2, int64_t* n_boundary,
+                      int* block_size, int64_t* n_blocks);
+int aggmg_coarse_chunk_forward_dev(aggmg_ctx* ctx, aggmg_hier* h, const double* rhs_owned, int64_t blk_lo,
+                                   int64_t blk_hi, double* partR, double* partL);
+int aggmg_coarse_boundary_solve_dev(aggmg_ctx* ctx, aggmg_hier* h, const double* partR, const double* partL,
+                                    double* xq);
+int aggmg_coarse_chunk_backward_dev(aggmg_ctx* ctx, aggmg_hier* h, const double* rhs_owned, int64_t blk_lo,
+                                    int64_t blk_hi, const double* xq, double* x_owned);
 /* Which coarsest solver a hierarchy uses: on_device (1 = cyclic reduction), its block size and the
  * largest pivot-block condition estimate met while factoring (0 for the host solver). */
 int aggmg_hier_coarse_info(aggmg_ctx* ctx, const aggmg_hier* h, int* on_device, int* block_size,

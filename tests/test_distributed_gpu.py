@@ -53,7 +53,7 @@ def _worker(rank, world, port, n, q):
         lo, hi = layout.own[0]
         ref_own = ref[lo * (p + 1):hi * (p + 1)]
         err = float(np.max(np.abs(got - ref_own)))
-        q.put((rank, err, float(np.max(np.abs(ref_own))), dv.exchanges))
+        q.put((rank, err, float(np.max(np.abs(ref_own))), dv.exchanges, dv.chunked))
     finally:
         dist.destroy_process_group()
 
@@ -70,6 +70,25 @@ def test_two_ranks_one_gpu_match_single_gpu():
     for pr in procs:
         pr.join(600)
     assert all(pr.exitcode == 0 for pr in procs), [pr.exitcode for pr in procs]
-    for rank, err, scale, nex in sorted(q.get() for _ in range(2)):
+    for rank, err, scale, nex, chunked in sorted(q.get() for _ in range(2)):
         assert err == 0.0, (rank, err, scale)    # bitwise: same per-row arithmetic on every rank
-        assert nex == 6                          # 2 all-gathers per cycle
+        assert not chunked and nex == 6          # small coarsest level: gather + replicated solve, 2 per cycle
+
+
+def test_two_ranks_chunked_coarse_solve():
+    """coarsest level large enough (2^13 rows) for the chunked cyclic reduction: every rank
+    eliminates its own chunks, only the chunk-boundary system and the coarse ghosts are exchanged"""
+    import torch.multiprocessing as mp
+    from test_distributed_cpu import free_port
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, 2**16, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    for pr in procs:
+        pr.join(900)
+    assert all(pr.exitcode == 0 for pr in procs), [pr.exitcode for pr in procs]
+    for rank, err, scale, nex, chunked in sorted(q.get() for _ in range(2)):
+        assert chunked and nex == 9              # x0 ghosts, boundary system, coarse ghosts
+        assert err == 0.0, (rank, err, scale)
