@@ -5,10 +5,13 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A step is one multigrid_v_cycle (V(3,3), alpha = 2/3, src/solvers.jl:19-50) over the
-BASELINE.json config-3 hierarchy: DG p=3 fine level (2^E elements, default E=22) ->
-AggDG pAgg=1 (4:1) -> AggDG (2:1) -> AggDG (2:1), all operators and vectors resident in HBM
-before the timed region.  For N > 1 the same hierarchy is partitioned by contiguous element
-range (strong scaling, config 4).  Rank 0 prints ONE JSON line.
+BASELINE.json config-3/4 hierarchy: DG p=3 fine level (2^E elements) -> AggDG pAgg=1 (4:1) ->
+AggDG (2:1) -> AggDG (2:1), all operators and vectors resident in HBM before the timed region.
+Default E = 24: the size BASELINE.json's north_star / BASELINE.md section 2 quote the 1-vs-8-GPU
+target on ("2^24-element p=3 DG hierarchy"), so that `--gpus 1,2,4,8` is one strong-scaling
+series; at N = 1 the same line also carries the literal config-3 size (2^22) as `config3_2p22`.
+For N > 1 the hierarchy is partitioned by contiguous element range (config 4).  Rank 0 prints
+ONE JSON line.
 
 metric  fine-level DoF-updates/s per V-cycle = N_fine * (nPre + nPost) / t_vcycle, the whole
         cycle timed (the coarsest direct solve included; its share is reported beside it).
@@ -37,7 +40,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--log2-elems", type=int, default=22, help="fine DG elements = 2^E (config 3: 22)")
+    ap.add_argument("--log2-elems", type=int, default=24, help="fine DG elements = 2^E (north-star scaling size 24)")
+    ap.add_argument("--also-log2-elems", type=int, default=22,
+                    help="N = 1 only: second, untimed-region run at this size (config 3 literal: 22); 0 = off")
     ap.add_argument("--p", type=int, default=3)
     ap.add_argument("--cpu-log2-elems", type=int, default=20, help="size of the CPU-baseline sample")
     ap.add_argument("--cpu-cycles", type=int, default=4)
@@ -161,46 +166,59 @@ def main():
         return dist_mg.bench_main(args, rank, world, local_rank, nPre, nPost, alpha)
 
     ctx = mg.Context(local_rank)
-    n = 2 ** args.log2_elems
-    t_setup = time.perf_counter()
-    U = UniformDgAggHierarchy(n, p=args.p, pAgg=1, ratios=(4, 2, 2))
-    H = build_device_hierarchy(U, ctx)
-    bytes_model = U.algorithmic_bytes(nPre, nPost)
-    N = U.levels[0]['m'] * U.levels[0]['ne']
-    b = ctx.to_device(U.rhs())
-    xa = ctx.to_device(np.zeros(N))
-    xb = ctx.alloc(N)
-    level_sizes = [lv['m'] * lv['ne'] for lv in U.levels]
-    del U
-    t_setup = time.perf_counter() - t_setup
-    assert all(H.structured_levels()), "fused HIP kernels were not selected"
 
-    src, dst = xa, xb
-    for _ in range(args.warmup):
-        H.vcycle_dev(src, b, dst, nPre, nPost, alpha)
-        src, dst = dst, src
-    ctx.synchronize()
-    ctx.profile_enable(True)
-    coarse_ms = 0.0
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        H.vcycle_dev(src, b, dst, nPre, nPost, alpha)
-        coarse_ms += H.last_coarse_ms()
-        src, dst = dst, src
-    ctx.synchronize()
-    dt = time.perf_counter() - t0
-    ctx.profile_enable(False)
-    prof = ctx.profile_collect()
+    def run_size(E, steps, warmup, profile):
+        """build the hierarchy at 2^E fine elements, run `steps` timed V-cycles and the same count
+        through the multi-cycle entry point"""
+        n = 2 ** E
+        t_setup = time.perf_counter()
+        U = UniformDgAggHierarchy(n, p=args.p, pAgg=1, ratios=(4, 2, 2))
+        H = build_device_hierarchy(U, ctx)
+        bytes_model = U.algorithmic_bytes(nPre, nPost)
+        N = U.levels[0]['m'] * U.levels[0]['ne']
+        b = ctx.to_device(U.rhs())
+        xa = ctx.to_device(np.zeros(N))
+        xb = ctx.alloc(N)
+        level_sizes = [lv['m'] * lv['ne'] for lv in U.levels]
+        del U
+        t_setup = time.perf_counter() - t_setup
+        assert all(H.structured_levels()), "fused HIP kernels were not selected"
+        src, dst = xa, xb
+        for _ in range(warmup):
+            H.vcycle_dev(src, b, dst, nPre, nPost, alpha)
+            src, dst = dst, src
+        ctx.synchronize()
+        if profile:
+            ctx.profile_enable(True)
+        coarse_ms = 0.0
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            H.vcycle_dev(src, b, dst, nPre, nPost, alpha)
+            coarse_ms += H.last_coarse_ms()
+            src, dst = dst, src
+        ctx.synchronize()
+        dt = time.perf_counter() - t0
+        prof = None
+        if profile:
+            ctx.profile_enable(False)
+            prof = ctx.profile_collect()
+        # the same K cycles through the multi-cycle entry point (the loop body of multigrid(),
+        # src/solvers.jl:124-126): consecutive cycles share one fused fine-level launch.  Reported
+        # beside `value`, which stays K independent multigrid_v_cycle calls.
+        H.vcycles_dev(src, b, dst, steps, nPre, nPost, alpha)
+        ctx.synchronize()
+        t1 = time.perf_counter()
+        H.vcycles_dev(src, b, dst, steps, nPre, nPost, alpha)
+        ctx.synchronize()
+        dt_loop = time.perf_counter() - t1
+        info = H.coarse_info()
+        H.free()
+        return dict(N=N, dt=dt, dt_loop=dt_loop, prof=prof, bytes_model=bytes_model, level_sizes=level_sizes,
+                    coarse_ms=coarse_ms, t_setup=t_setup, coarse_info=info)
 
-    # the same K cycles through the multi-cycle entry point (the loop body of multigrid(),
-    # src/solvers.jl:124-126): consecutive cycles share one fused fine-level launch.  Reported
-    # beside `value`, which stays K independent multigrid_v_cycle calls.
-    H.vcycles_dev(src, b, dst, args.steps, nPre, nPost, alpha)
-    ctx.synchronize()
-    t1 = time.perf_counter()
-    H.vcycles_dev(src, b, dst, args.steps, nPre, nPost, alpha)
-    ctx.synchronize()
-    dt_loop = time.perf_counter() - t1
+    R = run_size(args.log2_elems, args.steps, args.warmup, True)
+    N, dt, dt_loop, prof, bytes_model = R["N"], R["dt"], R["dt_loop"], R["prof"], R["bytes_model"]
+    level_sizes, coarse_ms, t_setup = R["level_sizes"], R["coarse_ms"], R["t_setup"]
 
     ms_per_step = 1e3 * dt / args.steps
     value = N * (nPre + nPost) * args.steps / dt
@@ -234,8 +252,10 @@ def main():
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
-        "config": {"workload": f"config 3: V(3,3) cycle, alpha=2/3, DG p={args.p} n=2^{args.log2_elems} -> AggDG pAgg=1 "
-                               f"4:1 -> 2:1 -> 2:1 (4 levels), uniform mesh, Neumann/Dirichlet, CDir=1000n",
+        "config": {"workload": f"config 3/4 hierarchy: V(3,3) cycle, alpha=2/3, DG p={args.p} n=2^{args.log2_elems} -> AggDG "
+                               f"pAgg=1 4:1 -> 2:1 -> 2:1 (4 levels), uniform mesh, Neumann/Dirichlet, CDir=1000n"
+                               + (" (north-star 1-vs-8-GPU size; config 3's own 2^22 in config3_2p22)"
+                                  if args.log2_elems == 24 else ""),
                    "fine_dofs": N, "level_dofs": level_sizes, "nPre": nPre, "nPost": nPost,
                    "parallelism": "single GPU"},
         "achieved_algorithmic_GBs_vcycle": vcycle_bytes * args.steps / dt / 1e9,
@@ -244,7 +264,7 @@ def main():
                          "note": f"aggmg_vcycles_dev({args.steps} cycles): same arithmetic as {args.steps} separate "
                                  "V-cycles (bitwise), post-smoothing of cycle i and pre-smoothing of cycle i+1 in one "
                                  "fine-level launch"},
-        "coarse_solve": H.coarse_info(),
+        "coarse_solve": R["coarse_info"],
         "coarse_solve_host_ms_per_step": coarse_ms / args.steps,
         "value_excl_coarse_solve": N * (nPre + nPost) / max(1e-3 * (ms_per_step - coarse_ms / args.steps), 1e-12),
         "roofline": {"bound": "hbm", "kernel": f"btd_fused_kernel<{args.p + 1},cmp> {dkind} level {dlevel + 1}",
@@ -257,6 +277,13 @@ def main():
         "kernels": kern_ms,
         "setup_s": t_setup,
     }
+    if args.also_log2_elems and args.also_log2_elems != args.log2_elems:
+        R2 = run_size(args.also_log2_elems, args.steps, args.warmup, False)
+        out[f"config3_2p{args.also_log2_elems}"] = {
+            "workload": f"config 3: same hierarchy at 2^{args.also_log2_elems} fine elements (N_fine={R2['N']})",
+            "value": R2["N"] * (nPre + nPost) * args.steps / R2["dt"], "unit": "DoF-updates/s",
+            "ms_per_step": 1e3 * R2["dt"] / args.steps,
+            "vcycles_loop_ms_per_cycle": 1e3 * R2["dt_loop"] / args.steps, "setup_s": R2["t_setup"]}
     if not args.no_smoother_bench:
         out["smoother_only"] = smoother_bench(mg, ctx, args, alpha)
     if not args.no_cpu_baseline:
