@@ -449,7 +449,8 @@ def bench_main(args, rank, world, local_rank, nPre, nPost, alpha):
                        "backend": backend,
                        "parallelism": f"element-range x{world}, deep halos W={layout.W}, "
                                       f"{dv.exchanges // (args.steps + args.warmup)} RCCL all-gathers per cycle, "
-                                      f"coarsest solve replicated"},
+                                      + ("coarsest solve: chunk elimination on each rank's own blocks, boundary system replicated"
+                                         if dv.chunked else "coarsest solve gathered and replicated")},
             "roofline": {"bound": "hbm", "kernel": f"btd_fused_kernel<{args.p + 1},cmp> {dkind} level {dlevel + 1} (rank 0)",
                          "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "traffic": None, "algorithmic_bytes_per_launch": per_launch,

@@ -39,9 +39,9 @@ def load(kind):
 
 
 shutil.copy(glob.glob(os.path.join(src, "kt", "*", "*kernel_stats.csv"))[0],
-            os.path.join(ROOT, "profiles", f"{tag}_bench_kernel_stats.csv"))
+            os.path.join(ROOT, "profiles", f"{tag}_bench_kernel_stats_2p{E}.csv"))
 F, W = load("fetch"), load("write")
-lines = [f"# rocprofv3 PMC summary {tag} -- `python bench.py --steps 5 --warmup 1` (config 3, 2^{E} fine elements, MI355X)",
+lines = [f"# rocprofv3 PMC summary {tag} -- `python bench.py --steps 5 --warmup 1` (config 3/4 hierarchy, 2^{E} fine elements, MI355X)",
          "",
          "Separate passes `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (`--output-format csv`), KiB per dispatch,",
          "mean over the pass.  gfx950: FETCH_SIZE counts half the bytes of a coalesced streaming read",
@@ -63,7 +63,10 @@ for (k, g), (f, n) in sorted(F.items(), key=lambda kv: -kv[1][0]):
         traffic[f"{role}_log2n{E}"] = hb
     name = k.split("(")[0].replace("void ", "")
     lines.append(f"| `{name}` | {role} ({g}) | {n} | {f:.1f} | {w:.1f} | {hb:.4g} | {er} | {ew} |")
-lines += ["", f"Kernel-trace stats of the same command: profiles/{tag}_bench_kernel_stats.csv."]
-open(os.path.join(ROOT, "profiles", f"{tag}_pmc_summary.md"), "w").write("\n".join(lines) + "\n")
-json.dump(traffic, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
+lines += ["", f"Kernel-trace stats of the same command: profiles/{tag}_bench_kernel_stats_2p{E}.csv."]
+open(os.path.join(ROOT, "profiles", f"{tag}_pmc_summary_2p{E}.md"), "w").write("\n".join(lines) + "\n")
+tf = os.path.join(ROOT, "profiles", "traffic.json")
+old = json.load(open(tf)) if os.path.exists(tf) else {}
+old.update(traffic)
+json.dump(old, open(tf, "w"), indent=1)
 print("\n".join(lines))
