@@ -51,6 +51,8 @@ struct CsrDev {
   int32_t* colind = nullptr;
   double* vals = nullptr;
   int lpr = 1;
+  int32_t* rowblk = nullptr;  // CSR-stream row blocks (short-row matrices), nblk + 1 entries
+  int64_t nblk = 0;
   CsrView view() const { return CsrView{rowptr, colind, vals, nrows}; }
 };
 
@@ -366,6 +368,23 @@ static int upload_csr(aggmg_ctx* ctx, int64_t nrows, int64_t ncols, const std::v
   CHECK(dev_upload(ctx, rowptr, &d->rowptr));
   CHECK(dev_upload(ctx, colind, &d->colind));
   CHECK(dev_upload(ctx, vals, &d->vals));
+  // short rows: cut the rows into blocks of <= kStreamNnz entries and <= 4 * kThreads rows for the
+  // CSR-stream kernel; long-row matrices keep the lanes-per-row kernel
+  if (nrows > 0 && (double)d->nnz / (double)nrows <= 48.0) {
+    std::vector<int32_t> blk;
+    blk.push_back(0);
+    int64_t r = 0;
+    while (r < nrows) {
+      int64_t e = r + 1;  // a block always takes at least one row (a long row stands alone)
+      const int64_t base = rowptr[r];
+      while (e < nrows && e - r < 4 * kThreads && rowptr[e + 1] - base <= kStreamNnz) ++e;
+      if (rowptr[r + 1] - base > kStreamNnz) e = r + 1;
+      blk.push_back((int32_t)e);
+      r = e;
+    }
+    d->nblk = (int64_t)blk.size() - 1;
+    CHECK(dev_upload(ctx, blk, &d->rowblk));
+  }
   return AGGMG_OK;
 }
 
@@ -373,6 +392,7 @@ static void free_csr(CsrDev* d) {
   if (d->rowptr) (void)hipFree(d->rowptr);
   if (d->colind) (void)hipFree(d->colind);
   if (d->vals) (void)hipFree(d->vals);
+  if (d->rowblk) (void)hipFree(d->rowblk);
   *d = CsrDev();
 }
 
@@ -731,6 +751,12 @@ template <int MODE>
 static int launch_csr(aggmg_ctx* ctx, const CsrDev& A, const double* x, const double* b, const double* dg,
                       double alpha, double* y) {
   if (A.nrows == 0) return AGGMG_OK;
+  if (A.rowblk) {
+    hipLaunchKernelGGL((csr_stream_kernel<MODE>), dim3((unsigned)A.nblk), dim3(kThreads), 0, ctx->stream, A.view(),
+                       (const int32_t*)A.rowblk, x, b, dg, alpha, y);
+    HIPCHK(hipGetLastError());
+    return AGGMG_OK;
+  }
   const int lpr = A.lpr;
   const int64_t rows_per_block = kThreads / lpr;
   const int64_t nblk = (A.nrows + rows_per_block - 1) / rows_per_block;

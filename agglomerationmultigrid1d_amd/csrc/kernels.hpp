@@ -64,6 +64,71 @@ __global__ __launch_bounds__(kThreads) void csr_row_kernel(CsrView A, const doub
   }
 }
 
+// "CSR-stream" variant for short rows (a few to a few dozen entries per row: CG and DG stiffness
+// matrices, transfers): a workgroup owns a run of consecutive rows holding at most kStreamNnz
+// entries (row blocks cut on the host at upload), streams their values / column indices with
+// fully coalesced loads, parks the products a_ij * x_j in LDS and lets one thread per row add its
+// products in ascending column order -- the order SparseArrays' CSC scatter accumulates them.
+// A row longer than kStreamNnz forms a block of its own and is reduced across the workgroup.
+constexpr int kStreamNnz = 4096;
+template <int MODE>
+__global__ __launch_bounds__(kThreads) void csr_stream_kernel(CsrView A, const int32_t* __restrict__ rowblk,
+                                                              const double* __restrict__ x,
+                                                              const double* __restrict__ b,
+                                                              const double* __restrict__ dg, double alpha,
+                                                              double* __restrict__ y) {
+  __shared__ double prod[kStreamNnz];
+  __shared__ double red[kThreads / 64];
+  const int tid = threadIdx.x;
+  const int r0 = rowblk[blockIdx.x], r1 = rowblk[blockIdx.x + 1];
+  const int p0 = A.rowptr[r0], p1 = A.rowptr[r1];
+  const int nn = p1 - p0;
+  auto finish = [&](int row, double acc) {
+    if (MODE == kSpmvSet) y[row] = acc;
+    if (MODE == kSpmvAdd) y[row] += acc;
+    if (MODE == kResidual) y[row] = b[row] - acc;
+    if (MODE == kJacobi) {
+      const double r = b[row] - acc;
+      const double yy = r / dg[row];
+      y[row] = x[row] + alpha * yy;
+    }
+  };
+  if (nn <= kStreamNnz) {
+    // four independent (value, index, gather) chains in flight per thread
+    int p = tid;
+    for (; p + 3 * kThreads < nn; p += 4 * kThreads) {
+      const int c0 = A.colind[p0 + p], c1 = A.colind[p0 + p + kThreads], c2 = A.colind[p0 + p + 2 * kThreads],
+                c3 = A.colind[p0 + p + 3 * kThreads];
+      const double v0 = A.vals[p0 + p], v1 = A.vals[p0 + p + kThreads], v2 = A.vals[p0 + p + 2 * kThreads],
+                   v3 = A.vals[p0 + p + 3 * kThreads];
+      prod[p] = v0 * x[c0];
+      prod[p + kThreads] = v1 * x[c1];
+      prod[p + 2 * kThreads] = v2 * x[c2];
+      prod[p + 3 * kThreads] = v3 * x[c3];
+    }
+    for (; p < nn; p += kThreads) prod[p] = A.vals[p0 + p] * x[A.colind[p0 + p]];
+    __syncthreads();
+    for (int r = r0 + tid; r < r1; r += kThreads) {
+      const int q0 = A.rowptr[r] - p0, q1 = A.rowptr[r + 1] - p0;
+      double acc = 0.0;
+      for (int q = q0; q < q1; ++q) acc += prod[q];
+      finish(r, acc);
+    }
+  } else {  // one long row
+    double acc = 0.0;
+    for (int p = p0 + tid; p < p1; p += kThreads) acc += A.vals[p] * x[A.colind[p]];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if ((tid & 63) == 0) red[tid >> 6] = acc;
+    __syncthreads();
+    if (tid == 0) {
+      double t = 0.0;
+      for (int w = 0; w < kThreads / 64; ++w) t += red[w];
+      finish(r0, t);
+    }
+  }
+}
+
 // y[inds] (+)= Binv_blk * r[inds]   -- generic block apply (arbitrary, possibly overlapping,
 // index lists: BlockJacobi / AdditiveSchwarz / HybridSchwarz, src/smoother.jl:6-18,30-46,69-81).
 // One thread per (block, local row).  ATOMIC for overlapping blocks (y pre-zeroed).
