@@ -1,0 +1,133 @@
+"""Edge cases of the hot path on the GPU against the oracle: degenerate mesh sizes (1, 2, 3
+elements; element counts that do not fill a tile; a single-level hierarchy), every DG block size the
+fused kernels are instantiated for inside a full V-cycle, Schwarz smoothers inside fused sweeps,
+zero sweeps, alpha = 1, multi-column smoother application."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-12
+
+
+def rel(a, b):
+    return np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(np.linalg.norm(b), 1e-300)
+
+
+@pytest.fixture(scope="module")
+def mg():
+    import agglomerationmultigrid1d_amd as mg
+    mg.default_context()
+    return mg
+
+
+def dense_lu_solve(A, b):
+    import scipy.linalg as sla
+    return sla.lu_solve(sla.lu_factor(A.toarray()), b)
+
+
+def vcycle_check(o, mg, Ho, b, x0=None, it_tol=1e-9, **kw):
+    H = mg.MeshHierarchy.from_reference(Ho)
+    x0 = np.zeros(len(b)) if x0 is None else x0
+    x = mg.multigrid_v_cycle(H, x0, b, **kw)
+    xr = o.multigrid_v_cycle(Ho, x0, b, coarse_solve=dense_lu_solve, **kw)
+    A = Ho.mStiffness[0]
+    r0 = max(np.linalg.norm(b - A @ x0), np.linalg.norm(b))
+    assert np.linalg.norm(A @ (x - xr)) <= TOL * r0
+    assert rel(x, xr) < it_tol
+    return H
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 63, 249, 257])
+def test_tiny_and_ragged_meshes(oracle, mg, n):
+    """smoother + residual on meshes of 1..3 elements and sizes straddling the 248/256-element tiles"""
+    o = oracle
+    mesh, bd = o.model_problem(n)
+    dg = o.DgMesh(mesh, 3)
+    G, D, C = o.dg_flux_operators(dg, mesh, bd, 1000.0 * n)
+    A = o.dg_stiffness(dg, G, D, C)
+    So, Sg = o.dg_smoother(dg, A, 'blockJac'), mg.dg_smoother(dg, A, 'blockJac')
+    assert Sg.structured
+    u, b = o.splitmix_normal(A.shape[0], 1), o.splitmix_normal(A.shape[0], 2)
+    for ns in (1, 4, 9):
+        ref = u
+        for _ in range(ns):
+            ref = ref + o.apply_smoother(So, b - o.csc_matvec(A, ref), alpha=2.0 / 3.0)
+        assert rel(mg.smooth(Sg.A, Sg, u, b, 2.0 / 3.0, ns), ref) < TOL
+    assert rel(mg.residual(Sg.A, u, b), b - o.csc_matvec(A, u)) < TOL
+
+
+def test_two_level_and_single_level_hierarchies(oracle, mg):
+    o = oracle
+    Ho, b = o.build_dg_agg_hierarchy(8, p=3, pAgg=1, nAgg=1, first=4)       # 2 levels, 2 coarse elements
+    vcycle_check(o, mg, Ho, b)
+    Ho, b = o.build_dg_agg_hierarchy(4, p=1, pAgg=0, nAgg=1, first=4)       # coarsest = one scalar
+    vcycle_check(o, mg, Ho, b)
+    # a hierarchy with one level: the "V-cycle" is the direct solve (src/solvers.jl:39)
+    mesh, bd = o.model_problem(40)
+    dg = o.DgMesh(mesh, 2)
+    G, D, C = o.dg_flux_operators(dg, mesh, bd, 40000.0)
+    A = o.dg_stiffness(dg, G, D, C)
+    bb = o.splitmix_normal(A.shape[0], 3)
+    H = mg.MeshHierarchy([dg], [A], [], [])
+    x = mg.multigrid_v_cycle(H, np.zeros(len(bb)), bb)
+    assert np.linalg.norm(A @ x - bb) <= 1e-9 * np.linalg.norm(bb)
+    assert rel(x, o.sparse_direct_solve(A, bb)) < 1e-8
+
+
+@pytest.mark.parametrize("ps", [(5, 2), (6, 3), (7, 3), (9, 4, 2)])
+def test_vcycle_all_block_sizes(oracle, mg, ps):
+    """dg_dg p-coarsening chains through every fused-kernel instantiation (m = 3 .. 10 -> generic)"""
+    o = oracle
+    Ho, b = o.build_dg_p_hierarchy(40, ps=ps)
+    H = vcycle_check(o, mg, Ho, b, it_tol=1e-8)
+    # p = 9 (m = 10) has no fused instantiation: the generic CSR path must take over silently
+    assert H.structured_levels()[0] == (ps[0] + 1 <= 9)
+
+
+def test_sweep_parameters(oracle, mg):
+    o = oracle
+    Ho, b = o.build_dg_agg_hierarchy(96, p=3, pAgg=1, nAgg=2, first=4)
+    for kw in (dict(nPre=0, nPost=3), dict(nPre=3, nPost=0), dict(nPre=2, nPost=5, alpha=1.0),
+               dict(nPre=8, nPost=8, alpha=0.3)):
+        vcycle_check(o, mg, Ho, b, x0=o.splitmix_normal(len(b), 5), it_tol=1e-8, **kw)
+    H = mg.MeshHierarchy.from_reference(Ho)
+    with pytest.raises(mg.ArgumentError):
+        mg.multigrid_v_cycle(H, np.zeros(len(b)), b, nPre=-1)
+    with pytest.raises(TypeError):
+        mg.multigrid_v_cycle(H, np.zeros(len(b)), b, nPre=2.5)     # nPre::Integer
+
+
+def test_schwarz_smoothers_in_fused_sweeps(oracle, mg):
+    """aggmg_smooth with overlapping CG element blocks (additive / hybrid Schwarz, src/smoother.jl
+    :1-46): the tests/cg_smoother_test.jl iteration through the device path"""
+    o = oracle
+    n = 16
+    mesh = o.create_uniform_mesh(n, 0.0, 1.0)
+    ue = lambda x: -0.5 * x**2 + x
+    bd = o.set_boundary(mesh, 0.0, 1.0, [('dir', ue(0.0)), ('dir', ue(1.0))])
+    cg = o.CgMesh(mesh, 4)
+    A, b = o.cg_stiffness_and_rhs(cg, mesh, lambda x: 1.0, bd)
+    u0 = o.splitmix_normal(A.shape[0], 2)
+    for kind, alpha in (('jac', 0.5), ('addSchwarz', 0.5), ('hybridSchwarz', 1.0)):
+        So, Sg = o.cg_smoother(cg, A, kind), mg.cg_smoother(cg, A, kind)
+        ref = u0
+        for _ in range(5):
+            ref = ref + o.apply_smoother(So, b - o.csc_matvec(A, ref), alpha=alpha)
+        assert rel(mg.smooth(Sg.A, Sg, u0, b, alpha, 5), ref) < TOL, kind
+        xo, ito, reso, _ = o.iterative_smoother_solve(A, So, np.zeros(len(b)), b, maxiter=40, alpha=alpha)
+        xg, itg, resg, _ = mg.iterative_smoother_solve(A, Sg, np.zeros(len(b)), b, maxiter=40, alpha=alpha)
+        assert itg == ito and rel(xg, xo) < 1e-10 and np.allclose(resg, reso, rtol=1e-8)
+
+
+def test_multi_column_apply_and_empty(oracle, mg):
+    o = oracle
+    mesh, bd = o.model_problem(12)
+    dg = o.DgMesh(mesh, 2)
+    G, D, C = o.dg_flux_operators(dg, mesh, bd, 12000.0)
+    A = o.dg_stiffness(dg, G, D, C)
+    So, Sg = o.dg_smoother(dg, A, 'blockJac'), mg.dg_smoother(dg, A, 'blockJac')
+    B = np.stack([o.splitmix_normal(A.shape[0], s) for s in range(5)], axis=1)
+    assert rel(mg.apply_smoother(Sg, B, 0.7), o.apply_smoother(So, B, 0.7)) < TOL
+    Y0 = mg.apply_smoother(Sg, np.zeros((A.shape[0], 0)))
+    assert Y0.shape == (A.shape[0], 0)
