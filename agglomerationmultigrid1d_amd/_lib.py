@@ -76,6 +76,7 @@ SYMBOLS = {
     "aggmg_op_release_host": (c_int, [_P, _P]),
     "aggmg_blockjacobi_setup": (c_int, [_P, _P, c_int64, c_int64, POINTER(c_int64), c_int, c_int,
                                         POINTER(_P)]),
+    "aggmg_blockdiag_setup": (c_int, [_P, c_int64, c_int64, _PD, c_int, POINTER(_P)]),
     "aggmg_jacobi_setup": (c_int, [_P, _P, POINTER(_P)]),
     "aggmg_smoother_free": (c_int, [_P, _P]),
     "aggmg_smoother_apply": (c_int, [_P, _P, _PD, c_int64, c_int64, c_double, _PD]),

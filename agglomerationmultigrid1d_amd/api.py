@@ -299,6 +299,100 @@ class HybridSchwarzSmoother(_BlockSmoother):
     _kind = 1
 
 
+class _BlockObject(AbstractSmoother):
+    """device handle of a block-diagonal matrix or of its factorisation"""
+
+    def __init__(self, ctx, handle, N):
+        self._ctx, self.handle, self.N = ctx, handle, N
+
+    def free(self):
+        if getattr(self, "handle", None) and self._ctx.handle:
+            self._ctx.lib.aggmg_smoother_free(self._ctx.handle, self.handle)
+        self.handle = None
+
+    def _apply(self, B):
+        B = np.asarray(B, dtype=np.float64)
+        if B.ndim not in (1, 2) or B.shape[0] != self.N:
+            raise DimensionMismatch("BlockDiagonal: DimensionMismatch")
+        ncols = 1 if B.ndim == 1 else B.shape[1]
+        Bf = np.asfortranarray(B.reshape(self.N, ncols))
+        Y = np.empty((self.N, ncols), order='F')
+        c = self._ctx
+        c.check(c.lib.aggmg_smoother_apply(c.handle, self.handle, Bf.ctypes.data_as(_PD), self.N, ncols, 1.0,
+                                           Y.ctypes.data_as(_PD)))
+        return Y[:, 0].copy() if B.ndim == 1 else np.ascontiguousarray(Y)
+
+
+class BlockDiagonal:
+    """struct BlockDiagonal{mBlocks, mBlockSize, mBlockInds} (src/block_diagonal.jl:11-15) with the
+    BlockDiagonal(mBlocks) constructor (:27-41): equal-sized dense blocks, contiguous index lists.
+    `A * x` / `A * B` for dense vectors and matrices run the batched block kernel (mul!, :166-176);
+    `lu(A)` (:276) gives a BlockDiagonalLU."""
+
+    def __init__(self, mBlocks, ctx=None):
+        if len(mBlocks) == 0:
+            raise ArgumentError("BlockDiagonal needs at least one block")
+        m = np.asarray(mBlocks[0]).shape[0]
+        for blk in mBlocks:
+            if np.asarray(blk).shape != (m, m):
+                raise ArgumentError("All blocks must be of the same size.")   # block_diagonal.jl:35-37
+        self.mBlocks = [np.array(blk, dtype=np.float64) for blk in mBlocks]
+        self.mBlockSize = m
+        nb = len(mBlocks)
+        self.mBlockInds = np.arange(nb, dtype=np.int64)[None, :] * m + np.arange(1, m + 1, dtype=np.int64)[:, None]
+        self._ctx = ctx or default_context()
+        self._dev = None
+
+    @property
+    def shape(self):
+        n = len(self.mBlocks) * self.mBlockSize
+        return (n, n)
+
+    def _setup(self, factorize):
+        c = self._ctx
+        flat = np.ascontiguousarray(np.stack([b.T for b in self.mBlocks]))   # column-major per block
+        h = ctypes.c_void_p()
+        c.check(c.lib.aggmg_blockdiag_setup(c.handle, self.mBlockSize, len(self.mBlocks), flat.ctypes.data_as(_PD),
+                                            1 if factorize else 0, ctypes.byref(h)))
+        return _BlockObject(c, h, self.shape[0])
+
+    def __matmul__(self, B):
+        if self._dev is None:
+            self._dev = self._setup(False)
+        return self._dev._apply(B)
+
+    mul = __matmul__
+
+    def lu(self):
+        return BlockDiagonalLU(self)
+
+    def todense(self):
+        """Matrix(A) (src/block_diagonal.jl:107-114)"""
+        out = np.zeros(self.shape)
+        m = self.mBlockSize
+        for k, blk in enumerate(self.mBlocks):
+            out[k * m:(k + 1) * m, k * m:(k + 1) * m] = blk
+        return out
+
+
+class BlockDiagonalLU:
+    """struct BlockDiagonalLU (src/block_diagonal.jl:17-21, ctor :47-58): `A \\ x`, `A \\ B` for dense
+    right-hand sides (ldiv!, :299-309).  A singular block raises SingularException."""
+
+    def __init__(self, A):
+        self.mBlockSize, self.mBlockInds = A.mBlockSize, A.mBlockInds
+        self._dev = A._setup(True)
+
+    @property
+    def shape(self):
+        return (self._dev.N, self._dev.N)
+
+    def solve(self, B):
+        return self._dev._apply(B)
+
+    ldiv = solve
+
+
 def _mesh_block_inds(mesh):
     if hasattr(mesh, "mBlockInds"):
         return np.asarray(mesh.mBlockInds, dtype=np.int64)

@@ -711,6 +711,46 @@ extern "C" int aggmg_blockjacobi_setup(aggmg_ctx* ctx, aggmg_op* A, int64_t m, i
   return AGGMG_OK;
 }
 
+// BlockDiagonal / BlockDiagonalLU (src/block_diagonal.jl:11-21): a block-diagonal matrix given by its
+// dense blocks, applied (mul!, :166-176) or solved with (ldiv!, :299-309) through the same batched
+// small-block kernel as the block smoother.  blocks: nb blocks of m x m, each column-major (a Julia
+// Matrix{Float64}); contiguous aligned index lists as the BlockDiagonal(mBlocks) constructor makes.
+extern "C" int aggmg_blockdiag_setup(aggmg_ctx* ctx, int64_t m, int64_t nb, const double* blocks, int factorize,
+                                     aggmg_smoother** out) {
+  if (!ctx || !out || (!blocks && nb > 0)) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_blockdiag_setup: NULL argument");
+  *out = nullptr;
+  if (m <= 0 || m > 64 || nb < 0) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_blockdiag_setup: block size must be in 1..64");
+  if (m * nb >= ((int64_t)1 << 31)) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_blockdiag_setup: size >= 2^31");
+  HIPCHK(hipSetDevice(ctx->device));
+  auto sm = std::make_unique<aggmg_smoother>();
+  sm->kind = 1;
+  sm->A = nullptr;
+  sm->N = m * nb;
+  sm->m = m;
+  sm->nb = nb;
+  sm->contiguous = true;
+  std::vector<int32_t> inds((size_t)nb * m);
+  for (int64_t i = 0; i < nb * m; ++i) inds[i] = (int32_t)i;
+  std::vector<double> mats((size_t)nb * m * m), blk((size_t)m * m), inv;
+  std::vector<int> piv;
+  for (int64_t k = 0; k < nb; ++k) {
+    for (int64_t i = 0; i < m; ++i)
+      for (int64_t j = 0; j < m; ++j) blk[i * m + j] = blocks[k * m * m + j * m + i];  // column- to row-major
+    if (factorize) {
+      if (!invert_block((int)m, blk, inv, piv))
+        return fail(ctx, AGGMG_ERR_SINGULAR,
+                    "aggmg_blockdiag_setup: singular block " + std::to_string(k + 1) + " (SingularException)");
+      std::copy(inv.begin(), inv.end(), mats.begin() + k * m * m);
+    } else {
+      std::copy(blk.begin(), blk.end(), mats.begin() + k * m * m);
+    }
+  }
+  CHECK(dev_upload(ctx, mats, &sm->binv));
+  CHECK(dev_upload(ctx, inds, &sm->inds));
+  *out = sm.release();
+  return AGGMG_OK;
+}
+
 extern "C" int aggmg_jacobi_setup(aggmg_ctx* ctx, aggmg_op* A, aggmg_smoother** out) {
   if (!ctx || !A || !out) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_jacobi_setup: NULL argument");
   *out = nullptr;

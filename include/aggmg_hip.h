@@ -88,6 +88,13 @@ int aggmg_blockjacobi_setup(aggmg_ctx* ctx, aggmg_op* A, int64_t m, int64_t nb,
                             aggmg_smoother** out);
 /* dg_smoother / cg_smoother (..., :jac): JacobiSmoother(Diagonal(A)) src/smoother.jl:95-102,146-152 */
 int aggmg_jacobi_setup(aggmg_ctx* ctx, aggmg_op* A, aggmg_smoother** out);
+/* BlockDiagonal (factorize = 0: apply = `A * X`, mul! src/block_diagonal.jl:166-176) and
+ * BlockDiagonalLU (factorize = 1: apply = `A \\ X`, ldiv! :299-309; `lu(A)` :276) as block objects of
+ * the same kind as the block smoother: blocks = nb dense m x m blocks, each column-major, with the
+ * contiguous index lists the BlockDiagonal(mBlocks) constructor (:27-41) makes.  Applied with
+ * aggmg_smoother_apply(..., alpha = 1).  A singular block -> AGGMG_ERR_SINGULAR. */
+int aggmg_blockdiag_setup(aggmg_ctx* ctx, int64_t m, int64_t nb, const double* blocks, int factorize,
+                          aggmg_smoother** out);
 int aggmg_smoother_free(aggmg_ctx* ctx, aggmg_smoother* sm);
 /* apply_smoother(S, B; alpha) -> alpha * (S \ B), B is N x ncols column-major, result in Y.
  * src/smoother.jl:6-18,30-46,56-58,69-81.  Host pointers. */

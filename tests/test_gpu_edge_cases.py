@@ -131,3 +131,29 @@ def test_multi_column_apply_and_empty(oracle, mg):
     assert rel(mg.apply_smoother(Sg, B, 0.7), o.apply_smoother(So, B, 0.7)) < TOL
     Y0 = mg.apply_smoother(Sg, np.zeros((A.shape[0], 0)))
     assert Y0.shape == (A.shape[0], 0)
+
+
+def test_blockdiagonal_container(oracle, mg):
+    """tests/blockdiagonal_test.jl through the device path: BlockDiagonal * x / * B and
+    lu(BlockDiagonal) \\ x / \\ B against the dense equivalents (the reference prints five norms
+    ~1e-16; the sparse-operand variants are set-up code and stay on the oracle side)."""
+    o = oracle
+    rng = np.random.default_rng(0)
+    blocks = [rng.random((3, 3)) + 3 * np.eye(3) for _ in range(50)]
+    A = mg.BlockDiagonal(blocks)
+    Ao = o.BlockDiagonal([b.copy() for b in blocks])
+    A2 = A.todense()
+    x = rng.standard_normal(150)
+    B = rng.standard_normal((150, 4))
+    assert rel(A @ x, A2 @ x) < 1e-14 and rel(A @ B, A2 @ B) < 1e-14
+    assert rel(A @ x, Ao.mul_dense(x)) < 1e-14
+    ALU = A.lu()
+    assert rel(ALU.solve(x), np.linalg.solve(A2, x)) < 1e-13
+    assert rel(ALU.solve(B), Ao.lu().solve_dense(B)) < 1e-13
+    assert np.array_equal(A.mBlockInds, Ao.mBlockInds) and A.shape == (150, 150)
+    with pytest.raises(mg.ArgumentError):
+        mg.BlockDiagonal([np.eye(2), np.eye(3)])
+    with pytest.raises(mg.DimensionMismatch):
+        A @ np.zeros(149)
+    with pytest.raises(mg.SingularException):
+        mg.BlockDiagonal([np.eye(2), np.zeros((2, 2))]).lu()
