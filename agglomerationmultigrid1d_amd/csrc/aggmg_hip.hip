@@ -10,12 +10,15 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "kernels.hpp"
@@ -147,6 +150,42 @@ struct aggmg_hier {
   std::vector<double> h_coarse;
   double last_coarse_ms = 0.0;
 };
+
+// ---------------------------------------------------------------------------------------------
+// host-side parallel loop for the O(n) set-up passes (block extraction / inversion, format
+// conversion, cyclic-reduction factorisation).  Plain std::thread: no OpenMP runtime is pulled
+// into a process that already hosts numpy's and torch's.
+// ---------------------------------------------------------------------------------------------
+static int setup_threads() {
+  static int n = [] {
+    const char* e = std::getenv("AGGMG_SETUP_THREADS");
+    int v = e ? std::atoi(e) : 0;
+    if (v <= 0) {
+      v = (int)std::thread::hardware_concurrency();
+      if (const char* o = std::getenv("OMP_NUM_THREADS")) v = std::min(v, std::max(1, std::atoi(o)));
+      v = std::min(v, 16);
+    }
+    return std::max(1, v);
+  }();
+  return n;
+}
+
+template <typename F>
+static void parallel_for(int64_t n, F&& body) {  // body(begin, end)
+  const int nt = (int)std::min<int64_t>(setup_threads(), std::max<int64_t>(1, n / 4096));
+  if (nt <= 1) {
+    body((int64_t)0, n);
+    return;
+  }
+  std::vector<std::thread> th;
+  const int64_t chunk = (n + nt - 1) / nt;
+  for (int t = 0; t < nt; ++t) {
+    const int64_t b = t * chunk, e = std::min(n, b + chunk);
+    if (b >= e) break;
+    th.emplace_back([&body, b, e] { body(b, e); });
+  }
+  for (auto& t : th) t.join();
+}
 
 // ---------------------------------------------------------------------------------------------
 // error helpers
@@ -575,20 +614,22 @@ static int build_btd(aggmg_ctx* ctx, aggmg_smoother* sm, const std::vector<doubl
       if (h.colind[p] < lo || h.colind[p] >= hi) return AGGMG_OK;  // not block-tridiagonal
   }
   std::vector<double> dblk((size_t)N * m, 0.0), sub((size_t)N * m, 0.0), sup((size_t)N * m, 0.0);
-  for (int64_t r = 0; r < N; ++r) {
-    const int64_t e = r / m;
-    for (int32_t p = h.rowptr[r]; p < h.rowptr[r + 1]; ++p) {
-      const int64_t c = h.colind[p];
-      const int64_t ce = c / m;
-      const int j = (int)(c - ce * m);
-      if (ce == e)
-        dblk[r * m + j] = h.vals[p];
-      else if (ce == e - 1)
-        sub[r * m + j] = h.vals[p];
-      else
-        sup[r * m + j] = h.vals[p];
+  parallel_for(N, [&](int64_t rb, int64_t re) {
+    for (int64_t r = rb; r < re; ++r) {
+      const int64_t e = r / m;
+      for (int32_t p = h.rowptr[r]; p < h.rowptr[r + 1]; ++p) {
+        const int64_t c = h.colind[p];
+        const int64_t ce = c / m;
+        const int j = (int)(c - ce * m);
+        if (ce == e)
+          dblk[r * m + j] = h.vals[p];
+        else if (ce == e - 1)
+          sub[r * m + j] = h.vals[p];
+        else
+          sup[r * m + j] = h.vals[p];
+      }
     }
-  }
+  });
   // compressed pattern: Sub_e non-zero in one common column, Sup_e in one common row
   int c_sub = -1, r_sup = -1;
   bool cmp = m >= 2;
@@ -622,31 +663,35 @@ static int build_btd(aggmg_ctx* ctx, aggmg_smoother* sm, const std::vector<doubl
   if (cmp) {
     std::vector<double> scol(N), pcol(N), qrow((size_t)ne * m);
     for (int64_t r = 0; r < N; ++r) scol[r] = sub[r * m + c_sub];
-    for (int64_t e = 0; e < ne; ++e) {
-      for (int j = 0; j < m; ++j) qrow[e * m + j] = sup[(e * m + r_sup) * m + j];
-      for (int i = 0; i < m; ++i) {
-        double acc = 0.0;
-        for (int j = 0; j < m; ++j) acc += binv_all[(e * m + i) * m + j] * scol[e * m + j];
-        pcol[e * m + i] = acc;
+    parallel_for(ne, [&](int64_t eb, int64_t ee) {
+      for (int64_t e = eb; e < ee; ++e) {
+        for (int j = 0; j < m; ++j) qrow[e * m + j] = sup[(e * m + r_sup) * m + j];
+        for (int i = 0; i < m; ++i) {
+          double acc = 0.0;
+          for (int j = 0; j < m; ++j) acc += binv_all[(e * m + i) * m + j] * scol[e * m + j];
+          pcol[e * m + i] = acc;
+        }
       }
-    }
+    });
     if (st == AGGMG_OK) st = dev_upload(ctx, scol, &b->scol);
     if (st == AGGMG_OK) st = dev_upload(ctx, pcol, &b->pcol);
     if (st == AGGMG_OK) st = dev_upload(ctx, qrow, &b->qrow);
   } else {
     std::vector<double> P((size_t)N * m), Q((size_t)N * m);
-    for (int64_t e = 0; e < ne; ++e)
-      for (int i = 0; i < m; ++i)
-        for (int j = 0; j < m; ++j) {
-          double p = 0.0, q = 0.0;
-          for (int k = 0; k < m; ++k) {
-            const double bi = binv_all[(e * m + i) * m + k];
-            p += bi * sub[(e * m + k) * m + j];
-            q += bi * sup[(e * m + k) * m + j];
+    parallel_for(ne, [&](int64_t eb, int64_t ee) {
+      for (int64_t e = eb; e < ee; ++e)
+        for (int i = 0; i < m; ++i)
+          for (int j = 0; j < m; ++j) {
+            double p = 0.0, q = 0.0;
+            for (int k = 0; k < m; ++k) {
+              const double bi = binv_all[(e * m + i) * m + k];
+              p += bi * sub[(e * m + k) * m + j];
+              q += bi * sup[(e * m + k) * m + j];
+            }
+            P[(e * m + i) * m + j] = p;
+            Q[(e * m + i) * m + j] = q;
           }
-          P[(e * m + i) * m + j] = p;
-          Q[(e * m + i) * m + j] = q;
-        }
+    });
     if (st == AGGMG_OK) st = dev_upload(ctx, sub, &b->sub);
     if (st == AGGMG_OK) st = dev_upload(ctx, sup, &b->sup);
     if (st == AGGMG_OK) st = dev_upload(ctx, P, &b->P);
@@ -693,16 +738,25 @@ extern "C" int aggmg_blockjacobi_setup(aggmg_ctx* ctx, aggmg_op* A, int64_t m, i
   sm->overlapping = overlapping;
   sm->contiguous = contiguous;
 
-  std::vector<double> binv((size_t)nb * m * m), blk((size_t)m * m), inv;
-  std::vector<int> piv;
-  for (int64_t k = 0; k < nb; ++k) {
-    for (int64_t i = 0; i < m; ++i)
-      for (int64_t j = 0; j < m; ++j) blk[i * m + j] = host_entry(A->host, inds[k * m + i], inds[k * m + j]);
-    if (!invert_block((int)m, blk, inv, piv))
-      return fail(ctx, AGGMG_ERR_SINGULAR,
-                  "aggmg_blockjacobi_setup: singular block " + std::to_string(k + 1) + " (SingularException)");
-    std::copy(inv.begin(), inv.end(), binv.begin() + k * m * m);
-  }
+  std::vector<double> binv((size_t)nb * m * m);
+  std::atomic<int64_t> singular{-1};
+  parallel_for(nb, [&](int64_t kb, int64_t ke) {
+    std::vector<double> blk((size_t)m * m), inv;
+    std::vector<int> piv;
+    for (int64_t k = kb; k < ke; ++k) {
+      for (int64_t i = 0; i < m; ++i)
+        for (int64_t j = 0; j < m; ++j) blk[i * m + j] = host_entry(A->host, inds[k * m + i], inds[k * m + j]);
+      if (!invert_block((int)m, blk, inv, piv)) {
+        int64_t expect = -1;
+        singular.compare_exchange_strong(expect, k);
+        return;
+      }
+      std::copy(inv.begin(), inv.end(), binv.begin() + k * m * m);
+    }
+  });
+  if (singular.load() >= 0)
+    return fail(ctx, AGGMG_ERR_SINGULAR,
+                "aggmg_blockjacobi_setup: singular block " + std::to_string(singular.load() + 1) + " (SingularException)");
   CHECK(dev_upload(ctx, binv, &sm->binv));
   CHECK(dev_upload(ctx, inds, &sm->inds));
   if (sm->kind == 2) CHECK(dev_upload(ctx, counts, &sm->counts));
@@ -1397,50 +1451,69 @@ static int cr_setup(aggmg_ctx* ctx, const HostCsr& h, int64_t N, int hint_m, CrD
     std::vector<int32_t> perm((size_t)no * m);
     std::vector<double> Za((size_t)no * mm2), Zc((size_t)no * mm2);  // b_odd \ a_odd, b_odd \ c_odd
     std::vector<double> a2((size_t)ne * mm2, 0.0), b2((size_t)ne * mm2, 0.0), c2((size_t)ne * mm2, 0.0);
-    for (int64_t j = 0; j < no; ++j) {
-      const int64_t i = 2 * j + 1;
-      if (!pivot_cond(&b[i * mm2]) || !lu_perm(m, &b[i * mm2], &lu[j * mm2], &perm[j * m])) {
-        free_cr(cr);
-        return AGGMG_OK;
+    std::atomic<int> bad{0};
+    std::vector<double> conds((size_t)setup_threads() + 1, 0.0);
+    std::atomic<int> slot{0};
+    parallel_for(no, [&](int64_t jb, int64_t je) {
+      std::vector<double> tb(mm2), tinv;
+      std::vector<int> tp;
+      double lc = 0.0;
+      for (int64_t j = jb; j < je; ++j) {
+        const int64_t i = 2 * j + 1;
+        std::copy(&b[i * mm2], &b[i * mm2] + mm2, tb.begin());  // condition monitor (explicit inverse)
+        const double nb1 = norm1(m, tb.data());
+        if (!invert_block(m, tb, tinv, tp) || !lu_perm(m, &b[i * mm2], &lu[j * mm2], &perm[j * m])) {
+          bad.store(1);
+          return;
+        }
+        lc = std::max(lc, nb1 * norm1(m, tinv.data()));
+        lu_perm_solve(m, &lu[j * mm2], &perm[j * m], &a[i * mm2], m, &Za[j * mm2]);
+        lu_perm_solve(m, &lu[j * mm2], &perm[j * m], &c[i * mm2], m, &Zc[j * mm2]);
       }
-      lu_perm_solve(m, &lu[j * mm2], &perm[j * m], &a[i * mm2], m, &Za[j * mm2]);
-      lu_perm_solve(m, &lu[j * mm2], &perm[j * m], &c[i * mm2], m, &Zc[j * mm2]);
+      conds[slot.fetch_add(1) % conds.size()] = lc;  // one slot per worker chunk
+    });
+    if (bad.load()) {
+      free_cr(cr);
+      return AGGMG_OK;
     }
-    for (int64_t j = 0; j < ne; ++j) {
-      const int64_t i = 2 * j;
-      double* B2 = &b2[j * mm2];
-      std::copy(b.begin() + i * mm2, b.begin() + (i + 1) * mm2, B2);
-      if (j > 0) {  // eliminate x_{i-1}: -a_i (b_{i-1} \ [a_{i-1} | c_{i-1}])
-        const double* A = &a[i * mm2];
-        const double* ZA = &Za[(j - 1) * mm2];
-        const double* ZC = &Zc[(j - 1) * mm2];
-        for (int r = 0; r < m; ++r)
-          for (int q = 0; q < m; ++q) {
-            double s1 = 0.0, s2 = 0.0;
-            for (int k = 0; k < m; ++k) {
-              s1 += A[r * m + k] * ZA[k * m + q];
-              s2 += A[r * m + k] * ZC[k * m + q];
+    for (double v : conds) cond = std::max(cond, v);
+    parallel_for(ne, [&](int64_t jb, int64_t je) {
+      for (int64_t j = jb; j < je; ++j) {
+        const int64_t i = 2 * j;
+        double* B2 = &b2[j * mm2];
+        std::copy(b.begin() + i * mm2, b.begin() + (i + 1) * mm2, B2);
+        if (j > 0) {  // eliminate x_{i-1}: -a_i (b_{i-1} \ [a_{i-1} | c_{i-1}])
+          const double* A = &a[i * mm2];
+          const double* ZA = &Za[(j - 1) * mm2];
+          const double* ZC = &Zc[(j - 1) * mm2];
+          for (int r = 0; r < m; ++r)
+            for (int q = 0; q < m; ++q) {
+              double s1 = 0.0, s2 = 0.0;
+              for (int k = 0; k < m; ++k) {
+                s1 += A[r * m + k] * ZA[k * m + q];
+                s2 += A[r * m + k] * ZC[k * m + q];
+              }
+              a2[j * mm2 + r * m + q] = -s1;
+              B2[r * m + q] -= s2;
             }
-            a2[j * mm2 + r * m + q] = -s1;
-            B2[r * m + q] -= s2;
-          }
-      }
-      if (i + 1 < n) {  // eliminate x_{i+1}: -c_i (b_{i+1} \ [a_{i+1} | c_{i+1}])
-        const double* C = &c[i * mm2];
-        const double* ZA = &Za[j * mm2];
-        const double* ZC = &Zc[j * mm2];
-        for (int r = 0; r < m; ++r)
-          for (int q = 0; q < m; ++q) {
-            double s1 = 0.0, s2 = 0.0;
-            for (int k = 0; k < m; ++k) {
-              s1 += C[r * m + k] * ZA[k * m + q];
-              s2 += C[r * m + k] * ZC[k * m + q];
+        }
+        if (i + 1 < n) {  // eliminate x_{i+1}: -c_i (b_{i+1} \ [a_{i+1} | c_{i+1}])
+          const double* C = &c[i * mm2];
+          const double* ZA = &Za[j * mm2];
+          const double* ZC = &Zc[j * mm2];
+          for (int r = 0; r < m; ++r)
+            for (int q = 0; q < m; ++q) {
+              double s1 = 0.0, s2 = 0.0;
+              for (int k = 0; k < m; ++k) {
+                s1 += C[r * m + k] * ZA[k * m + q];
+                s2 += C[r * m + k] * ZC[k * m + q];
+              }
+              B2[r * m + q] -= s1;
+              c2[j * mm2 + r * m + q] = -s2;
             }
-            B2[r * m + q] -= s1;
-            c2[j * mm2 + r * m + q] = -s2;
-          }
+        }
       }
-    }
+    });
     CrLevel L;
     L.n = n;
     L.n_even = ne;
@@ -1696,17 +1769,20 @@ static int build_transfer(aggmg_ctx* ctx, const aggmg_op* L, const aggmg_op* A, 
     CHECK(dev_upload(ctx, lf, &out->lf));
     if (A && A->host_valid) {
       // ld[(e,j)][c] = sum_i L[(e,i)][c] * D_e[i][j]  so that  L' r = sum_rows ld * (B^{-1} r)
-      std::vector<double> ld((size_t)Nf * mc, 0.0), D((size_t)mf * mf);
-      for (int64_t e = 0; e < nef; ++e) {
-        for (int i = 0; i < mf; ++i)
-          for (int j = 0; j < mf; ++j) D[i * mf + j] = host_entry(A->host, e * mf + i, e * mf + j);
-        for (int j = 0; j < mf; ++j)
-          for (int c = 0; c < mc; ++c) {
-            double acc = 0.0;
-            for (int i = 0; i < mf; ++i) acc += lf[(e * mf + i) * mc + c] * D[i * mf + j];
-            ld[(e * mf + j) * mc + c] = acc;
-          }
-      }
+      std::vector<double> ld((size_t)Nf * mc, 0.0);
+      parallel_for(nef, [&](int64_t eb, int64_t ee) {
+        std::vector<double> D((size_t)mf * mf);
+        for (int64_t e = eb; e < ee; ++e) {
+          for (int i = 0; i < mf; ++i)
+            for (int j = 0; j < mf; ++j) D[i * mf + j] = host_entry(A->host, e * mf + i, e * mf + j);
+          for (int j = 0; j < mf; ++j)
+            for (int c = 0; c < mc; ++c) {
+              double acc = 0.0;
+              for (int i = 0; i < mf; ++i) acc += lf[(e * mf + i) * mc + c] * D[i * mf + j];
+              ld[(e * mf + j) * mc + c] = acc;
+            }
+        }
+      });
       CHECK(dev_upload(ctx, ld, &out->ld));
     }
     out->mc = mc;
