@@ -462,3 +462,187 @@ def build_device_hierarchy(U, ctx=None, keep_host=False):
     Ls = [DeviceOperator(U.interpolation_csc(k), _lib.OP_TRANSFER, ctx) for k in range(n - 1)]
     H = MeshHierarchy([U.descriptor(k) for k in range(n)], ops, sms, Ls, ctx=ctx, keep_host=keep_host)
     return H
+
+
+# ------------------------------------------------------------------------------------------
+# CG p-chain + DG p=0 coarsest level (the realisable shape of BASELINE config 5 / config 1,
+# tests/dg_cg_heirarchy_test.jl with nCG levels and nDG = 1)
+# ------------------------------------------------------------------------------------------
+class UniformCgDgHierarchy:
+    """CgMesh(p) for p in `ps` (p-coarsening by nodal injection, Galerkin operators, point-Jacobi)
+    followed by one re-discretised DgMesh(p=0) level reached through the lumped-mass L2 transfer
+    (interpFlag = 1), as MeshHierarchy(mMeshes, mesh, bdConds, A; nCG, nDG=1, CDir) builds it
+    (src/mesh_heirarchy.jl:30-73).  O(n) / vectorised:
+
+        cg_stiffness_and_rhs      src/cg_mesh.jl:125-185
+        cg_cg_interpolation       src/interpolation.jl:5-55
+        dg_cg_interpolation(...,1) src/interpolation.jl:145-220
+        L'*A*L                    src/mesh_heirarchy.jl:57
+
+    CG numbering: vertices 1..n+1, then the p-1 interior nodes of every element in element order
+    (src/cg_mesh.jl:37-45,59-65); node indices here are 0-based."""
+
+    def __init__(self, n, ps=(4, 2, 1), CDir=None, xin=0.0, xout=1.0, bc=None, func=np.cos):
+        self.n, self.ps = n, tuple(ps)
+        self.CDir = 1000.0 * n if CDir is None else float(CDir)
+        self.bc = bc or (('neu', -math.sin(xin)), ('dir', math.cos(xout)))
+        self.func = func
+        i = np.arange(n + 1, dtype=np.float64)
+        self.xv = xin + (i / n) * (xout - xin)
+        self.xv[0] = xin
+        self.h = self.xv[1:] - self.xv[:-1]
+        self.xc = (self.xv[:-1] + self.xv[1:]) / 2.0
+        self.J = self.h / 2.0
+        self.refs = [RefElement(p) for p in self.ps]
+        self.A, self.L = [], []
+        A0, self.b = self._cg_stiffness_and_rhs(self.ps[0], self.refs[0])
+        self.A.append(A0)
+        for k in range(1, len(self.ps)):
+            L = self._cg_cg(self.ps[k], self.ps[k - 1], self.refs[k], self.refs[k - 1])
+            self.L.append(L)
+            self.A.append((L.T @ self.A[-1] @ L).tocsc())
+        # DG p = 0 level: re-discretised operator, lumped-mass transfer from the last CG level
+        dg0 = UniformDgAggHierarchy(n, p=0, pAgg=0, ratios=(), CDir=self.CDir, xin=xin, xout=xout, bc=self.bc,
+                                    func=func)
+        self.L.append(self._dg0_cg(self.ps[-1], self.refs[-1]))
+        self.A.append(dg0.stiffness_csc(0))
+        for M in self.A + self.L:
+            M.sort_indices()
+
+    def nodes(self, p):
+        """(n, p+1) 0-based node numbers per element in local order [left, right, interior...]"""
+        n = self.n
+        k = np.arange(n, dtype=np.int64)
+        out = np.empty((n, p + 1), dtype=np.int64)
+        out[:, 0], out[:, 1] = k, k + 1
+        for j in range(p - 1):
+            out[:, 2 + j] = (n + 1) + k * (p - 1) + j
+        return out
+
+    def num_nodes(self, p):
+        return self.n * p + 1
+
+    def _dir_nodes(self):
+        d = []
+        if self.bc[0][0] == 'dir':
+            d.append((0, self.bc[0][1]))
+        if self.bc[1][0] == 'dir':
+            d.append((self.n, self.bc[1][1]))
+        return d
+
+    def _cg_stiffness_and_rhs(self, p, ref):
+        n = self.n
+        nd = self.nodes(p)
+        N = self.num_nodes(p)
+        m = p + 1
+        K = np.zeros((n, m, m))
+        invJ = 1.0 / self.J
+        for l in range(len(ref.gw)):          # temp[i,j] += (1/J) * w_l * dphi_i * dphi_j, in loop order
+            K += ((invJ * ref.gw[l])[:, None] * ref.dphi[l][None, :])[:, :, None] * ref.dphi[l][None, None, :]
+        xq = self.xc[:, None] + self.h[:, None] / 2.0 * ref.gq[None, :]
+        fq = self.func(xq)
+        fe = np.zeros((n, m))
+        for l in range(len(ref.gw)):
+            fe += (self.J[:, None] * ref.gw[l]) * ref.phi[l][None, :] * fq[:, l][:, None]
+        f = np.zeros(N)
+        np.add.at(f, nd.reshape(-1), fe.reshape(-1))
+        (lk, lv), (rk, rv) = self.bc
+        if lk == 'neu':
+            f[0] += -lv
+        if rk == 'neu':
+            f[n] += rv
+        rows = np.repeat(nd, m, axis=1).reshape(-1)           # nd[k,i] for (i,j)
+        cols = np.tile(nd, (1, m)).reshape(-1)                # nd[k,j]
+        vals = K.reshape(-1)
+        dirs = self._dir_nodes()
+        if dirs:
+            # f += -A[:, dir] * dirVals on the unconstrained matrix, then the strong rows / columns
+            for node, val in dirs:
+                sel = cols == node
+                np.add.at(f, rows[sel], -vals[sel] * val)
+            for node, val in dirs:
+                f[node] = val
+            dn = np.array([d[0] for d in dirs])
+            keep = ~(np.isin(rows, dn) | np.isin(cols, dn))
+            rows = np.concatenate([rows[keep], dn])
+            cols = np.concatenate([cols[keep], dn])
+            vals = np.concatenate([vals[keep], np.ones(len(dn))])
+        A = sp.coo_matrix((vals, (rows, cols)), shape=(N, N)).tocsc()
+        A.sum_duplicates()
+        return A, f
+
+    def _cg_cg(self, p_lo, p_hi, ref_lo, ref_hi):
+        """prolongation CG(p_lo) -> CG(p_hi): interior fine nodes x all coarse nodes of the element,
+        plus the vertex identity pairs (the last element to touch a vertex writes its value)."""
+        lowVal = np.array([[np.dot(ref_lo.coeff[:, j], legendre_vandermonde(ref_hi.nodes, p_lo)[i])
+                            for j in range(p_lo + 1)] for i in range(p_hi + 1)])
+        n = self.n
+        hi, lo = self.nodes(p_hi), self.nodes(p_lo)
+        rows, cols, vals = [], [], []
+        if p_hi >= 2:
+            r = np.repeat(hi[:, 2:], p_lo + 1, axis=1).reshape(-1)
+            c = np.tile(lo, (1, p_hi - 1)).reshape(-1)
+            v = np.tile(lowVal[2:, :].reshape(-1), n)
+            rows.append(r), cols.append(c), vals.append(v)
+        vtx = np.arange(n + 1, dtype=np.int64)
+        vv = np.full(n + 1, lowVal[0, 0])
+        vv[n] = lowVal[1, 1]
+        rows.append(vtx), cols.append(vtx), vals.append(vv)
+        L = sp.coo_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))),
+                          shape=(self.num_nodes(p_hi), self.num_nodes(p_lo))).tocsc()
+        return L
+
+    def _dg0_cg(self, p_hi, ref_hi):
+        """dg_cg_interpolation(DgMesh(p=0), CgMesh(p_hi), mesh, 1): N row-scaled by the lumped mass"""
+        n = self.n
+        nd = self.nodes(p_hi)
+        m = p_hi + 1
+        gq, gw = gauss_quad(0 + p_hi)
+        hiV = np.array([[np.dot(ref_hi.coeff[:, i], legendre_vandermonde(gq, p_hi)[l]) for i in range(m)]
+                        for l in range(len(gq))])
+        T = np.zeros((n, m))
+        for l in range(len(gq)):               # temp[i,0] += J * w_l * hiV[l,i] * 1.0
+            T += (self.J[:, None] * gw[l]) * hiV[l][None, :] * 1.0
+        rows = nd.reshape(-1)
+        cols = np.repeat(np.arange(n, dtype=np.int64), m)
+        Nm = sp.coo_matrix((T.reshape(-1), (rows, cols)), shape=(self.num_nodes(p_hi), n)).tocsc()
+        # lumped mass: row sums of the CG mass matrix (ascending column order within the row)
+        Me = self.J[:, None, None] * ref_hi.mass[None, :, :]
+        Mr = np.repeat(nd, m, axis=1).reshape(-1)
+        Mc = np.tile(nd, (1, m)).reshape(-1)
+        Mm = sp.coo_matrix((Me.reshape(-1), (Mr, Mc)), shape=(self.num_nodes(p_hi),) * 2).tocsr()
+        Mm.sum_duplicates()
+        Mm.sort_indices()
+        lumped = np.add.reduceat(Mm.data, Mm.indptr[:-1])
+        Nm.data = Nm.data / lumped[Nm.indices]
+        return Nm
+
+    @property
+    def nlevels(self):
+        return len(self.A)
+
+    def rhs(self):
+        return self.b
+
+    def algorithmic_bytes(self, nPre=3, nPost=3):
+        out = []
+        for k in range(self.nlevels - 1):
+            N, nnzA = self.A[k].shape[0], self.A[k].nnz
+            Nc, nnzL = self.L[k].shape[1], self.L[k].nnz
+            S = 12 * nnzA + 4 * (N + 1) + 8 * N + 24 * N          # point-Jacobi sweep
+            R = 12 * nnzA + 4 * (N + 1) + 24 * N
+            Td = 12 * nnzL + 4 * (Nc + 1) + 8 * N + 8 * Nc
+            Tu = 12 * nnzL + 4 * (N + 1) + 8 * Nc + 16 * N
+            out.append(dict(N=N, nnzA=nnzA, nnzL=nnzL, sweep=S, residual=R, restrict=Td, prolong=Tu,
+                            vcycle=(nPre + nPost) * S + R + Td + Tu))
+        return out
+
+
+def build_device_cg_hierarchy(U, ctx=None, keep_host=False):
+    """UniformCgDgHierarchy -> product MeshHierarchy (CG levels :jac, src/mesh_heirarchy.jl:51,58)"""
+    from . import _lib
+    from .api import DeviceOperator, JacobiSmoother, MeshHierarchy
+    ops = [DeviceOperator(A, _lib.OP_STIFFNESS, ctx) for A in U.A]
+    sms = [JacobiSmoother(ops[k], ctx) for k in range(U.nlevels - 1)]
+    Ls = [DeviceOperator(L, _lib.OP_TRANSFER, ctx) for L in U.L]
+    return MeshHierarchy(None, ops, sms, Ls, ctx=ctx, keep_host=keep_host)

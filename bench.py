@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--p", type=int, default=3)
     ap.add_argument("--cpu-log2-elems", type=int, default=20, help="size of the CPU-baseline sample")
     ap.add_argument("--cpu-cycles", type=int, default=4)
+    ap.add_argument("--cg-log2-elems", type=int, default=20,
+                    help="N = 1 only: extra V-cycle on the CG p=4,2,1 -> DG p=0 hierarchy (config 5 shape) at 2^E "
+                         "elements, generic CSR kernels; 0 = off")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-smoother-bench", action="store_true")
     return ap.parse_args()
@@ -172,6 +175,38 @@ def smoother_bench(mg, ctx, args, alpha):
     out["generic_csr_residual"] = {"us_per_residual": 1e6 * dt / 100, "algorithmic_GBs": R_bytes * 100 / dt / 1e9,
                                    "frac_of_8TBs": R_bytes * 100 / dt / 1e9 / HBM_PEAK_GBS}
     return out
+
+
+def cg_bench(mg, ctx, args, nPre, nPost, alpha):
+    """BASELINE config 5's realisable shape on ONE GPU: CG p=4 -> 2 -> 1 (point-Jacobi,
+    Galerkin operators) -> DG p=0, V(3,3); every level runs the generic CSR kernels."""
+    from agglomerationmultigrid1d_amd.uniform import UniformCgDgHierarchy, build_device_cg_hierarchy
+    n = 2 ** args.cg_log2_elems
+    t0 = time.perf_counter()
+    U = UniformCgDgHierarchy(n, ps=(4, 2, 1))
+    H = build_device_cg_hierarchy(U, ctx)
+    N = U.A[0].shape[0]
+    bm = U.algorithmic_bytes(nPre, nPost)
+    b = ctx.to_device(U.rhs())
+    xa, xb = ctx.to_device(np.zeros(N)), ctx.alloc(N)
+    t_setup = time.perf_counter() - t0
+    steps = max(5, args.steps // 2)
+    for _ in range(2):
+        H.vcycle_dev(xa, b, xb, nPre, nPost, alpha)
+        xa, xb = xb, xa
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        H.vcycle_dev(xa, b, xb, nPre, nPost, alpha)
+        xa, xb = xb, xa
+    ctx.synchronize()
+    dt = time.perf_counter() - t0
+    vb = sum(l["vcycle"] for l in bm)
+    return {"workload": f"CG n=2^{args.cg_log2_elems} p=4 -> 2 -> 1 -> DG p=0, point-Jacobi, V(3,3), N_fine={N}, "
+                        f"nnz(A_1)={U.A[0].nnz}",
+            "value": N * (nPre + nPost) * steps / dt, "unit": "DoF-updates/s", "ms_per_step": 1e3 * dt / steps,
+            "achieved_algorithmic_GBs_vcycle": vb * steps / dt / 1e9, "frac_of_8TBs": vb * steps / dt / 1e9 / HBM_PEAK_GBS,
+            "coarse_solve": H.coarse_info(), "setup_s": t_setup}
 
 
 def main():
@@ -310,6 +345,8 @@ def main():
             "value": R2["N"] * (nPre + nPost) * args.steps / R2["dt"], "unit": "DoF-updates/s",
             "ms_per_step": 1e3 * R2["dt"] / args.steps,
             "vcycles_loop_ms_per_cycle": 1e3 * R2["dt_loop"] / args.steps, "setup_s": R2["t_setup"]}
+    if args.cg_log2_elems:
+        out["config5_shape_1gpu"] = cg_bench(mg, ctx, args, nPre, nPost, alpha)
     if not args.no_smoother_bench:
         out["smoother_only"] = smoother_bench(mg, ctx, args, alpha)
     if not args.no_cpu_baseline:

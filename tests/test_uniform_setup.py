@@ -111,3 +111,36 @@ def test_algorithmic_bytes_model():
         UniformDgAggHierarchy(16, pAgg=2)
     with pytest.raises(ValueError):   # the reference reads baseMesh...mNodesX[2]: needs p >= 1
         UniformDgAggHierarchy(16, p=0, pAgg=0, ratios=(2,))
+
+
+@pytest.mark.parametrize("n,ps", [(16, (4, 2, 1)), (32, (1,)), (8, (8, 4, 2, 1)), (24, (3, 1))])
+def test_cg_dg0_hierarchy_matches_oracle(oracle, n, ps):
+    """CG p-chain + DG p=0 (config 1 / config 5 shapes): operators to round-off, transfer index
+    maps bit for bit."""
+    from agglomerationmultigrid1d_amd.uniform import UniformCgDgHierarchy
+    o = oracle
+    U = UniformCgDgHierarchy(n, ps=ps)
+    H, b = o.build_cg_hierarchy(n, ps=ps, nDG=1, pDG=0)
+    assert U.nlevels == len(H.mStiffness)
+    assert np.allclose(U.rhs(), b, rtol=1e-13, atol=1e-13 * np.abs(b).max())
+    for k in range(U.nlevels):
+        assert relmax(U.A[k], H.mStiffness[k]) < 1e-12
+        thr = 1e-12 * abs(H.mStiffness[k]).max()
+        assert same_maps(drop_small(U.A[k], thr), drop_small(H.mStiffness[k], thr)), k
+    for k in range(U.nlevels - 1):
+        assert same_maps(U.L[k], H.mInterpolation[k]), f"transfer index map differs at level {k}"
+        assert relmax(U.L[k], H.mInterpolation[k]) < 1e-13
+
+
+def test_cg_other_bcs(oracle):
+    from agglomerationmultigrid1d_amd.uniform import UniformCgDgHierarchy
+    o = oracle
+    n = 12
+    bc = [('dir', 0.25), ('dir', -1.0)]
+    U = UniformCgDgHierarchy(n, ps=(2,), bc=tuple(bc), func=np.sin)
+    mesh = o.create_uniform_mesh(n, 0.0, 1.0)
+    bd = o.set_boundary(mesh, 0.0, 1.0, bc)
+    cg = o.CgMesh(mesh, 2)
+    A, b = o.cg_stiffness_and_rhs(cg, mesh, math.sin, bd)
+    assert relmax(U.A[0], A) < 1e-13 and same_maps(U.A[0], A)
+    assert np.allclose(U.rhs(), b, rtol=1e-13, atol=1e-14)
