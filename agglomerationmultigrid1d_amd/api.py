@@ -93,7 +93,9 @@ class Context:
         return v
 
     def profile_enable(self, on=True):
-        self.check(self.lib.aggmg_profile_enable(self.handle, 1 if on else 0))
+        """True / 1: HIP events around every launch; 2: only the fine-level fused-down launch;
+        False / 0: off"""
+        self.check(self.lib.aggmg_profile_enable(self.handle, int(on)))
 
     def profile_collect(self):
         """-> {(kind_name, level): (total_ms, count)} for every tag seen since the last call."""

@@ -40,7 +40,7 @@ struct aggmg_ctx {
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
   std::string err;
-  bool profiling = false;
+  int profiling = 0;  // 0 off, 1 every launch, 2 only the fine-level fused-down launch (dominant kernel)
   std::vector<ProfEvent> prof;
   std::vector<hipEvent_t> ev_pool;
   // scratch vectors for ping-pong / temporaries, grown on demand
@@ -247,12 +247,13 @@ struct ProfScope {
   int idx = -1;
   ProfScope(aggmg_ctx* c, int kind, int level) : ctx(c) {
     if (!ctx->profiling) return;
+    if (ctx->profiling == 2 && !(kind == AGGMG_KIND_FUSED_DOWN && level == 0)) return;
     ProfEvent pe;
     for (hipEvent_t* e : {&pe.a, &pe.b}) {
       if (!ctx->ev_pool.empty()) {
         *e = ctx->ev_pool.back();
         ctx->ev_pool.pop_back();
-      } else if (hipEventCreate(e) != hipSuccess) {
+      } else if (hipEventCreateWithFlags(e, hipEventDisableSystemFence) != hipSuccess) {
         return;
       }
     }
@@ -365,7 +366,7 @@ extern "C" int aggmg_memcpy_d2h(aggmg_ctx* ctx, void* dst, const void* src, int6
 
 extern "C" int aggmg_profile_enable(aggmg_ctx* ctx, int on) {
   if (!ctx) return AGGMG_ERR_ARGUMENT;
-  ctx->profiling = on != 0;
+  ctx->profiling = on < 0 ? 0 : (on > 2 ? 1 : on);
   return AGGMG_OK;
 }
 

@@ -200,6 +200,9 @@ int aggmg_hier_last_coarse_ms(aggmg_ctx* ctx, const aggmg_hier* h, double* ms);
 #define AGGMG_KIND_BLOCK_APPLY 7 /* generic gather block apply */
 #define AGGMG_KIND_COARSE 8      /* device coarsest solve (all its launches) */
 #define AGGMG_KIND_FUSED_MID 9   /* prolong-add -> nPost + nPre sweeps -> restriction (between cycles) */
+/* on: 0 = off, 1 = every launch, 2 = only the fine-level fused-down launch (the dominant kernel:
+ * one event pair per cycle, so that timing it does not disturb the cycle being timed -- an event pair
+ * costs ~7 us of stream time on MI355X). */
 int aggmg_profile_enable(aggmg_ctx* ctx, int on);
 int aggmg_profile_collect(aggmg_ctx* ctx, double* total_ms, int64_t* counts);
 

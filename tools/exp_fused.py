@@ -38,6 +38,12 @@ xa, xb = u, v
 for _ in range(3):
     H.vcycle_dev(xa, b, xb)
 ctx.synchronize()
+t0 = time.perf_counter()
+for _ in range(20):
+    H.vcycle_dev(xa, b, xb)
+    xa, xb = xb, xa
+ctx.synchronize()
+out["vcycle_noevents_us"] = round(1e6 * (time.perf_counter() - t0) / 20, 1)
 ctx.profile_enable(True)
 t0 = time.perf_counter()
 for _ in range(20):
