@@ -72,9 +72,10 @@ struct BtdDev {
   bool cmp = false;
   int c_sub = 0, r_sup = 0;
   double *binv = nullptr, *dblk = nullptr, *scol = nullptr, *pcol = nullptr, *qrow = nullptr;
+  double* bsym = nullptr;  // packed symmetric inverses (replaces binv + pcol in the kernels) or null
   double *sub = nullptr, *sup = nullptr, *P = nullptr, *Q = nullptr;
   ~BtdDev() {
-    for (double* p : {binv, dblk, scol, pcol, qrow, sub, sup, P, Q})
+    for (double* p : {binv, dblk, scol, pcol, qrow, bsym, sub, sup, P, Q})
       if (p) (void)hipFree(p);
   }
 };
@@ -677,6 +678,40 @@ static int build_btd(aggmg_ctx* ctx, aggmg_smoother* sm, const std::vector<doubl
     if (st == AGGMG_OK) st = dev_upload(ctx, scol, &b->scol);
     if (st == AGGMG_OK) st = dev_upload(ctx, pcol, &b->pcol);
     if (st == AGGMG_OK) st = dev_upload(ctx, qrow, &b->qrow);
+    // symmetric to round-off?  (B_e^{-1} symmetric, and Sub_e[:, c] == Sup_{e-1}[r, :] with c == r)
+    // then the kernels read the packed upper triangle and rebuild pcol from the neighbour's q row
+    const bool grp = (m == 2 || m == 4 || m == 8);
+    if (grp && c_sub == r_sup && !std::getenv("AGGMG_NO_SYM")) {
+      std::atomic<int> asym{0};
+      const double tol = 1e-13;
+      parallel_for(ne, [&](int64_t eb, int64_t ee) {
+        for (int64_t e = eb; e < ee && !asym.load(std::memory_order_relaxed); ++e) {
+          double scale = 0.0, qs = 0.0;
+          for (int q = 0; q < m * m; ++q) scale = std::max(scale, std::fabs(binv_all[e * m * m + q]));
+          for (int i = 0; i < m; ++i)
+            for (int j = i + 1; j < m; ++j)
+              if (std::fabs(binv_all[(e * m + i) * m + j] - binv_all[(e * m + j) * m + i]) > tol * scale) asym.store(1);
+          if (e > 0) {
+            for (int j = 0; j < m; ++j) qs = std::max(qs, std::fabs(qrow[(e - 1) * m + j]));
+            for (int j = 0; j < m; ++j)
+              if (std::fabs(scol[e * m + j] - qrow[(e - 1) * m + j]) > tol * qs) asym.store(1);
+          }
+        }
+      });
+      if (!asym.load()) {
+        const int T = m * (m + 1) / 2;
+        std::vector<double> bsym((size_t)ne * T);
+        parallel_for(ne, [&](int64_t eb, int64_t ee) {
+          for (int64_t e = eb; e < ee; ++e) {
+            int q = 0;
+            for (int i = 0; i < m; ++i)
+              for (int j = i; j < m; ++j)
+                bsym[e * T + q++] = 0.5 * (binv_all[(e * m + i) * m + j] + binv_all[(e * m + j) * m + i]);
+          }
+        });
+        if (st == AGGMG_OK) st = dev_upload(ctx, bsym, &b->bsym);
+      }
+    }
   } else {
     std::vector<double> P((size_t)N * m), Q((size_t)N * m);
     parallel_for(ne, [&](int64_t eb, int64_t ee) {
@@ -898,6 +933,15 @@ static int launch_btd_t(aggmg_ctx* ctx, FusedArgs a, int halo) {
   const int64_t ntiles = (a.lv.ne + owned - 1) / owned;
   if (ntiles == 0) return AGGMG_OK;
   const size_t lds = (size_t)2 * (T::TE + 2) * M * sizeof(double);
+  constexpr bool kGrp = CMP && (M == 2 || M == 4 || M == 8);
+  if constexpr (kGrp) {
+    if (a.lv.bsym) {
+      hipLaunchKernelGGL((btd_fused_kernel<M, CMP, T::NS, true>), dim3((unsigned)ntiles), dim3(kThreads), lds,
+                         ctx->stream, a);
+      HIPCHK(hipGetLastError());
+      return AGGMG_OK;
+    }
+  }
   hipLaunchKernelGGL((btd_fused_kernel<M, CMP, T::NS>), dim3((unsigned)ntiles), dim3(kThreads), lds,
                      ctx->stream, a);
   HIPCHK(hipGetLastError());
@@ -946,7 +990,7 @@ static int btd_tile_elems(const BtdDev& b) {
 static FusedArgs btd_args(const BtdDev& b) {
   FusedArgs a;
   std::memset(&a, 0, sizeof(a));
-  a.lv = BtdLevel{b.binv, b.dblk, b.scol, b.pcol, b.qrow, b.sub, b.sup, b.P, b.Q, b.ne, b.c_sub, b.r_sup};
+  a.lv = BtdLevel{b.binv, b.dblk, b.bsym, b.scol, b.pcol, b.qrow, b.sub, b.sup, b.P, b.Q, b.ne, b.c_sub, b.r_sup};
   return a;
 }
 

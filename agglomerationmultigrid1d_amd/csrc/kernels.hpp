@@ -182,6 +182,11 @@ __global__ __launch_bounds__(kThreads) void axpy_scaled_kernel(int64_t n, const 
 // (B^{-1}D = I is used algebraically; differs from the reference's LU solve at round-off only).
 struct BtdLevel {
   const double *binv, *dblk;
+  // symmetric operators (A = A' to round-off, detected at set-up): bsym [ne][M(M+1)/2] holds the
+  // upper triangle of the symmetric B_e^{-1} instead of binv, and pcol is not stored at all: the
+  // sub-diagonal column of element e is the super-diagonal row of element e-1
+  // (scol_e = qrow_{e-1}), so pcol_e = B_e^{-1} qrow_{e-1} is formed in the kernel
+  const double* bsym;
   const double *scol, *pcol, *qrow;
   const double *sub, *sup, *P, *Q;
   int64_t ne;
@@ -242,8 +247,9 @@ __device__ __forceinline__ double group_bcast(double v, int j) {
   return __shfl(v, j, W);
 }
 
-template <int M, bool CMP, int NS>
+template <int M, bool CMP, int NS, bool SYM = false>
 __global__ __launch_bounds__(kThreads) void btd_fused_kernel(FusedArgs a) {
+  static_assert(!SYM || (CMP && (M == 2 || M == 4 || M == 8)), "symmetric packing needs the lane-group path");
   // GRP: the rows of one element sit in M = 2^k adjacent lanes, so element-wide sums and
   // broadcasts (q.u+, B^{-1} b) go through cross-lane moves instead of LDS round trips
   constexpr bool GRP = CMP && (M == 2 || M == 4 || M == 8);
@@ -295,8 +301,17 @@ __global__ __launch_bounds__(kThreads) void btd_fused_kernel(FusedArgs a) {
     for (int j = 0; j < M; ++j) bi[s][j] = 0.0;
     if (valid[s]) {
       if (need_g) {
+        if (SYM) {  // row i of the symmetric inverse out of its packed upper triangle
+          constexpr int T = M * (M + 1) / 2;
 #pragma unroll
-        for (int j = 0; j < M; ++j) bi[s][j] = AGGMG_LD(a.lv.binv[row * M + j]);
+          for (int j = 0; j < M; ++j) {
+            const int lo_ = i < j ? i : j, hi_ = i < j ? j : i;
+            bi[s][j] = a.lv.bsym[e * T + lo_ * M - (lo_ * (lo_ - 1)) / 2 + (hi_ - lo_)];
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < M; ++j) bi[s][j] = AGGMG_LD(a.lv.binv[row * M + j]);
+        }
       }
       bb[s] = a.b[row];
       if (a.u_in) uu[s] = a.u_in[row];
@@ -306,7 +321,11 @@ __global__ __launch_bounds__(kThreads) void btd_fused_kernel(FusedArgs a) {
         l2y[s] = t2.y;
       }
       if (CMP) {
-        pc[s] = need_g ? AGGMG_LD(a.lv.pcol[row]) : 0.0;
+        if (SYM) {
+          pc[s] = (need_g && e > 0) ? a.lv.qrow[(e - 1) * M + i] : 0.0;  // q_{e-1}[i]; B^{-1} applied below
+        } else {
+          pc[s] = need_g ? AGGMG_LD(a.lv.pcol[row]) : 0.0;
+        }
         if (GRP) {
           qv[s][0] = AGGMG_LD(a.lv.qrow[e * M + i]);
         } else {
@@ -367,6 +386,13 @@ __global__ __launch_bounds__(kThreads) void btd_fused_kernel(FusedArgs a) {
 #pragma unroll
       for (int j = 0; j < M; ++j) acc += bi[s][j] * group_bcast<M>(bb[s], j);
       g[s] = acc;
+      if (SYM) {  // pcol = B^{-1} q_{e-1}
+        const double qp = pc[s];
+        double pacc = 0.0;
+#pragma unroll
+        for (int j = 0; j < M; ++j) pacc += bi[s][j] * group_bcast<M>(qp, j);
+        pc[s] = pacc;
+      }
     }
     __syncthreads();
   } else {

@@ -157,3 +157,51 @@ def test_blockdiagonal_container(oracle, mg):
         A @ np.zeros(149)
     with pytest.raises(mg.SingularException):
         mg.BlockDiagonal([np.eye(2), np.zeros((2, 2))]).lu()
+
+
+def test_nonsymmetric_operators_take_the_general_path(oracle, mg):
+    """The fused kernels store the packed symmetric inverse only when the operator is symmetric to
+    round-off; an operator with the same pattern but perturbed (non-symmetric) values must run the
+    general form -- and both must match the oracle, which knows nothing about symmetry."""
+    o = oracle
+    import scipy.sparse as sp
+    rng = np.random.default_rng(3)
+    for p, n in ((3, 528), (1, 304), (7, 64)):
+        Ho, b = o.build_dg_agg_hierarchy(n, p=p, pAgg=1, nAgg=2, first=4)
+        A = Ho.mStiffness[0].copy()
+        # same pattern, symmetry broken at 1e-6 (far above the 1e-13 detection threshold, small
+        # enough that the fine operator still matches its coarse levels and the cycle stays sane)
+        A.data = A.data * (1.0 + 1e-6 * rng.standard_normal(A.nnz))
+        assert abs(A - A.T).max() > 1e-9 * abs(A).max()
+        Ho.mStiffness[0] = A
+        Ho.mSmoothers[0] = o.dg_smoother(Ho.mMeshes[0], A, 'blockJac')
+        H = mg.MeshHierarchy.from_reference(Ho)
+        assert all(H.structured_levels())
+        x0 = o.splitmix_normal(len(b), 4)
+        x = mg.multigrid_v_cycle(H, x0, b)
+        xr = o.multigrid_v_cycle(Ho, x0, b)
+        # the perturbed fine operator no longer matches its coarse levels, so the cycle amplifies
+        # instead of contracting: round-off is measured against ||A x||, not the initial residual
+        scale = max(np.linalg.norm(b - A @ x0), np.linalg.norm(A @ xr))
+        assert np.linalg.norm(A @ (x - xr)) <= TOL * scale and rel(x, xr) < 1e-9
+        S = H.mSmoothers[0]
+        u = o.splitmix_normal(len(b), 5)
+        ref = u
+        for _ in range(4):
+            ref = ref + o.apply_smoother(Ho.mSmoothers[0], b - o.csc_matvec(A, ref), alpha=2.0 / 3.0)
+        assert rel(mg.smooth(S.A, S, u, b, 2.0 / 3.0, 4), ref) < TOL
+        assert rel(mg.residual(S.A, u, b), b - o.csc_matvec(A, u)) < TOL
+    # dense off-diagonal blocks (agglomerated level) with broken symmetry
+    Ho, b = o.build_dg_agg_hierarchy(512, p=2, pAgg=1, nAgg=2, first=2)
+    A1 = Ho.mStiffness[1].copy()
+    A1.data = A1.data * (1.0 + 1e-3 * rng.standard_normal(A1.nnz))
+    So = o.BlockJacobi(*[x for x in (lambda bl, ii: (bl, ii))(
+        [o.LU(A1[np.ix_(Ho.mSmoothers[1].mBlockInds[:, k] - 1, Ho.mSmoothers[1].mBlockInds[:, k] - 1)].toarray())
+         for k in range(Ho.mSmoothers[1].mBlockInds.shape[1])], Ho.mSmoothers[1].mBlockInds)])
+    Sg = mg.BlockJacobi(A1, So.mBlockInds)
+    assert Sg.structured
+    u, bb = o.splitmix_normal(A1.shape[0], 6), o.splitmix_normal(A1.shape[0], 7)
+    ref = u
+    for _ in range(5):
+        ref = ref + o.apply_smoother(So, bb - o.csc_matvec(A1, ref), alpha=2.0 / 3.0)
+    assert rel(mg.smooth(Sg.A, Sg, u, bb, 2.0 / 3.0, 5), ref) < TOL
