@@ -909,16 +909,22 @@ static int launch_csr(aggmg_ctx* ctx, const CsrDev& A, const double* x, const do
 
 template <int M, bool CMP>
 struct BtdTile {
-  // slabs per tile: sized so a tile is ~256 elements while the per-thread register arrays
-  // (NS x (2..3) x M doubles) stay well under the 128-VGPR / 4-waves-per-SIMD step
+  // Threads per workgroup and slabs per thread.  A tile of TE = (NT / M) * NS elements wants to be
+  // large (the halo costs 2 * halo / TE redundant work) while the per-thread register arrays
+  // (NS x (2..3) x M doubles) must stay small enough for >= 6-7 waves per SIMD: the sweeps only hide
+  // behind other workgroups' loads at that occupancy (measured: NS 4 -> 2 at M = 4 is 9 % per cycle).
+#ifndef AGGMG_NT4
+#define AGGMG_NT4 256
+#endif
 #ifndef AGGMG_NS4
-#define AGGMG_NS4 4
+#define AGGMG_NS4 2
 #endif
 #ifndef AGGMG_NS2
 #define AGGMG_NS2 2
 #endif
+  static constexpr int NT = (M == 4) ? AGGMG_NT4 : kThreads;
   static constexpr int NS = (M == 1) ? 2 : (M == 2) ? AGGMG_NS2 : (M == 3) ? 3 : (M == 4) ? AGGMG_NS4 : (M <= 7) ? 3 : 2;
-  static constexpr int EPS = kThreads / M;
+  static constexpr int EPS = NT / M;
   static constexpr int TE = EPS * NS;
 };
 
@@ -936,13 +942,13 @@ static int launch_btd_t(aggmg_ctx* ctx, FusedArgs a, int halo) {
   constexpr bool kGrp = CMP && (M == 2 || M == 4 || M == 8);
   if constexpr (kGrp) {
     if (a.lv.bsym) {
-      hipLaunchKernelGGL((btd_fused_kernel<M, CMP, T::NS, true>), dim3((unsigned)ntiles), dim3(kThreads), lds,
+      hipLaunchKernelGGL((btd_fused_kernel<M, CMP, T::NS, true, T::NT>), dim3((unsigned)ntiles), dim3(T::NT), lds,
                          ctx->stream, a);
       HIPCHK(hipGetLastError());
       return AGGMG_OK;
     }
   }
-  hipLaunchKernelGGL((btd_fused_kernel<M, CMP, T::NS>), dim3((unsigned)ntiles), dim3(kThreads), lds,
+  hipLaunchKernelGGL((btd_fused_kernel<M, CMP, T::NS, false, T::NT>), dim3((unsigned)ntiles), dim3(T::NT), lds,
                      ctx->stream, a);
   HIPCHK(hipGetLastError());
   return AGGMG_OK;

@@ -247,13 +247,13 @@ __device__ __forceinline__ double group_bcast(double v, int j) {
   return __shfl(v, j, W);
 }
 
-template <int M, bool CMP, int NS, bool SYM = false>
-__global__ __launch_bounds__(kThreads) void btd_fused_kernel(FusedArgs a) {
+template <int M, bool CMP, int NS, bool SYM = false, int NT = kThreads>
+__global__ __launch_bounds__(NT) void btd_fused_kernel(FusedArgs a) {
   static_assert(!SYM || (CMP && (M == 2 || M == 4 || M == 8)), "symmetric packing needs the lane-group path");
   // GRP: the rows of one element sit in M = 2^k adjacent lanes, so element-wide sums and
   // broadcasts (q.u+, B^{-1} b) go through cross-lane moves instead of LDS round trips
   constexpr bool GRP = CMP && (M == 2 || M == 4 || M == 8);
-  constexpr int EPS = kThreads / M;  // elements per slab
+  constexpr int EPS = NT / M;  // elements per slab
   constexpr int TE = EPS * NS;       // elements per tile (owned + halos)
   extern __shared__ double lds[];
   // two iterate buffers, each padded by one zero element on both sides: index (x*M + j),
@@ -554,7 +554,7 @@ __global__ __launch_bounds__(kThreads) void btd_fused_kernel(FusedArgs a) {
       }
     }
     __syncthreads();
-    for (int t = tid; t < ncoarse * 2; t += kThreads) {
+    for (int t = tid; t < ncoarse * 2; t += NT) {
       const int Jl = t >> 1, c = t & 1;
       const int64_t J = J0 + Jl;
       if (J >= nec) continue;
@@ -572,7 +572,7 @@ __global__ __launch_bounds__(kThreads) void btd_fused_kernel(FusedArgs a) {
     if (active) nxt[x * M + i] = rr[s];
   }
   __syncthreads();
-  for (int t = tid; t < ncoarse * mc; t += kThreads) {
+  for (int t = tid; t < ncoarse * mc; t += NT) {
     const int Jl = t / mc, c = t - Jl * mc;
     const int64_t J = J0 + Jl;
     if (J >= nec) continue;

@@ -14,7 +14,7 @@ import sys
 src, tag, E = sys.argv[1], sys.argv[2], int(sys.argv[3])
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ne = 2 ** E
-TE, M = 256, 4
+TE, M = 128, 4   # BtdTile<4, true>: 256 threads x 2 slabs
 
 
 def grid(owned):
@@ -24,9 +24,10 @@ def grid(owned):
 roles = {grid(TE - 2 * 4): "fused_down_L0", grid(((TE - 2 * 3) // 1)): "fused_up_L0",
          grid(((TE - 2 * 7) // 4) * 4): "fused_mid_L0"}
 expected = {  # bytes per fine element the kernel must move
-    "fused_down_L0": (128 + 32 + 32 + 32 + 32 + 64, 32 + 4),
-    "fused_up_L0": (128 + 32 + 32 + 32 + 32 + 64, 32),
-    "fused_mid_L0": (128 + 32 + 32 + 32 + 32 + 64 + 64, 32 + 4),
+    # symmetric operator: packed inverse 80, q row 32, b 32, u 32, L'D or L rows 64
+    "fused_down_L0": (80 + 32 + 32 + 32 + 64, 32 + 4),
+    "fused_up_L0": (80 + 32 + 32 + 32 + 64, 32),
+    "fused_mid_L0": (80 + 32 + 32 + 32 + 64 + 64, 32 + 4),
 }
 
 
