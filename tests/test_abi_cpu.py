@@ -46,3 +46,16 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "aggmg_oracle" not in src and "oracle/" not in src, f
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/aggmg_hip.h must be consumable by a C compiler (the ABI a Julia `ccall` / cgo / JNI
+    binding targets): compile a C99 translation unit that takes the address of every entry point."""
+    import subprocess
+    syms = header_symbols()
+    src = tmp_path / "abi_check.c"
+    body = "\n".join(f"    p[{i}] = (fn)&{s};" for i, s in enumerate(syms))
+    src.write_text('#include "aggmg_hip.h"\n#include <stddef.h>\ntypedef void (*fn)(void);\n'
+                   'fn table(fn* p) {\n' + body + "\n    return p[0];\n}\n")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
+                           "-c", str(src), "-o", str(tmp_path / "abi_check.o")])
