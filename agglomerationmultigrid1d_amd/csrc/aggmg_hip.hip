@@ -920,7 +920,7 @@ struct BtdTile {
 #define AGGMG_NS4 2
 #endif
 #ifndef AGGMG_NS2
-#define AGGMG_NS2 2
+#define AGGMG_NS2 1
 #endif
   static constexpr int NT = (M == 4) ? AGGMG_NT4 : kThreads;
   static constexpr int NS = (M == 1) ? 2 : (M == 2) ? AGGMG_NS2 : (M == 3) ? 3 : (M == 4) ? AGGMG_NS4 : (M <= 7) ? 3 : 2;
