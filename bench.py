@@ -342,10 +342,13 @@ def main():
         "roofline": {"bound": "hbm", "kernel": f"btd_fused_kernel<{args.p + 1},cmp> {dkind} level {dlevel + 1}",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "algorithmic_bytes_per_launch": per_launch,
+                     "physical_GBs": (traffic / (dms / dcnt * 1e-3) / 1e9) if traffic else None,
+                     "physical_frac": (traffic / (dms / dcnt * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                      "ms_per_launch": dms / dcnt, "launches_timed": dcnt,
                      "note": "achieved = algorithmic bytes (SURVEY 8d model: CSR int32 + fp64, every sweep re-reading "
                              "the operator) / HIP-event duration; the fused kernel reads the operator once per launch, "
-                             "so achieved may exceed what the same launch physically moves"},
+                             "so achieved exceeds what the launch physically moves: traffic = PMC bytes per launch "
+                             "(2*FETCH_SIZE + WRITE_SIZE, profiles/), physical_* = traffic / the same duration"},
         "kernels": kern_ms,
         "setup_s": t_setup,
     }
