@@ -205,3 +205,33 @@ def test_nonsymmetric_operators_take_the_general_path(oracle, mg):
     for _ in range(5):
         ref = ref + o.apply_smoother(So, bb - o.csc_matvec(A1, ref), alpha=2.0 / 3.0)
     assert rel(mg.smooth(Sg.A, Sg, u, bb, 2.0 / 3.0, 5), ref) < TOL
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_randomized_hierarchies(oracle, mg, seed):
+    """seeded random shapes: element count, fine p, agglomerated p, ratios, depth, sweep counts,
+    damping, initial guess -- one V-cycle and a three-cycle fused loop against the oracle"""
+    o = oracle
+    rng = np.random.default_rng(1000 + seed)
+    p = int(rng.integers(1, 5))
+    pAgg = int(rng.integers(0, 2))
+    first = int(rng.choice([2, 4]))
+    nAgg = int(rng.integers(1, 4))
+    tot = first * 2 ** (nAgg - 1)
+    n = tot * int(rng.integers(2, 40))
+    nPre, nPost = int(rng.integers(0, 5)), int(rng.integers(0, 5))
+    alpha = float(rng.uniform(0.3, 1.0))
+    Ho, b = o.build_dg_agg_hierarchy(n, p=p, pAgg=pAgg, nAgg=nAgg, first=first)
+    x0 = o.splitmix_normal(len(b), seed) * float(rng.choice([0.0, 1.0]))
+    H = vcycle_check(o, mg, Ho, b, x0=x0, it_tol=1e-8, nPre=nPre, nPost=nPost, alpha=alpha)
+    ctx = H.ctx
+    dz = ctx.alloc(len(b))
+    H.vcycles_dev(ctx.to_device(x0), ctx.to_device(b), dz, 3, nPre=nPre, nPost=nPost, alpha=alpha)
+    xr = x0
+    for _ in range(3):
+        xr = o.multigrid_v_cycle(Ho, xr, b, nPre=nPre, nPost=nPost, alpha=alpha, coarse_solve=dense_lu_solve)
+    A = Ho.mStiffness[0]
+    # weak coarse spaces (pAgg = 0) amplify a random iterate instead of damping it: round-off is
+    # then relative to ||A x||, not to the initial residual
+    scale = max(np.linalg.norm(b - A @ x0), np.linalg.norm(b), np.linalg.norm(A @ xr))
+    assert np.linalg.norm(A @ (dz.download() - xr)) <= 3 * TOL * scale, (n, p, pAgg, first, nAgg, nPre, nPost, alpha)
