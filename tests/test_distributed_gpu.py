@@ -92,3 +92,22 @@ def test_two_ranks_chunked_coarse_solve():
     for rank, err, scale, nex, chunked in sorted(q.get() for _ in range(2)):
         assert chunked and nex == 9              # x0 ghosts, boundary system, coarse ghosts
         assert err == 0.0, (rank, err, scale)
+
+
+def test_four_ranks_chunked_coarse_solve():
+    """four ranks on the one GPU (the box allows six GPU processes): interior ranks have ghosts on
+    both sides and two neighbours in every exchange"""
+    import torch.multiprocessing as mp
+    from test_distributed_cpu import free_port
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 4, port, 2**16, q)) for r in range(4)]
+    for pr in procs:
+        pr.start()
+    for pr in procs:
+        pr.join(900)
+    assert all(pr.exitcode == 0 for pr in procs), [pr.exitcode for pr in procs]
+    for rank, err, scale, nex, chunked in sorted(q.get() for _ in range(4)):
+        assert chunked and nex == 9
+        assert err == 0.0, (rank, err, scale)
