@@ -732,6 +732,40 @@ static int build_btd(aggmg_ctx* ctx, aggmg_smoother* sm, const std::vector<doubl
     if (st == AGGMG_OK) st = dev_upload(ctx, sup, &b->sup);
     if (st == AGGMG_OK) st = dev_upload(ctx, P, &b->P);
     if (st == AGGMG_OK) st = dev_upload(ctx, Q, &b->Q);
+    // symmetric to round-off (B_e^{-1} symmetric, Sub_e == Sup_{e-1}')?  then the kernels read the
+    // packed inverse and the super-diagonal blocks only
+    if ((m == 2 || m == 4) && !std::getenv("AGGMG_NO_SYM")) {
+      std::atomic<int> asym{0};
+      const double tol = 1e-13;
+      parallel_for(ne, [&](int64_t eb, int64_t ee) {
+        for (int64_t e = eb; e < ee && !asym.load(std::memory_order_relaxed); ++e) {
+          double scale = 0.0, ss = 0.0;
+          for (int q = 0; q < m * m; ++q) scale = std::max(scale, std::fabs(binv_all[e * m * m + q]));
+          for (int i = 0; i < m; ++i)
+            for (int j = i + 1; j < m; ++j)
+              if (std::fabs(binv_all[(e * m + i) * m + j] - binv_all[(e * m + j) * m + i]) > tol * scale) asym.store(1);
+          if (e > 0) {
+            for (int q = 0; q < m * m; ++q) ss = std::max(ss, std::fabs(sup[(e - 1) * m * m + q]));
+            for (int i = 0; i < m; ++i)
+              for (int j = 0; j < m; ++j)
+                if (std::fabs(sub[(e * m + i) * m + j] - sup[((e - 1) * m + j) * m + i]) > tol * ss) asym.store(1);
+          }
+        }
+      });
+      if (!asym.load()) {
+        const int T = m * (m + 1) / 2;
+        std::vector<double> bsym((size_t)ne * T);
+        parallel_for(ne, [&](int64_t eb, int64_t ee) {
+          for (int64_t e = eb; e < ee; ++e) {
+            int q = 0;
+            for (int i = 0; i < m; ++i)
+              for (int j = i; j < m; ++j)
+                bsym[e * T + q++] = 0.5 * (binv_all[(e * m + i) * m + j] + binv_all[(e * m + j) * m + i]);
+          }
+        });
+        if (st == AGGMG_OK) st = dev_upload(ctx, bsym, &b->bsym);
+      }
+    }
   }
   if (st != AGGMG_OK) return st;
   sm->btd = b;
@@ -939,7 +973,7 @@ static int launch_btd_t(aggmg_ctx* ctx, FusedArgs a, int halo) {
   const int64_t ntiles = (a.lv.ne + owned - 1) / owned;
   if (ntiles == 0) return AGGMG_OK;
   const size_t lds = (size_t)2 * (T::TE + 2) * M * sizeof(double);
-  constexpr bool kGrp = CMP && (M == 2 || M == 4 || M == 8);
+  constexpr bool kGrp = (CMP && (M == 2 || M == 4 || M == 8)) || (!CMP && (M == 2 || M == 4));
   if constexpr (kGrp) {
     if (a.lv.bsym) {
       hipLaunchKernelGGL((btd_fused_kernel<M, CMP, T::NS, true, T::NT>), dim3((unsigned)ntiles), dim3(T::NT), lds,

@@ -249,10 +249,13 @@ __device__ __forceinline__ double group_bcast(double v, int j) {
 
 template <int M, bool CMP, int NS, bool SYM = false, int NT = kThreads>
 __global__ __launch_bounds__(NT) void btd_fused_kernel(FusedArgs a) {
-  static_assert(!SYM || (CMP && (M == 2 || M == 4 || M == 8)), "symmetric packing needs the lane-group path");
+  static_assert(!SYM || M == 2 || M == 4 || M == 8, "symmetric packing needs the lane-group path");
   // GRP: the rows of one element sit in M = 2^k adjacent lanes, so element-wide sums and
   // broadcasts (q.u+, B^{-1} b) go through cross-lane moves instead of LDS round trips
   constexpr bool GRP = CMP && (M == 2 || M == 4 || M == 8);
+  // dense off-diagonal blocks of a symmetric operator: only the super-diagonal blocks are read
+  // (Sub_e = Sup_{e-1}'), P = B^{-1}Sub and Q = B^{-1}Sup are formed in registers at load time
+  constexpr bool DSYM = !CMP && SYM;
   constexpr int EPS = NT / M;  // elements per slab
   constexpr int TE = EPS * NS;       // elements per tile (owned + halos)
   extern __shared__ double lds[];
@@ -332,6 +335,13 @@ __global__ __launch_bounds__(NT) void btd_fused_kernel(FusedArgs a) {
 #pragma unroll
           for (int j = 0; j < (GRP ? 1 : M); ++j) qv[s][j] = a.lv.qrow[e * M + j];
         }
+      } else if (DSYM) {
+        // park Sup_{e-1}[i][:] in Pr and Sup_e[i][:] in Qr; turned into P, Q rows after the loop
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+          Pr[s][j] = (need_g && e > 0) ? a.lv.sup[(row - M) * M + j] : 0.0;
+          Qr[s][j] = need_g ? a.lv.sup[row * M + j] : 0.0;
+        }
       } else {
 #pragma unroll
         for (int j = 0; j < M; ++j) {
@@ -375,10 +385,10 @@ __global__ __launch_bounds__(NT) void btd_fused_kernel(FusedArgs a) {
       if (j == a.lv.r_sup) binv_r[s] = bi[s][j];
     if (active) {
       buf0[x * M + i] = uu[s];
-      if (!GRP) buf1[x * M + i] = bb[s];
+      if (!GRP && !DSYM) buf1[x * M + i] = bb[s];
     }
   }
-  if (GRP) {
+  if (GRP || DSYM) {
     // g = B^{-1} b with the element's b_e broadcast across its lane group
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
@@ -386,7 +396,28 @@ __global__ __launch_bounds__(NT) void btd_fused_kernel(FusedArgs a) {
 #pragma unroll
       for (int j = 0; j < M; ++j) acc += bi[s][j] * group_bcast<M>(bb[s], j);
       g[s] = acc;
-      if (SYM) {  // pcol = B^{-1} q_{e-1}
+      if (DSYM) {
+        // P_i[j] = sum_k B^{-1}_ik Sup_{e-1}[j][k]   (lane j holds row j of Sup_{e-1})
+        // Q_i[j] = sum_k B^{-1}_ik Sup_e[k][j]       (lane k holds row k of Sup_e)
+        double pn[M], qn[M];
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+          double pa = 0.0, qa = 0.0;
+#pragma unroll
+          for (int k = 0; k < M; ++k) {
+            pa += bi[s][k] * group_bcast<M>(Pr[s][k], j);
+            qa += bi[s][k] * group_bcast<M>(Qr[s][j], k);
+          }
+          pn[j] = pa;
+          qn[j] = qa;
+        }
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+          Pr[s][j] = pn[j];
+          Qr[s][j] = qn[j];
+        }
+      }
+      if (SYM && CMP) {  // pcol = B^{-1} q_{e-1}
         const double qp = pc[s];
         double pacc = 0.0;
 #pragma unroll
