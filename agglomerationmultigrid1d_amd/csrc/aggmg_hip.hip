@@ -138,6 +138,8 @@ struct CrDev {
   int q = 0;                    // next q levels run chunk-wise in LDS (one launch forward, one backward)
   std::vector<double*> d, x;    // per-level vectors for levels 0..nglobal
   double *partR = nullptr, *partL = nullptr, *xq = nullptr;  // chunk-boundary vectors (level nglobal+q)
+  double* stack = nullptr;      // per-chunk reduced right-hand sides of the chunk levels
+  int stack_stride = 0;
   size_t tail_lds = 0, chunk_lds = 0;
   double cond_est = 0.0;
 };
@@ -1689,6 +1691,8 @@ static int cr_setup(aggmg_ctx* ctx, const HostCsr& h, int64_t N, int hint_m, CrD
     CHECK(dalloc(nq, &cr->partR));
     CHECK(dalloc(nq, &cr->partL));  // partL[0] is never written: stays zero
     CHECK(dalloc(nq, &cr->xq));
+    cr->stack_stride = (int)(cr->chunk_lds / sizeof(double));
+    CHECK(dalloc((level_n(g + q) + 1) * (int64_t)cr->stack_stride, &cr->stack));
   }
   HIPCHK(hipStreamSynchronize(ctx->stream));
   cr->valid = true;
@@ -1727,6 +1731,8 @@ static int cr_solve_t(aggmg_ctx* ctx, CrDev& cr, const double* rhs, double* out)
     C.q = q;
     for (int l = 0; l < q; ++l) C.lv[l] = cr.lv[g + l];
     C.nq = g + q < nl ? cr.lv[g + q].n : 1;
+    C.stack = cr.stack;
+    C.stack_stride = cr.stack_stride;
     // one workgroup per block surviving the chunk levels: chunk c = blocks [c 2^q, (c+1) 2^q]
     const unsigned grid = (unsigned)C.nq;
     hipLaunchKernelGGL((cr_chunk_forward_kernel<M>), dim3(std::max(grid, 1u)), dim3(kThreads), cr.chunk_lds,
@@ -1774,6 +1780,8 @@ static int cr_phase_t(aggmg_ctx* ctx, CrDev& cr, int phase, const double* d_owne
   C.q = q;
   for (int l = 0; l < q; ++l) C.lv[l] = cr.lv[l];
   C.nq = q < nl ? cr.lv[q].n : 1;
+  C.stack = cr.stack;
+  C.stack_stride = cr.stack_stride;
   C.c0 = blk_lo >> q;
   const int64_t c1 = (blk_hi + ((int64_t)1 << q) - 1) >> q;
   const unsigned grid = (unsigned)std::max<int64_t>(c1 - C.c0, 0);

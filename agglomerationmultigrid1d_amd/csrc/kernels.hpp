@@ -840,6 +840,8 @@ struct CrChunk {
   int q;
   int64_t nq;  // blocks left after the q chunk levels
   int64_t c0;  // first chunk of this launch (element-partitioned runs launch a sub-range)
+  double* stack;     // [n_chunks][stack_stride] reduced right-hand sides of the chunk levels, or null
+  int stack_stride;
 };
 
 template <int M>
@@ -891,6 +893,13 @@ __global__ __launch_bounds__(kThreads) void cr_chunk_forward_kernel(CrChunk C, c
     partR[c * M + threadIdx.x] = sh[off[q] + threadIdx.x];  // left boundary of this chunk (block c of level q)
     if (hi[q] > lo[q]) partL[(c + 1) * M + threadIdx.x] = sh[off[q] + M + threadIdx.x];
   }
+  // keep the reduced right-hand sides of all q levels for the back substitution (a few KB per
+  // chunk, L2 / Infinity-Cache resident) instead of recomputing the forward pass there
+  if (C.stack) {
+    const int len = off[q];
+    double* st = C.stack + c * (int64_t)C.stack_stride;
+    for (int t = threadIdx.x; t < len; t += blockDim.x) st[t] = sh[t];
+  }
 }
 
 template <int M>
@@ -910,8 +919,20 @@ __global__ __launch_bounds__(kThreads) void cr_chunk_backward_kernel(CrChunk C, 
   }
   __syncthreads();
   const int64_t c = C.c0 + blockIdx.x;
-  cr_chunk_forward<M>(C, c, d0, sh, off, lo, hi);
   const int q = C.q;
+  if (C.stack) {
+    for (int l = 0; l <= q; ++l) {
+      const int64_t nl = l < q ? C.lv[l].n : C.nq;
+      lo[l] = c << (q - l);
+      const int64_t h = (c + 1) << (q - l);
+      hi[l] = h < nl - 1 ? h : nl - 1;
+    }
+    const double* st = C.stack + c * (int64_t)C.stack_stride;
+    for (int t = tid; t < off[q]; t += blockDim.x) sh[t] = st[t];
+    __syncthreads();
+  } else {
+    cr_chunk_forward<M>(C, c, d0, sh, off, lo, hi);
+  }
   const int cntq = (int)(hi[q] - lo[q] + 1) * M;
   for (int t = tid; t < cntq; t += blockDim.x) sh[off[q] + t] = xq[lo[q] * M + t];
   __syncthreads();
