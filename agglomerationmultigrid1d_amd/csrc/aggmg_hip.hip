@@ -1605,6 +1605,10 @@ static int cr_setup(aggmg_ctx* ctx, const HostCsr& h, int64_t N, int hint_m, CrD
     L.n = n;
     L.n_even = ne;
     L.n_odd = no;
+    // the kernels multiply by the inverted diagonal of U (a division is a ~40-instruction
+    // dependent chain on every level of the reduction)
+    for (int64_t j = 0; j < no; ++j)
+      for (int i = 0; i < m; ++i) lu[j * mm2 + i * m + i] = 1.0 / lu[j * mm2 + i * m + i];
     int st = upd(a, &L.a);
     if (st == AGGMG_OK) st = upd(c, &L.c);
     if (st == AGGMG_OK) st = upd(lu, &L.lu);
@@ -1632,6 +1636,7 @@ static int cr_setup(aggmg_ctx* ctx, const HostCsr& h, int64_t N, int hint_m, CrD
     }
     const double* p = nullptr;
     const int32_t* q = nullptr;
+    for (int i = 0; i < m; ++i) lu[i * m + i] = 1.0 / lu[i * m + i];
     int st = upd(lu, &p);
     if (st == AGGMG_OK) st = upi(perm, &q);
     if (st != AGGMG_OK) {
@@ -1737,12 +1742,12 @@ static int cr_solve_t(aggmg_ctx* ctx, CrDev& cr, const double* rhs, double* out)
     const unsigned grid = (unsigned)C.nq;
     hipLaunchKernelGGL((cr_chunk_forward_kernel<M>), dim3(std::max(grid, 1u)), dim3(kThreads), cr.chunk_lds,
                        ctx->stream, C, dl(g), cr.partR, cr.partL);
-    hipLaunchKernelGGL((cr_tail_kernel<M>), dim3(1), dim3(1024), cr.tail_lds, ctx->stream, T,
+    hipLaunchKernelGGL((cr_tail_kernel<M>), dim3(1), dim3(kCrTailThreads), cr.tail_lds, ctx->stream, T,
                        (const double*)cr.partR, (const double*)cr.partL, cr.xq);
     hipLaunchKernelGGL((cr_chunk_backward_kernel<M>), dim3(std::max(grid, 1u)), dim3(kThreads), cr.chunk_lds,
                        ctx->stream, C, dl(g), (const double*)cr.xq, xl(g));
   } else {
-    hipLaunchKernelGGL((cr_tail_kernel<M>), dim3(1), dim3(1024), cr.tail_lds, ctx->stream, T, dl(g),
+    hipLaunchKernelGGL((cr_tail_kernel<M>), dim3(1), dim3(kCrTailThreads), cr.tail_lds, ctx->stream, T, dl(g),
                        (const double*)nullptr, xl(g));
   }
   for (int l = g - 1; l >= 0; --l) {
@@ -1770,7 +1775,7 @@ static int cr_phase_t(aggmg_ctx* ctx, CrDev& cr, int phase, const double* d_owne
   T.lu_last = cr.lu_last;
   T.perm_last = cr.perm_last;
   if (phase == 1) {  // boundary system
-    hipLaunchKernelGGL((cr_tail_kernel<M>), dim3(1), dim3(1024), cr.tail_lds, ctx->stream, T, (const double*)partR,
+    hipLaunchKernelGGL((cr_tail_kernel<M>), dim3(1), dim3(kCrTailThreads), cr.tail_lds, ctx->stream, T, (const double*)partR,
                        (const double*)partL, const_cast<double*>(xq));
     HIPCHK(hipGetLastError());
     return AGGMG_OK;
@@ -2313,3 +2318,9 @@ extern "C" int aggmg_hier_last_coarse_ms(aggmg_ctx* ctx, const aggmg_hier* h, do
   *ms = h->last_coarse_ms;
   return AGGMG_OK;
 }
+
+#ifdef AGGMG_CR_STAMPS
+extern "C" int aggmg_debug_cr_stamps(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(aggmg::g_cr_stamps), sizeof(unsigned long long) * 96) == hipSuccess ? 0 : -1;
+}
+#endif
