@@ -9,7 +9,7 @@ from .api import (AbstractSmoother, AdditiveSchwarzSmoother, BlockDiagonal, Bloc
                   DeviceOperator,
                   DeviceVector, HybridSchwarzSmoother, JacobiSmoother, MeshHierarchy,
                   apply_smoother, cg_smoother, default_context, dg_smoother,
-                  iterative_smoother_solve, ldiv, multigrid, multigrid_v_cycle, prolong_add,
-                  residual, restrict, smooth)
+                  dot, iterative_smoother_solve, ldiv, multigrid, multigrid_dev, multigrid_v_cycle, norm2, pcg,
+                  prolong_add, residual, restrict, smooth)
 
 __all__ = [n for n in dir() if not n.startswith("_")]

@@ -104,6 +104,14 @@ SYMBOLS = {
     "aggmg_coarse_chunk_backward_dev": (c_int, [_P, _P, _P, c_int64, c_int64, _P, _P]),
     "aggmg_hier_coarse_info": (c_int, [_P, _P, POINTER(c_int), POINTER(c_int), POINTER(c_double)]),
     "aggmg_hier_last_coarse_ms": (c_int, [_P, _P, POINTER(c_double)]),
+    "aggmg_dot_dev": (c_int, [_P, _P, _P, c_int64, POINTER(c_double)]),
+    "aggmg_norm2_dev": (c_int, [_P, _P, c_int64, POINTER(c_double)]),
+    "aggmg_residual_norm_dev": (c_int, [_P, _P, _P, _P, POINTER(c_double)]),
+    "aggmg_multigrid_dev": (c_int, [_P, _P, _P, _P, c_int, c_double, c_int, c_int, c_int, c_double, _P,
+                                    _PD, POINTER(c_int), POINTER(c_int)]),
+    "aggmg_smoother_solve_dev": (c_int, [_P, _P, _P, _P, _P, c_int, c_double, c_double, c_int, _P,
+                                         _PD, POINTER(c_int), POINTER(c_int)]),
+    "aggmg_pcg_dev": (c_int, [_P, _P, _P, _P, c_int, c_double, c_int, c_int, c_double, _PD, POINTER(c_int)]),
     "aggmg_profile_enable": (c_int, [_P, c_int]),
     "aggmg_profile_collect": (c_int, [_P, _PD, POINTER(c_int64)]),
     "aggmg_version": (c_char_p, []),

@@ -608,29 +608,70 @@ def _device_residual_norm(H_or_op, x, b):
     return np.linalg.norm(r, 2)
 
 
+def norm2(x, ctx=None):
+    """||x||_2 of a DeviceVector (or of a host array, uploaded first) -- C ABI aggmg_norm2_dev"""
+    c = ctx or getattr(x, "ctx", None) or default_context()
+    dx = x if isinstance(x, DeviceVector) else c.to_device(_f64(x))
+    out = ctypes.c_double(0.0)
+    c.check(c.lib.aggmg_norm2_dev(c.handle, dx.ptr, dx.n, ctypes.byref(out)))
+    return out.value
+
+
+def dot(x, y, ctx=None):
+    """x . y of two DeviceVectors (host arrays are uploaded first) -- C ABI aggmg_dot_dev"""
+    c = ctx or getattr(x, "ctx", None) or default_context()
+    dx = x if isinstance(x, DeviceVector) else c.to_device(_f64(x))
+    dy = y if isinstance(y, DeviceVector) else c.to_device(_f64(y))
+    if dx.n != dy.n:
+        raise DimensionMismatch("dot: vectors differ in length")
+    out = ctypes.c_double(0.0)
+    c.check(c.lib.aggmg_dot_dev(c.handle, dx.ptr, dy.ptr, dx.n, ctypes.byref(out)))
+    return out.value
+
+
+def multigrid_dev(H, x0, b, maxiter, tol, check_every=1, nPre=3, nPost=3, alpha=2.0 / 3.0):
+    """The loop of multigrid (src/solvers.jl:122-134) resident on the device -- C ABI
+    aggmg_multigrid_dev.  x0, b: DeviceVectors.  -> (x DeviceVector, cycles, res list)"""
+    c = H.ctx
+    N = H._ops[0].shape[0]
+    if x0.n != N or b.n != N:
+        raise DimensionMismatch("multigrid: x0 / b do not match the fine operator")
+    x = c.alloc(N)
+    nchk = max(1, -(-int(maxiter) // max(1, int(check_every))))
+    hist = np.zeros(nchk)
+    ncyc, nck = ctypes.c_int(0), ctypes.c_int(0)
+    c.check(c.lib.aggmg_multigrid_dev(c.handle, H.handle, x0.ptr, b.ptr, int(maxiter), float(tol), int(check_every),
+                                      int(nPre), int(nPost), float(alpha), x.ptr, _pd(hist),
+                                      ctypes.byref(ncyc), ctypes.byref(nck)))
+    return x, ncyc.value, hist[:nck.value].tolist()
+
+
 def multigrid(H, x0, b, maxiter, tol, exact=True, check_every=1):
     """multigrid(H, x0, b, maxiter, tol) -> (x, iter, res, err)  (src/solvers.jl:116-139).
-    The reference solves the fine system directly for the error history (:120); pass
-    exact=False to skip that at sizes where a fine-level direct solve is not wanted (err is
-    then empty).  check_every = c > 1 runs c cycles per residual check in one device-resident
-    call (fused across cycles); res / err then have one entry per check and `iter` counts cycles."""
+    The reference solves the fine system directly for the error history (:120); with exact=True
+    that is reproduced (host direct solve, the iterate comes back after every cycle).  exact=False
+    skips it -- err is then empty and the whole loop, residual norms included, stays on the device
+    (aggmg_multigrid_dev).  check_every = c > 1 runs c cycles per residual check in one fused
+    device call; res / err then have one entry per check and `iter` counts cycles."""
     x0 = _f64(x0)
     b = _f64(b)
+    c = H.ctx
+    if not exact:
+        dx, ncyc, res = multigrid_dev(H, c.to_device(x0), c.to_device(b), maxiter, tol, check_every)
+        return dx.download(), (ncyc if check_every > 1 else len(res)), res, []
     x = np.zeros(len(x0))
-    u_exact = spla.spsolve(sp.csc_matrix(H.mStiffness[0]), b) if exact else None
+    u_exact = spla.spsolve(sp.csc_matrix(H.mStiffness[0]), b)
     err, res = [], []
     nb = np.linalg.norm(b, 2)
     if check_every <= 1:
         for i in range(int(maxiter)):
             x = multigrid_v_cycle(H, x0, b)
             x0 = x
-            if exact:
-                err.append(np.linalg.norm(x - u_exact, 2))
+            err.append(np.linalg.norm(x - u_exact, 2))
             res.append(_device_residual_norm(H._ops[0], x, b))
             if res[i] < tol * nb:
                 break
         return x, len(res), res, err
-    c = H.ctx
     db, dx, dy = c.to_device(b), c.to_device(x0), c.alloc(len(b))
     done = 0
     while done < int(maxiter):
@@ -639,32 +680,60 @@ def multigrid(H, x0, b, maxiter, tol, exact=True, check_every=1):
         dx, dy = dy, dx
         done += k
         x = dx.download()
-        if exact:
-            err.append(np.linalg.norm(x - u_exact, 2))
+        err.append(np.linalg.norm(x - u_exact, 2))
         res.append(_device_residual_norm(H._ops[0], x, b))
         if res[-1] < tol * nb:
             break
     return x, done, res, err
 
 
-def iterative_smoother_solve(A, smoother, x0, b, maxiter=1000, tol=1e-6, alpha=1.0, exact=True):
+def pcg(H, b, x0=None, maxiter=50, tol=1e-10, nPre=3, nPost=3, alpha=2.0 / 3.0):
+    """Conjugate gradients with ldiv!(y, H, r) (src/solvers.jl:84-92) as the preconditioner,
+    resident on the device (C ABI aggmg_pcg_dev).  EXTENSION: the reference offers ldiv! for this
+    use but has no Krylov loop.  -> (x, iter, res)"""
+    b = _f64(b)
+    c = H.ctx
+    N = H._ops[0].shape[0]
+    if b.shape != (N,):
+        raise DimensionMismatch("pcg: b does not match the fine operator")
+    dx = c.to_device(np.zeros(N) if x0 is None else _f64(x0))
+    db = c.to_device(b)
+    hist = np.zeros(max(1, int(maxiter)))
+    it = ctypes.c_int(0)
+    c.check(c.lib.aggmg_pcg_dev(c.handle, H.handle, db.ptr, dx.ptr, int(maxiter), float(tol), int(nPre), int(nPost),
+                                float(alpha), _pd(hist), ctypes.byref(it)))
+    return dx.download(), it.value, hist[:it.value].tolist()
+
+
+def iterative_smoother_solve(A, smoother, x0, b, maxiter=1000, tol=1e-6, alpha=1.0, exact=True, check_every=1):
     """iterative_smoother_solve(A, smoother, x0, b; maxiter=1000, tol=1e-6, alpha=1.0)
     -> (x, iter, res, err)  (src/solvers.jl:189-213).  Each iteration is one fused device sweep
-    x = x0 + apply_smoother(S, b - A*x0; alpha)."""
+    x = x0 + apply_smoother(S, b - A*x0; alpha).  exact=False skips the direct solve of :194 and
+    keeps the loop and the residual norms on the device (aggmg_smoother_solve_dev)."""
     op = smoother.A if not isinstance(A, DeviceOperator) else A
     x0 = _f64(x0).copy()
     b = _f64(b)
-    uExact = spla.spsolve(sp.csc_matrix(A), b) if (exact and not isinstance(A, DeviceOperator)) else None
+    c = op.ctx
+    if not exact or isinstance(A, DeviceOperator):
+        N = op.shape[0]
+        dx0, db, dx = c.to_device(x0), c.to_device(b), c.alloc(N)
+        nchk = max(1, -(-int(maxiter) // max(1, int(check_every))))
+        hist = np.zeros(nchk)
+        nit, nck = ctypes.c_int(0), ctypes.c_int(0)
+        c.check(c.lib.aggmg_smoother_solve_dev(c.handle, op.handle, smoother.handle, dx0.ptr, db.ptr, int(maxiter),
+                                               float(tol), float(alpha), int(check_every), dx.ptr, _pd(hist),
+                                               ctypes.byref(nit), ctypes.byref(nck)))
+        res = hist[:nck.value].tolist()
+        return dx.download(), (nit.value if check_every > 1 else len(res)), res, []
+    uExact = spla.spsolve(sp.csc_matrix(A), b)
     err, res = [], []
     nb = np.linalg.norm(b, 2)
-    c = op.ctx
     x = np.zeros(len(x0))
     for i in range(int(maxiter)):
         x = x0.copy()
         c.check(c.lib.aggmg_smooth(c.handle, op.handle, smoother.handle, _pd(x), _pd(b), float(alpha), 1))
         x0 = x
-        if uExact is not None:
-            err.append(np.linalg.norm(x - uExact, 2))
+        err.append(np.linalg.norm(x - uExact, 2))
         res.append(_device_residual_norm(op, x, b))
         if res[i] < tol * nb:
             break

@@ -46,6 +46,12 @@ struct aggmg_ctx {
   // scratch vectors for ping-pong / temporaries, grown on demand
   double* scratch[3] = {nullptr, nullptr, nullptr};
   int64_t scratch_len[3] = {0, 0, 0};
+  // outer-solver work space (aggmg_multigrid_dev, aggmg_pcg_dev, ...): vectors, dot-product
+  // partials and the device-resident scalars
+  double* solv[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  int64_t solv_len[5] = {0, 0, 0, 0, 0};
+  double* solv_part = nullptr;
+  double* solv_sc = nullptr;
 };
 
 struct CsrDev {
@@ -310,6 +316,10 @@ extern "C" int aggmg_destroy(aggmg_ctx* ctx) {
   for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
   for (int s = 0; s < 3; ++s)
     if (ctx->scratch[s]) (void)hipFree(ctx->scratch[s]);
+  for (int s = 0; s < 5; ++s)
+    if (ctx->solv[s]) (void)hipFree(ctx->solv[s]);
+  if (ctx->solv_part) (void)hipFree(ctx->solv_part);
+  if (ctx->solv_sc) (void)hipFree(ctx->solv_sc);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
   return AGGMG_OK;
@@ -2316,6 +2326,215 @@ extern "C" int aggmg_coarse_chunk_backward_dev(aggmg_ctx* ctx, aggmg_hier* h, co
 extern "C" int aggmg_hier_last_coarse_ms(aggmg_ctx* ctx, const aggmg_hier* h, double* ms) {
   if (!ctx || !h || !ms) return AGGMG_ERR_ARGUMENT;
   *ms = h->last_coarse_ms;
+  return AGGMG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// outer solver loops on the device: multigrid (src/solvers.jl:116-139) and
+// iterative_smoother_solve (src/solvers.jl:189-213) without the per-iteration host round trips of
+// the iterate, and ldiv! (src/solvers.jl:63-92) as the preconditioner of a conjugate-gradient loop
+// ---------------------------------------------------------------------------------------------
+static int solv_vec(aggmg_ctx* ctx, int slot, int64_t len, double** out) {
+  if (ctx->solv_len[slot] < len) {
+    if (ctx->solv[slot]) {
+      HIPCHK(hipStreamSynchronize(ctx->stream));
+      HIPCHK(hipFree(ctx->solv[slot]));
+    }
+    ctx->solv[slot] = nullptr;
+    ctx->solv_len[slot] = 0;
+    HIPCHK(hipMalloc((void**)&ctx->solv[slot], (size_t)std::max<int64_t>(len, 1) * sizeof(double)));
+    ctx->solv_len[slot] = len;
+  }
+  *out = ctx->solv[slot];
+  return AGGMG_OK;
+}
+
+static int solv_scalars(aggmg_ctx* ctx) {
+  if (!ctx->solv_part) HIPCHK(hipMalloc((void**)&ctx->solv_part, kDotBlocks * sizeof(double)));
+  if (!ctx->solv_sc) HIPCHK(hipMalloc((void**)&ctx->solv_sc, 16 * sizeof(double)));
+  return AGGMG_OK;
+}
+
+// sc_out[0] = x . y  (or its square root); everything stays on the stream
+static int dev_dot(aggmg_ctx* ctx, int64_t n, const double* x, const double* y, double* sc_out, int take_sqrt) {
+  CHECK(solv_scalars(ctx));
+  hipLaunchKernelGGL(dot_partial_kernel, dim3(kDotBlocks), dim3(kThreads), 0, ctx->stream, n, x, y, ctx->solv_part);
+  hipLaunchKernelGGL(dot_final_kernel, dim3(1), dim3(kThreads), 0, ctx->stream, kDotBlocks,
+                     (const double*)ctx->solv_part, sc_out, take_sqrt);
+  HIPCHK(hipGetLastError());
+  return AGGMG_OK;
+}
+
+static int read_scalar(aggmg_ctx* ctx, const double* sc, double* out) {
+  HIPCHK(hipMemcpyAsync(out, sc, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return AGGMG_OK;
+}
+
+extern "C" int aggmg_dot_dev(aggmg_ctx* ctx, const double* x, const double* y, int64_t n, double* out) {
+  if (!ctx) return AGGMG_ERR_ARGUMENT;
+  if (!x || !y || !out || n < 0) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_dot_dev: bad argument");
+  HIPCHK(hipSetDevice(ctx->device));
+  CHECK(solv_scalars(ctx));
+  CHECK(dev_dot(ctx, n, x, y, ctx->solv_sc + 15, 0));
+  return read_scalar(ctx, ctx->solv_sc + 15, out);
+}
+
+extern "C" int aggmg_norm2_dev(aggmg_ctx* ctx, const double* x, int64_t n, double* out) {
+  if (!ctx) return AGGMG_ERR_ARGUMENT;
+  if (!x || !out || n < 0) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_norm2_dev: bad argument");
+  HIPCHK(hipSetDevice(ctx->device));
+  CHECK(solv_scalars(ctx));
+  CHECK(dev_dot(ctx, n, x, x, ctx->solv_sc + 15, 1));
+  return read_scalar(ctx, ctx->solv_sc + 15, out);
+}
+
+// ||b - A x||_2 on the device (work vector slot 0)
+static int residual_norm(aggmg_ctx* ctx, aggmg_op* A, const double* x, const double* b, double* out) {
+  double* r = nullptr;
+  CHECK(solv_vec(ctx, 0, A->m, &r));
+  CHECK(aggmg_residual_dev(ctx, A, x, b, r));
+  CHECK(dev_dot(ctx, A->m, r, r, ctx->solv_sc + 14, 1));
+  return read_scalar(ctx, ctx->solv_sc + 14, out);
+}
+
+extern "C" int aggmg_residual_norm_dev(aggmg_ctx* ctx, aggmg_op* A, const double* x, const double* b, double* out) {
+  if (!ctx) return AGGMG_ERR_ARGUMENT;
+  if (!A || !x || !b || !out) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_residual_norm_dev: NULL argument");
+  HIPCHK(hipSetDevice(ctx->device));
+  CHECK(solv_scalars(ctx));
+  return residual_norm(ctx, A, x, b, out);
+}
+
+extern "C" int aggmg_multigrid_dev(aggmg_ctx* ctx, aggmg_hier* h, const double* x0, const double* b, int maxiter,
+                                   double tol, int check_every, int nPre, int nPost, double alpha, double* x_out,
+                                   double* res_hist, int* n_cycles, int* n_checks) {
+  CHECK(vcycle_args(ctx, h, x0, b, nPre, nPost));
+  if (!x_out || !res_hist || !n_cycles || !n_checks || maxiter < 0 || check_every < 1)
+    return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_multigrid_dev: bad argument");
+  if (x_out == x0 || x_out == b) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_multigrid_dev: x_out must not alias x0 or b");
+  HIPCHK(hipSetDevice(ctx->device));
+  CHECK(solv_scalars(ctx));
+  aggmg_op* A = h->lv[0].A;
+  const int64_t N = A->m;
+  double nb = 0.0;
+  CHECK(dev_dot(ctx, N, b, b, ctx->solv_sc + 13, 1));
+  CHECK(read_scalar(ctx, ctx->solv_sc + 13, &nb));
+  // iterate ping-pong: x_out and work vector 1 (the V-cycle wants distinct input and output)
+  double* alt = nullptr;
+  CHECK(solv_vec(ctx, 1, N, &alt));
+  const double* cur = x0;
+  int done = 0, checks = 0;
+  *n_cycles = 0;
+  *n_checks = 0;
+  if (maxiter == 0) {
+    HIPCHK(hipMemcpyAsync(x_out, x0, N * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    return AGGMG_OK;
+  }
+  while (done < maxiter) {
+    const int k = std::min(check_every, maxiter - done);
+    double* dst = (cur == x_out) ? alt : x_out;
+    CHECK(aggmg_vcycles_dev(ctx, h, cur, b, k, nPre, nPost, alpha, dst));
+    cur = dst;
+    done += k;
+    double res = 0.0;
+    CHECK(residual_norm(ctx, A, cur, b, &res));
+    res_hist[checks++] = res;
+    if (res < tol * nb) break;  // src/solvers.jl:131
+  }
+  if (cur != x_out) HIPCHK(hipMemcpyAsync(x_out, cur, N * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  *n_cycles = done;
+  *n_checks = checks;
+  return AGGMG_OK;
+}
+
+extern "C" int aggmg_smoother_solve_dev(aggmg_ctx* ctx, aggmg_op* A, aggmg_smoother* sm, const double* x0,
+                                        const double* b, int maxiter, double tol, double alpha, int check_every,
+                                        double* x_out, double* res_hist, int* n_iters, int* n_checks) {
+  CHECK(check_pair(ctx, A, sm, "aggmg_smoother_solve_dev"));
+  if (!x0 || !b || !x_out || !res_hist || !n_iters || !n_checks || maxiter < 0 || check_every < 1)
+    return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_smoother_solve_dev: bad argument");
+  if (x_out == x0 || x_out == b) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_smoother_solve_dev: x_out must not alias x0 or b");
+  HIPCHK(hipSetDevice(ctx->device));
+  CHECK(solv_scalars(ctx));
+  const int64_t N = A->m;
+  double nb = 0.0;
+  CHECK(dev_dot(ctx, N, b, b, ctx->solv_sc + 13, 1));
+  CHECK(read_scalar(ctx, ctx->solv_sc + 13, &nb));
+  double* alt = nullptr;
+  CHECK(solv_vec(ctx, 1, N, &alt));
+  const double* cur = x0;
+  int done = 0, checks = 0;
+  *n_iters = 0;
+  *n_checks = 0;
+  while (done < maxiter) {
+    const int k = std::min(check_every, maxiter - done);
+    double* dst = (cur == x_out) ? alt : x_out;
+    CHECK(aggmg_smooth_dev(ctx, A, sm, cur, b, alpha, k, dst));  // k x (x += alpha S (b - A x)), :200
+    cur = dst;
+    done += k;
+    double res = 0.0;
+    CHECK(residual_norm(ctx, A, cur, b, &res));
+    res_hist[checks++] = res;
+    if (res < tol * nb) break;  // src/solvers.jl:206
+  }
+  if (cur != x_out) HIPCHK(hipMemcpyAsync(x_out, cur, N * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  *n_iters = done;
+  *n_checks = checks;
+  return AGGMG_OK;
+}
+
+// Conjugate gradients on A x = b preconditioned by one V-cycle from a zero guess, i.e. by
+// ldiv!(y, H, r) (src/solvers.jl:84-92).  Needs a symmetric positive definite A and a symmetric
+// cycle (nPre == nPost, block-Jacobi / Jacobi smoothers, L' restriction): true for every hierarchy
+// the reference builds.  Extension: the reference stops at ldiv!, it has no Krylov loop.
+extern "C" int aggmg_pcg_dev(aggmg_ctx* ctx, aggmg_hier* h, const double* b, double* x_inout, int maxiter, double tol,
+                             int nPre, int nPost, double alpha, double* res_hist, int* n_iters) {
+  CHECK(vcycle_args(ctx, h, x_inout, b, nPre, nPost));
+  if (!res_hist || !n_iters || maxiter < 0) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_pcg_dev: bad argument");
+  if (x_inout == b) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_pcg_dev: x must not alias b");
+  if (h->coarse_mode == AGGMG_COARSE_EXTERNAL)
+    return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_pcg_dev: hierarchy was created with AGGMG_COARSE_EXTERNAL");
+  HIPCHK(hipSetDevice(ctx->device));
+  CHECK(solv_scalars(ctx));
+  aggmg_op* A = h->lv[0].A;
+  const int64_t N = A->m;
+  double *r = nullptr, *z = nullptr, *pv = nullptr, *q = nullptr, *zero = nullptr;
+  CHECK(solv_vec(ctx, 0, N, &r));
+  CHECK(solv_vec(ctx, 1, N, &z));
+  CHECK(solv_vec(ctx, 2, N, &pv));
+  CHECK(solv_vec(ctx, 3, N, &q));
+  CHECK(solv_vec(ctx, 4, N, &zero));
+  HIPCHK(hipMemsetAsync(zero, 0, N * sizeof(double), ctx->stream));
+  double* sc = ctx->solv_sc;  // [0] rz  [1] p.q  [2] rz_new  [3] ||r||  [13] ||b||
+  const unsigned grid = (unsigned)((N + kThreads - 1) / kThreads);
+  double nb = 0.0, res = 0.0;
+  CHECK(dev_dot(ctx, N, b, b, sc + 13, 1));
+  CHECK(read_scalar(ctx, sc + 13, &nb));
+  *n_iters = 0;
+  CHECK(aggmg_residual_dev(ctx, A, x_inout, b, r));                       // r = b - A x
+  CHECK(aggmg_vcycle_dev(ctx, h, zero, r, nPre, nPost, alpha, z));        // z = M^-1 r  (ldiv!)
+  HIPCHK(hipMemcpyAsync(pv, z, N * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+  CHECK(dev_dot(ctx, N, r, z, sc + 0, 0));
+  for (int it = 0; it < maxiter; ++it) {
+    CHECK(aggmg_residual_dev(ctx, A, pv, zero, q));                       // q = -A p
+    CHECK(dev_dot(ctx, N, pv, q, sc + 1, 0));
+    hipLaunchKernelGGL(pcg_xr_kernel, dim3(grid), dim3(kThreads), 0, ctx->stream, N, x_inout, r, (const double*)pv,
+                       (const double*)q, (const double*)(sc + 0), (const double*)(sc + 1));
+    CHECK(dev_dot(ctx, N, r, r, sc + 3, 1));
+    CHECK(read_scalar(ctx, sc + 3, &res));
+    res_hist[it] = res;
+    *n_iters = it + 1;
+    if (res < tol * nb) break;
+    CHECK(aggmg_vcycle_dev(ctx, h, zero, r, nPre, nPost, alpha, z));
+    CHECK(dev_dot(ctx, N, r, z, sc + 2, 0));
+    hipLaunchKernelGGL(pcg_p_kernel, dim3(grid), dim3(kThreads), 0, ctx->stream, N, pv, (const double*)z,
+                       (const double*)(sc + 2), (const double*)(sc + 0));
+    HIPCHK(hipMemcpyAsync(sc + 0, sc + 2, sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+  }
+  HIPCHK(hipStreamSynchronize(ctx->stream));
   return AGGMG_OK;
 }
 

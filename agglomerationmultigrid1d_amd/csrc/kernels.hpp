@@ -166,6 +166,69 @@ __global__ __launch_bounds__(kThreads) void axpy_scaled_kernel(int64_t n, const 
 }
 
 // ------------------------------------------------------------------------------------------
+// outer-solver vector kernels (multigrid / iterative_smoother_solve loops, PCG): the scalars stay
+// on the device, the host only reads the residual norm it needs for the stopping test
+// ------------------------------------------------------------------------------------------
+constexpr int kDotBlocks = 1024;  // fixed grid and fixed summation tree: results are reproducible
+
+// partial[b] = sum_{i in slice b} x_i y_i   (slice = contiguous n / gridDim range)
+__global__ __launch_bounds__(kThreads) void dot_partial_kernel(int64_t n, const double* __restrict__ x,
+                                                               const double* __restrict__ y,
+                                                               double* __restrict__ partial) {
+  __shared__ double sh[kThreads];
+  const int64_t per = (n + gridDim.x - 1) / gridDim.x;
+  const int64_t lo = (int64_t)blockIdx.x * per;
+  const int64_t hi = lo + per < n ? lo + per : n;
+  double acc = 0.0;
+  for (int64_t i = lo + threadIdx.x; i < hi; i += kThreads) acc += x[i] * y[i];
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = kThreads / 2; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = sh[0];
+}
+
+// out[0] = sum of the partials (one workgroup), optionally its square root
+__global__ __launch_bounds__(kThreads) void dot_final_kernel(int nparts, const double* __restrict__ partial,
+                                                             double* __restrict__ out, int take_sqrt) {
+  __shared__ double sh[kThreads];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += kThreads) acc += partial[i];
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = kThreads / 2; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = take_sqrt ? sqrt(sh[0]) : sh[0];
+}
+
+// PCG step with q = -A p (the residual kernel's sign):  a = rz / (-(p.q));  x += a p;  r += a q
+__global__ __launch_bounds__(kThreads) void pcg_xr_kernel(int64_t n, double* __restrict__ x, double* __restrict__ r,
+                                                          const double* __restrict__ p,
+                                                          const double* __restrict__ q,
+                                                          const double* __restrict__ rz,
+                                                          const double* __restrict__ pq) {
+  const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (i >= n) return;
+  const double a = rz[0] / (-pq[0]);
+  x[i] += a * p[i];
+  r[i] += a * q[i];
+}
+
+// p = z + (rz_new / rz_old) p
+__global__ __launch_bounds__(kThreads) void pcg_p_kernel(int64_t n, double* __restrict__ p,
+                                                         const double* __restrict__ z,
+                                                         const double* __restrict__ rz_new,
+                                                         const double* __restrict__ rz_old) {
+  const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (i >= n) return;
+  p[i] = z[i] + (rz_new[0] / rz_old[0]) * p[i];
+}
+
+// ------------------------------------------------------------------------------------------
 // fused block-tridiagonal kernel
 // ------------------------------------------------------------------------------------------
 // Level data, all fp64, row-major per DoF row (row = e*M + i):

@@ -184,6 +184,34 @@ int aggmg_hier_coarse_info(aggmg_ctx* ctx, const aggmg_hier* h, int* on_device, 
  * D2H + solve + H2D, measured with the host clock). */
 int aggmg_hier_last_coarse_ms(aggmg_ctx* ctx, const aggmg_hier* h, double* ms);
 
+/* ---- outer solver loops, device-resident -------------------------------------- */
+/* x . y and ||x||_2 of device vectors (fixed reduction tree: reproducible run to run). */
+int aggmg_dot_dev(aggmg_ctx* ctx, const double* x, const double* y, int64_t n, double* out);
+int aggmg_norm2_dev(aggmg_ctx* ctx, const double* x, int64_t n, double* out);
+/* ||b - A x||_2: the `la.norm( A * x - b, 2 )` of src/solvers.jl:129 and :204. */
+int aggmg_residual_norm_dev(aggmg_ctx* ctx, aggmg_op* A, const double* x, const double* b, double* out);
+/* multigrid(H, x0, b, maxiter, tol) -> x, iter, res       src/solvers.jl:116-139, without the
+ * fine-level direct solve of :120 (no `err` history): x <- multigrid_v_cycle(H, x, b) until
+ * ||A x - b|| < tol ||b|| (:131) or maxiter cycles.  The residual is checked every `check_every`
+ * cycles (1 = the reference's loop; c > 1 runs c cycles per check through aggmg_vcycles_dev);
+ * res_hist (host, >= ceil(maxiter / check_every) entries) receives one norm per check.  All
+ * vectors are device pointers; x_out may alias neither x0 nor b. */
+int aggmg_multigrid_dev(aggmg_ctx* ctx, aggmg_hier* h, const double* x0, const double* b, int maxiter,
+                        double tol, int check_every, int nPre, int nPost, double alpha, double* x_out,
+                        double* res_hist, int* n_cycles, int* n_checks);
+/* iterative_smoother_solve(A, smoother, x0, b; maxiter, tol, alpha) -> x, iter, res
+ * src/solvers.jl:189-213 without the direct solve of :194; same conventions as above. */
+int aggmg_smoother_solve_dev(aggmg_ctx* ctx, aggmg_op* A, aggmg_smoother* sm, const double* x0,
+                             const double* b, int maxiter, double tol, double alpha, int check_every,
+                             double* x_out, double* res_hist, int* n_iters, int* n_checks);
+/* Conjugate gradients on A x = b with ldiv!(y, H, r) (one V-cycle from a zero guess,
+ * src/solvers.jl:84-92) as the preconditioner; x_inout holds the initial guess and the result.
+ * EXTENSION: the reference provides ldiv! so that a hierarchy can be used as a preconditioner but
+ * has no Krylov loop of its own.  Needs A symmetric positive definite and nPre == nPost.
+ * res_hist (host, >= maxiter entries): ||r|| of the recurrence after every iteration. */
+int aggmg_pcg_dev(aggmg_ctx* ctx, aggmg_hier* h, const double* b, double* x_inout, int maxiter, double tol,
+                  int nPre, int nPost, double alpha, double* res_hist, int* n_iters);
+
 /* ---- measurement ---------------------------------------------------------------------------- */
 /* HIP-event timing of kernel launches on the context stream, by tag = kind * 16 + level
  * (level < 16; level 0 for the stand-alone fused ops).  While enabled every launch is bracketed

@@ -83,6 +83,32 @@ function DeviceHierarchy(H::MeshHierarchy; ctx::Context = Context(0))
     return DeviceHierarchy(ctx, H, ops, sms, Ls, r[])
 end
 
+# device vector: aggmg_dev_alloc / aggmg_memcpy_h2d / aggmg_memcpy_d2h
+mutable struct DeviceVector
+    ctx::Context
+    p::Ptr{Cvoid}
+    n::Int
+    function DeviceVector(ctx::Context, n::Integer)
+        r = Ref{Ptr{Cvoid}}(C_NULL)
+        check(ctx.h, ccall((:aggmg_dev_alloc, LIB), Cint, (Handle, Int64, Ref{Ptr{Cvoid}}), ctx.h, 8n, r))
+        v = new(ctx, r[], n)
+        finalizer(x -> ccall((:aggmg_dev_free, LIB), Cint, (Handle, Ptr{Cvoid}), x.ctx.h, x.p), v)
+        return v
+    end
+end
+function DeviceVector(ctx::Context, x::Vector{Float64})
+    v = DeviceVector(ctx, length(x))
+    GC.@preserve x check(ctx.h, ccall((:aggmg_memcpy_h2d, LIB), Cint, (Handle, Ptr{Cvoid}, Ptr{Float64}, Int64),
+        ctx.h, v.p, x, 8length(x)))
+    return v
+end
+function download(v::DeviceVector)
+    out = Vector{Float64}(undef, v.n)
+    GC.@preserve out check(v.ctx.h, ccall((:aggmg_memcpy_d2h, LIB), Cint, (Handle, Ptr{Float64}, Ptr{Cvoid}, Int64),
+        v.ctx.h, out, v.p, 8v.n))
+    return out
+end
+
 # same name, positional / keyword arguments, defaults and return shape as src/solvers.jl:19-20;
 # x0 and b are not mutated, a new Vector is returned
 function multigrid_v_cycle(Hd::DeviceHierarchy, x0::AbstractVector, b::AbstractVector;
@@ -100,6 +126,23 @@ function la.ldiv!(Hd::DeviceHierarchy, b::AbstractVector)
 end
 function la.ldiv!(y::AbstractVector, Hd::DeviceHierarchy, b::AbstractVector)
     y[:] = multigrid_v_cycle(Hd, zeros(size(Hd.H.mStiffness[1], 1)), b); return
+end
+
+# multigrid(H, x0, b, maxiter, tol) -> x, iter, res, err   (src/solvers.jl:116-139) with the loop,
+# the residual norms and the stopping test on the device.  `err` needs the fine-level direct solve
+# of :120: computed on the host only when asked for (exact = true) from the final iterate history,
+# otherwise returned empty.
+function multigrid(Hd::DeviceHierarchy, x0::AbstractVector, b::AbstractVector, maxiter::Integer,
+        tol::AbstractFloat; check_every::Integer = 1)
+    N = length(b)
+    dx0 = DeviceVector(Hd.ctx, Vector{Float64}(x0)); db = DeviceVector(Hd.ctx, Vector{Float64}(b))
+    dx = DeviceVector(Hd.ctx, N)
+    res = zeros(cld(max(maxiter, 1), check_every)); ncyc = Ref{Cint}(0); nchk = Ref{Cint}(0)
+    check(Hd.ctx.h, ccall((:aggmg_multigrid_dev, LIB), Cint,
+        (Handle, Handle, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Float64, Cint, Cint, Cint, Float64, Ptr{Cvoid},
+         Ptr{Float64}, Ref{Cint}, Ref{Cint}),
+        Hd.ctx.h, Hd.h, dx0.p, db.p, maxiter, Float64(tol), check_every, 3, 3, 2.0 / 3.0, dx.p, res, ncyc, nchk))
+    return download(dx), Int(ncyc[]), res[1:nchk[]], Float64[]
 end
 
 end # module

@@ -1551,6 +1551,37 @@ def iterative_smoother_solve(A, smoother, x0, b, maxiter=1000, tol=1e-6, alpha=1
     return x, len(res), res, err
 
 
+def pcg_ldiv(H, b, x0=None, maxiter=50, tol=1e-10, nPre=3, nPost=3, alpha=2.0 / 3.0):
+    """Conjugate gradients preconditioned with ldiv!(y, H, r) (src/solvers.jl:84-92).
+    EXTENSION: the reference has no Krylov loop; this restates the textbook
+    recurrence the device path (aggmg_pcg_dev) follows, operation for operation, so that the
+    two can be compared.  -> (x, iter, res) with res[i] = ||r_i|| of the recurrence."""
+    A = H.mStiffness[0]
+    N = A.shape[0]
+    x = np.zeros(N) if x0 is None else np.array(x0, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    zero = np.zeros(N)
+    nb = np.linalg.norm(b, 2)
+    r = b - csc_matvec(A, x)
+    z = multigrid_v_cycle(H, zero, r, nPre, nPost, alpha)
+    p = z.copy()
+    rz = float(r @ z)
+    res = []
+    for _ in range(maxiter):
+        q = -csc_matvec(A, p)
+        a = rz / (-(float(p @ q)))
+        x = x + a * p
+        r = r + a * q
+        res.append(np.linalg.norm(r, 2))
+        if res[-1] < tol * nb:
+            break
+        z = multigrid_v_cycle(H, zero, r, nPre, nPost, alpha)
+        rz_new = float(r @ z)
+        p = z + (rz_new / rz) * p
+        rz = rz_new
+    return x, len(res), res
+
+
 # --------------------------------------------------------------------------------------
 # Problem builders in the shape of the reference's test scripts (harness rows, SURVEY 8c)
 # --------------------------------------------------------------------------------------

@@ -1,0 +1,123 @@
+"""Device-resident outer solver loops against the CPU oracle:
+aggmg_multigrid_dev (src/solvers.jl:116-139), aggmg_smoother_solve_dev (src/solvers.jl:189-213),
+the reductions behind their stopping tests, and the ldiv!-preconditioned CG extension.
+
+Tolerances: norms / dot products 1e-13 relative (different summation tree than numpy);
+residual histories: the iterates agree to 1e-12 * ||x||, so a residual norm agrees to
+1e-12 * ||A|| ||x|| absolute -- stated as atol relative to ||b|| -- and the iteration counts must
+be equal."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mg():
+    import agglomerationmultigrid1d_amd as mg
+    mg.default_context()
+    return mg
+
+
+def test_dot_and_norm(oracle, mg):
+    ctx = mg.default_context()
+    for n in (0, 1, 7, 255, 256, 257, 4097, 1_000_003):
+        x = oracle.splitmix_normal(n, 3)
+        y = oracle.splitmix_normal(n, 4)
+        dx, dy = ctx.to_device(x), ctx.to_device(y)
+        d = mg.dot(dx, dy)
+        ref = float(np.dot(x, y))
+        assert abs(d - ref) <= 1e-13 * max(np.linalg.norm(x) * np.linalg.norm(y), 1e-300) + 0.0
+        assert abs(mg.norm2(dx) - np.linalg.norm(x)) <= 1e-13 * max(np.linalg.norm(x), 1e-300)
+        assert mg.dot(dx, dy) == d                       # reproducible run to run
+
+
+def test_multigrid_device_loop(oracle, mg):
+    o = oracle
+    Ho, b = o.build_dg_agg_hierarchy(64, p=3, pAgg=1, nAgg=3, first=4)
+    H = mg.MeshHierarchy.from_reference(Ho)
+    nb = np.linalg.norm(b)
+    x0 = np.zeros(len(b))
+    xo, ito, reso, _ = o.multigrid(Ho, x0, b, 200, 1e-10)
+    xg, itg, resg, errg = mg.multigrid(H, x0, b, 200, 1e-10, exact=False)
+    assert itg == ito and errg == []
+    assert np.allclose(resg, reso, rtol=1e-8, atol=1e-11 * nb)
+    assert np.linalg.norm(Ho.mStiffness[0] @ (xg - xo)) <= 1e-11 * nb
+    # checks every 4 cycles: every 4th entry of the same history (same arithmetic), cycle count
+    # rounded up to the check that first meets the tolerance
+    xg4, it4, res4, _ = mg.multigrid(H, x0, b, 200, 1e-10, exact=False, check_every=4)
+    k = len(res4)
+    assert it4 == 4 * k and 4 * (k - 1) < ito <= 4 * k
+    full = mg.multigrid(H, x0, b, it4, 0.0, exact=False)[2]
+    assert np.allclose(res4, full[3::4], rtol=1e-10, atol=1e-13 * nb)
+    # random initial guess, capped iteration count
+    x0r = o.splitmix_normal(len(b), 0)
+    _, ito, reso, _ = o.multigrid(Ho, x0r, b, 7, 1e-30)
+    _, itg, resg, _ = mg.multigrid(H, x0r, b, 7, 1e-30, exact=False)
+    assert itg == ito == 7
+    assert np.allclose(resg, reso, rtol=1e-8, atol=1e-11 * max(nb, reso[0]))
+    # maxiter = 0 returns x0
+    ctx = H.ctx
+    dx, n, res = mg.multigrid_dev(H, ctx.to_device(x0r), ctx.to_device(b), 0, 1e-10)
+    assert n == 0 and res == [] and np.array_equal(dx.download(), x0r)
+
+
+def test_multigrid_device_loop_generic_levels(oracle, mg):
+    """CG hierarchy (generic CSR kernels, host or device coarsest solve)"""
+    o = oracle
+    Ho, b = o.build_cg_hierarchy(32, ps=(4, 2, 1), nDG=1)
+    H = mg.MeshHierarchy.from_reference(Ho)
+    x0 = np.zeros(len(b))
+    xo, ito, reso, _ = o.multigrid(Ho, x0, b, 60, 1e-9)
+    xg, itg, resg, _ = mg.multigrid(H, x0, b, 60, 1e-9, exact=False)
+    assert itg == ito
+    assert np.allclose(resg, reso, rtol=1e-7, atol=1e-11 * np.linalg.norm(b))
+
+
+def test_smoother_solve_device_loop(oracle, mg):
+    o = oracle
+    Ho, b = o.build_dg_agg_hierarchy(48, p=3, pAgg=1, nAgg=1, first=4)
+    A, dg = Ho.mStiffness[0], Ho.mMeshes[0]
+    u0 = np.zeros(len(b))
+    So = o.dg_smoother(dg, A, 'blockJac')
+    Sg = mg.dg_smoother(dg, A, 'blockJac')
+    xo, ito, reso, _ = o.iterative_smoother_solve(A, So, u0, b, maxiter=40, tol=1e-30, alpha=2.0 / 3.0)
+    xg, itg, resg, errg = mg.iterative_smoother_solve(A, Sg, u0, b, maxiter=40, tol=1e-30, alpha=2.0 / 3.0, exact=False)
+    assert itg == ito == 40 and errg == []
+    assert np.allclose(resg, reso, rtol=1e-10, atol=1e-12 * np.linalg.norm(b))
+    assert np.linalg.norm(xg - xo) <= 1e-12 * np.linalg.norm(xo)
+    x5, it5, res5, _ = mg.iterative_smoother_solve(A, Sg, u0, b, maxiter=40, tol=1e-30, alpha=2.0 / 3.0, exact=False,
+                                                  check_every=5)
+    assert it5 == 40 and len(res5) == 8
+    assert np.allclose(res5, np.asarray(resg)[4::5], rtol=1e-10)
+    # point Jacobi on a CG operator (generic kernels)
+    Hc, bc = o.build_cg_hierarchy(32, ps=(2, 1), nDG=1)
+    Ac, cgm = Hc.mStiffness[0], Hc.mMeshes[0]
+    xo, ito, reso, _ = o.iterative_smoother_solve(Ac, o.cg_smoother(cgm, Ac, 'jac'), np.zeros(len(bc)), bc,
+                                                  maxiter=25, tol=1e-30, alpha=0.5)
+    xg, itg, resg, _ = mg.iterative_smoother_solve(Ac, mg.cg_smoother(cgm, Ac, 'jac'), np.zeros(len(bc)), bc,
+                                                   maxiter=25, tol=1e-30, alpha=0.5, exact=False)
+    assert itg == ito
+    assert np.allclose(resg, reso, rtol=1e-10, atol=1e-12 * np.linalg.norm(bc))
+
+
+def test_pcg_with_ldiv_preconditioner(oracle, mg):
+    """extension (no reference loop): device recurrence == the oracle's restatement of it"""
+    o = oracle
+    Ho, b = o.build_dg_agg_hierarchy(128, p=3, pAgg=1, nAgg=3, first=4)
+    H = mg.MeshHierarchy.from_reference(Ho)
+    nb = np.linalg.norm(b)
+    xo, ito, reso = o.pcg_ldiv(Ho, b, maxiter=60, tol=1e-10)
+    xg, itg, resg = mg.pcg(H, b, maxiter=60, tol=1e-10)
+    assert abs(itg - ito) <= 1                      # round-off may move the last crossing by one
+    k = min(itg, ito) - 1
+    assert np.allclose(resg[:k], reso[:k], rtol=1e-4, atol=1e-11 * nb)
+    A = Ho.mStiffness[0]
+    assert np.linalg.norm(A @ xg - b) <= 2e-10 * nb
+    # fewer iterations than the stationary multigrid loop to the same tolerance
+    _, itm, _, _ = mg.multigrid(H, np.zeros(len(b)), b, 200, 1e-10, exact=False)
+    assert itg < itm
+    # warm start from a random guess
+    x0 = o.splitmix_normal(len(b), 9)
+    xg2, it2, res2 = mg.pcg(H, b, x0=x0, maxiter=80, tol=1e-10)
+    assert np.linalg.norm(A @ xg2 - b) <= 2e-10 * nb
