@@ -97,6 +97,7 @@ SYMBOLS = {
     "aggmg_vcycles_dev": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_double, _P]),
     "aggmg_vcycle_down_dev": (c_int, [_P, _P, _P, _P, c_int, c_double]),
     "aggmg_vcycle_up_dev": (c_int, [_P, _P, _P, c_int, c_double, _P]),
+    "aggmg_vcycle_up_split_dev": (c_int, [_P, _P, _P, c_int, c_double, _P, c_int64, c_int64, c_int]),
     "aggmg_hier_coarse_buffers": (c_int, [_P, _P, POINTER(_P), POINTER(_P), POINTER(c_int64)]),
     "aggmg_coarse_plan": (c_int, [_P, _P, POINTER(c_int), POINTER(c_int64), POINTER(c_int), POINTER(c_int64)]),
     "aggmg_coarse_chunk_forward_dev": (c_int, [_P, _P, _P, c_int64, c_int64, _P, _P]),
@@ -104,6 +105,8 @@ SYMBOLS = {
     "aggmg_coarse_chunk_backward_dev": (c_int, [_P, _P, _P, c_int64, c_int64, _P, _P]),
     "aggmg_hier_coarse_info": (c_int, [_P, _P, POINTER(c_int), POINTER(c_int), POINTER(c_double)]),
     "aggmg_hier_last_coarse_ms": (c_int, [_P, _P, POINTER(c_double)]),
+    "aggmg_copy_segments_dev": (c_int, [_P, c_int, POINTER(_P), POINTER(_P), POINTER(c_int64), POINTER(c_int64),
+                                        POINTER(c_int64), POINTER(c_int64)]),
     "aggmg_dot_dev": (c_int, [_P, _P, _P, c_int64, POINTER(c_double)]),
     "aggmg_norm2_dev": (c_int, [_P, _P, c_int64, POINTER(c_double)]),
     "aggmg_residual_norm_dev": (c_int, [_P, _P, _P, _P, POINTER(c_double)]),

@@ -537,6 +537,13 @@ class MeshHierarchy:
         c = self.ctx
         c.check(c.lib.aggmg_vcycle_up_dev(c.handle, self.handle, _ptr(b), int(nPost), float(alpha), _ptr(x_out)))
 
+    def vcycle_up_split_dev(self, b, x_out, head_elems, tail_elem, part, nPost=3, alpha=2.0 / 3.0):
+        """the ascent in three calls (C ABI aggmg_vcycle_up_split_dev): part 0 = coarser levels, part 1 =
+        the fine-level tiles holding elements [0, head_elems) and [tail_elem, ne), part 2 = the rest"""
+        c = self.ctx
+        c.check(c.lib.aggmg_vcycle_up_split_dev(c.handle, self.handle, _ptr(b), int(nPost), float(alpha), _ptr(x_out),
+                                                int(head_elems), int(tail_elem), int(part)))
+
     def coarse_buffers(self):
         """-> (rhs_ptr, sol_ptr, n): device buffers of the coarsest level"""
         r, s_, n = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_int64(0)

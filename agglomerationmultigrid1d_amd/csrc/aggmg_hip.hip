@@ -974,15 +974,38 @@ struct BtdTile {
   static constexpr int TE = EPS * NS;
 };
 
+// Which tiles of a level a launch covers: all of them, only those holding elements [0, head) and
+// [tail, ne) ("ends"), or only the others ("middle").
+struct TileSel {
+  int mode = 0;  // 0 all, 1 ends, 2 middle
+  int64_t head = 0, tail = 0;
+};
+
 template <int M, bool CMP>
-static int launch_btd_t(aggmg_ctx* ctx, FusedArgs a, int halo) {
+static int launch_btd_t(aggmg_ctx* ctx, FusedArgs a, int halo, const TileSel& sel) {
   using T = BtdTile<M, CMP>;
   const int align = (a.lf_out || a.ld_out) ? a.rho_out : 1;
   int owned = ((T::TE - 2 * halo) / align) * align;
   if (owned <= 0) return fail(ctx, AGGMG_ERR_UNSUPPORTED, "fused tile too small for the requested halo");
   a.owned = owned;
   a.halo_left = halo;
-  const int64_t ntiles = (a.lv.ne + owned - 1) / owned;
+  int64_t ntiles = (a.lv.ne + owned - 1) / owned;
+  a.tile_split = 0;
+  a.tile_skip = 0;
+  if (sel.mode != 0) {
+    const int64_t head = std::min(std::max<int64_t>(sel.head, 0), a.lv.ne);
+    const int64_t tail = std::min(std::max(sel.tail, head), a.lv.ne);
+    const int64_t tA = std::min(ntiles, (head + owned - 1) / owned);       // tiles [0, tA) hold [0, head)
+    const int64_t tB = std::min(ntiles - tA, ntiles - tail / owned);       // the last tB tiles hold [tail, ne)
+    if (sel.mode == 1) {
+      a.tile_split = (int)tA;
+      a.tile_skip = ntiles - tA - tB;
+      ntiles = tA + tB;
+    } else {
+      a.tile_skip = tA;
+      ntiles = ntiles - tA - tB;
+    }
+  }
   if (ntiles == 0) return AGGMG_OK;
   const size_t lds = (size_t)2 * (T::TE + 2) * M * sizeof(double);
   constexpr bool kGrp = (CMP && (M == 2 || M == 4 || M == 8)) || (!CMP && (M == 2 || M == 4));
@@ -1005,17 +1028,17 @@ static int btd_max_halo() {
   return (BtdTile<M, CMP>::TE - 8) / 2;
 }
 
-static int launch_btd(aggmg_ctx* ctx, const BtdDev& b, const FusedArgs& a, int halo) {
-#define CASE(MM)                                        \
-  case MM:                                              \
-    return b.cmp ? launch_btd_t<MM, true>(ctx, a, halo) \
-                 : launch_btd_t<MM, false>(ctx, a, halo);
+static int launch_btd(aggmg_ctx* ctx, const BtdDev& b, const FusedArgs& a, int halo, const TileSel& sel = TileSel()) {
+#define CASE(MM)                                             \
+  case MM:                                                   \
+    return b.cmp ? launch_btd_t<MM, true>(ctx, a, halo, sel) \
+                 : launch_btd_t<MM, false>(ctx, a, halo, sel);
 #define CASE_C(MM) \
   case MM:         \
-    return launch_btd_t<MM, true>(ctx, a, halo);
+    return launch_btd_t<MM, true>(ctx, a, halo, sel);
   switch (b.m) {
     case 1:
-      return launch_btd_t<1, false>(ctx, a, halo);
+      return launch_btd_t<1, false>(ctx, a, halo, sel);
       CASE(2) CASE(3) CASE(4) CASE(5) CASE_C(6) CASE_C(7) CASE_C(8) CASE_C(9)
     default:
       return fail(ctx, AGGMG_ERR_UNSUPPORTED, "block size not instantiated for the fused kernel");
@@ -2062,10 +2085,12 @@ static int vcycle_down(aggmg_ctx* ctx, aggmg_hier* h, const double* x0, const do
 }
 
 // ---- ascend (src/solvers.jl:41-47): expects the coarsest solution in lv[n-1].u[0] ---------------
+// sel (fine level only): which tiles of the level-0 launch to run; with a selection the coarser
+// levels are skipped (the caller ran them with k_last = 1)
 static int vcycle_up(aggmg_ctx* ctx, aggmg_hier* h, const double* b, int nPost, double alpha, double* x_out,
-                     int k_last = 0) {
+                     int k_last = 0, const TileSel& sel = TileSel()) {
   const int n = (int)h->lv.size();
-  for (int k = n - 2; k >= k_last; --k) {
+  for (int k = (sel.mode != 0 ? 0 : n - 2); k >= k_last; --k) {
     Level& l = h->lv[k];
     Level& c = h->lv[k + 1];
     const double* rhs = k == 0 ? b : l.rhs;
@@ -2084,8 +2109,10 @@ static int vcycle_up(aggmg_ctx* ctx, aggmg_hier* h, const double* b, int nPost, 
       a.mc_in = l.tb->mc;
       a.rho_in = l.tb->rho;
       ProfScope ps(ctx, AGGMG_KIND_FUSED_UP, k);
-      CHECK(launch_btd(ctx, *l.S->btd, a, std::max(nPost, 0)));
+      CHECK(launch_btd(ctx, *l.S->btd, a, std::max(nPost, 0), k == 0 ? sel : TileSel()));
     } else {
+      if (k == 0 && sel.mode != 0)
+        return fail(ctx, AGGMG_ERR_UNSUPPORTED, "split ascent needs the fused block-tridiagonal fine level");
       {
         ProfScope ps(ctx, AGGMG_KIND_PROLONG, k);
         CHECK(launch_csr<kSpmvAdd>(ctx, l.L->csr, uc, nullptr, nullptr, 0.0, l.u[0]));
@@ -2242,6 +2269,27 @@ extern "C" int aggmg_vcycle_up_dev(aggmg_ctx* ctx, aggmg_hier* h, const double* 
   if (h->lv.size() < 2) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_vcycle_up_dev: needs at least two levels");
   if (x_out == b) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_vcycle_up_dev: x_out must not alias b");
   return vcycle_up(ctx, h, b, nPost, alpha, x_out);
+}
+
+// The ascent in three calls: part 0 the coarser levels (n-2 .. 1), part 1 the fine-level tiles that
+// hold elements [0, head_elems) and [tail_elem, ne), part 2 the remaining fine-level tiles.  Parts
+// 1 and 2 are independent of each other (tiles are), so they may run on different streams; the
+// result is bitwise that of aggmg_vcycle_up_dev.
+extern "C" int aggmg_vcycle_up_split_dev(aggmg_ctx* ctx, aggmg_hier* h, const double* b, int nPost, double alpha,
+                                         double* x_out, int64_t head_elems, int64_t tail_elem, int part) {
+  CHECK(vcycle_args(ctx, h, b, x_out, nPost, 0));
+  if (h->lv.size() < 2) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_vcycle_up_split_dev: needs at least two levels");
+  if (x_out == b) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_vcycle_up_split_dev: x_out must not alias b");
+  if (part < 0 || part > 2) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_vcycle_up_split_dev: part is 0, 1 or 2");
+  Level& l = h->lv[0];
+  if (!(l.S && l.S->btd && l.S->A == l.A && l.tb && nPost <= btd_max_sweeps(*l.S->btd, 0)))
+    return fail(ctx, AGGMG_ERR_UNSUPPORTED, "split ascent needs the fused block-tridiagonal fine level");
+  if (part == 0) return h->lv.size() > 2 ? vcycle_up(ctx, h, b, nPost, alpha, x_out, 1) : AGGMG_OK;
+  TileSel sel;
+  sel.mode = part;  // 1 ends, 2 middle
+  sel.head = head_elems;
+  sel.tail = tail_elem;
+  return vcycle_up(ctx, h, b, nPost, alpha, x_out, 0, sel);
 }
 
 extern "C" int aggmg_hier_coarse_buffers(aggmg_ctx* ctx, aggmg_hier* h, void** rhs_dev, void** sol_dev,
@@ -2535,6 +2583,37 @@ extern "C" int aggmg_pcg_dev(aggmg_ctx* ctx, aggmg_hier* h, const double* b, dou
     HIPCHK(hipMemcpyAsync(sc + 0, sc + 2, sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
   }
   HIPCHK(hipStreamSynchronize(ctx->stream));
+  return AGGMG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// interface packing for element-partitioned runs
+// ---------------------------------------------------------------------------------------------
+extern "C" int aggmg_copy_segments_dev(aggmg_ctx* ctx, int nseg, const double* const* src, double* const* dst,
+                                       const int64_t* rows, const int64_t* cols, const int64_t* src_ld,
+                                       const int64_t* dst_ld) {
+  if (!ctx) return AGGMG_ERR_ARGUMENT;
+  if (nseg < 0 || nseg > 4 || (nseg && (!src || !dst || !rows || !cols || !src_ld || !dst_ld)))
+    return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_copy_segments_dev: 0..4 segments, no NULL arrays");
+  CopySegs S{};
+  int64_t most = 0;
+  for (int g = 0; g < nseg; ++g) {
+    if (rows[g] < 0 || cols[g] < 0 || (rows[g] * cols[g] > 0 && (!src[g] || !dst[g])) ||
+        (rows[g] > 1 && (src_ld[g] < cols[g] || dst_ld[g] < cols[g])))
+      return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_copy_segments_dev: bad segment");
+    S.src[g] = src[g];
+    S.dst[g] = dst[g];
+    S.rows[g] = rows[g];
+    S.cols[g] = cols[g];
+    S.src_ld[g] = src_ld[g];
+    S.dst_ld[g] = dst_ld[g];
+    most = std::max(most, rows[g] * cols[g]);
+  }
+  if (nseg == 0 || most == 0) return AGGMG_OK;
+  HIPCHK(hipSetDevice(ctx->device));
+  const unsigned gx = (unsigned)std::min<int64_t>((most + kThreads - 1) / kThreads, 4096);
+  hipLaunchKernelGGL(copy_segments_kernel, dim3(gx, (unsigned)nseg), dim3(kThreads), 0, ctx->stream, S);
+  HIPCHK(hipGetLastError());
   return AGGMG_OK;
 }
 

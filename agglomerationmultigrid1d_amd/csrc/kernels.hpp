@@ -166,6 +166,25 @@ __global__ __launch_bounds__(kThreads) void axpy_scaled_kernel(int64_t n, const 
 }
 
 // ------------------------------------------------------------------------------------------
+// up to four strided 2-D copies in one launch (interface packing / unpacking around the
+// collectives of element-partitioned runs: one launch instead of one per slice)
+// ------------------------------------------------------------------------------------------
+struct CopySegs {
+  const double* src[4];
+  double* dst[4];
+  int64_t rows[4], cols[4], src_ld[4], dst_ld[4];
+};
+
+__global__ __launch_bounds__(kThreads) void copy_segments_kernel(CopySegs S) {
+  const int g = blockIdx.y;
+  const int64_t n = S.rows[g] * S.cols[g];
+  for (int64_t t = (int64_t)blockIdx.x * kThreads + threadIdx.x; t < n; t += (int64_t)gridDim.x * kThreads) {
+    const int64_t i = t / S.cols[g], j = t - i * S.cols[g];
+    S.dst[g][i * S.dst_ld[g] + j] = S.src[g][i * S.src_ld[g] + j];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // outer-solver vector kernels (multigrid / iterative_smoother_solve loops, PCG): the scalars stay
 // on the device, the host only reads the residual norm it needs for the stopping test
 // ------------------------------------------------------------------------------------------
@@ -277,7 +296,16 @@ struct FusedArgs {
   // tiling
   int owned;      // owned elements per tile (multiple of rho_out)
   int halo_left;  // elements of halo on the left of the owned range
+  // tile of workgroup b = b + (b >= tile_split ? tile_skip : 0): a launch may cover the tiles at
+  // the two ends of the level, or the ones in between (element-partitioned runs produce the
+  // interface elements first and exchange them under the interior launch)
+  int tile_split;
+  int64_t tile_skip;
 };
+
+__device__ __forceinline__ int64_t fused_tile(const FusedArgs& a) {
+  return (int64_t)blockIdx.x + ((int)blockIdx.x >= a.tile_split ? a.tile_skip : 0);
+}
 
 // streaming (read-once) operator data: optionally non-temporal so it does not displace the
 // re-read halo / coarse vectors in L2
@@ -332,7 +360,7 @@ __global__ __launch_bounds__(NT) void btd_fused_kernel(FusedArgs a) {
   const int le = tid / M;
   const int i = tid - le * M;
   const int64_t ne = a.lv.ne;
-  const int64_t e0 = (int64_t)blockIdx.x * a.owned - a.halo_left;  // element at x = 0
+  const int64_t e0 = fused_tile(a) * a.owned - a.halo_left;  // element at x = 0
 
   if (tid < M) {
     buf0[-M + tid] = 0.0;
@@ -632,7 +660,7 @@ __global__ __launch_bounds__(NT) void btd_fused_kernel(FusedArgs a) {
 
   const int rho = a.rho_out, mc = a.mc_out;
   const int ncoarse = a.owned / rho;  // owned coarse elements of this tile
-  const int64_t J0 = ((int64_t)blockIdx.x * a.owned) / rho;
+  const int64_t J0 = (fused_tile(a) * a.owned) / rho;
   const int64_t nec = ne / rho;
   if (pre2) {
     // ---- restriction, two coarse modes: every row thread forms its two products with the

@@ -197,14 +197,38 @@ class DistributedVCycle:
         o0 = gl * m
         o1 = o0 + (L.own[level][1] - L.own[level][0]) * m
         send, recv = self._xbuf(level)
-        self.c.torch.cat((x[o0:o0 + wm], x[o1 - wm:o1]), out=send)
+        self._copy([(send[:wm], x[o0:o0 + wm]), (send[wm:], x[o1 - wm:o1])])
         self.c.all_gather(recv, send)
         self.exchanges += 1
+        self._copy(self._ghost_pairs(x, recv, level))
+
+    def _ghost_pairs(self, x, recv, level):
+        """(dst, src) slices that move the neighbours' interface DoFs from an all-gathered
+        buffer into the ghost entries of x"""
+        L = self.L
+        m, W = L.m[level], L.W[level]
+        gl, gr = L.ghosts(level)
+        wm = W * m
+        o0 = gl * m
+        o1 = o0 + (L.own[level][1] - L.own[level][0]) * m
         r = L.rank
+        pairs = []
         if gl:   # left neighbour's last W elements
-            x[:o0].copy_(recv[(r - 1) * 2 * wm + wm:(r - 1) * 2 * wm + 2 * wm])
+            pairs.append((x[:o0], recv[(r - 1) * 2 * wm + wm:(r - 1) * 2 * wm + 2 * wm]))
         if gr:
-            x[o1:].copy_(recv[(r + 1) * 2 * wm:(r + 1) * 2 * wm + wm])
+            pairs.append((x[o1:], recv[(r + 1) * 2 * wm:(r + 1) * 2 * wm + wm]))
+        return pairs
+
+    def _copy(self, pairs):
+        """dst <- src for a few (dst, src) tensor pairs: ONE launch on the HIP engine
+        (aggmg_copy_segments_dev), plain copies otherwise"""
+        if not pairs:
+            return
+        if hasattr(self.e, "copy_segments"):
+            self.e.copy_segments(pairs)
+        else:
+            for d, s_ in pairs:
+                d.copy_(s_)
 
     def _xbuf(self, level):
         if level not in self._bufs:
@@ -212,13 +236,53 @@ class DistributedVCycle:
             self._bufs[level] = (self.e.new(2 * wm), self.e.new(2 * wm * self.L.world))
         return self._bufs[level]
 
-    def vcycle(self, x0, b, x_out, nPre=3, nPost=3, alpha=2.0 / 3.0, x0_ghosts_valid=False):
+    # ---- interface exchange of the NEXT cycle's x0 under the fine-level ascent -----------------
+    def _begin_exchange(self, x, launch_ends):
+        """On the side stream: the fine-level tiles at the two ends of the local domain
+        (launch_ends), then pack and all-gather x's interface elements -- while the main stream
+        smooths the middle.  Completed by _finish_exchange(x)."""
+        L = self.L
+        m, W = L.m[0], L.W[0]
+        gl, _ = L.ghosts(0)
+        wm = W * m
+        o0 = gl * m
+        o1 = o0 + (L.own[0][1] - L.own[0][0]) * m
+        send, recv = self._xbuf(0)
+        with self.e.side_stream():            # starts after everything enqueued on the main stream so far
+            launch_ends()
+            self.e.mark_side_ends()
+            send[:wm].copy_(x[o0:o0 + wm])    # plain copies: off the critical path
+            send[wm:].copy_(x[o1 - wm:o1])
+            self.c.all_gather(recv, send)
+        self.exchanges += 1
+        self._pending = x
+
+    def _finish_exchange(self, x):
+        self.e.wait_side_stream()             # main stream waits for the all-gather
+        self._pending = None
+        self._copy(self._ghost_pairs(x, self._xbuf(0)[1], 0))
+
+    def vcycle(self, x0, b, x_out, nPre=3, nPost=3, alpha=2.0 / 3.0, x0_ghosts_valid=False, overlap_next=False):
         """x0, b, x_out: local vectors (owned + ghosts).  b must be valid on the whole local domain
         (set once with exchange_ghosts or generated that way); x0's ghosts are refreshed here.  On
-        return the owned part of x_out is the V-cycle result; its ghosts are not."""
+        return the owned part of x_out is the V-cycle result; its ghosts are not.
+
+        overlap_next=True (the caller will pass x_out as the next cycle's x0, as the loop of
+        multigrid does, src/solvers.jl:124-126): the fine-level ascent produces the interface
+        elements of x_out first and their all-gather runs on a second stream under the rest of
+        that launch; the next vcycle(x_out, ...) only waits for it and fills the ghosts.  Same
+        arithmetic, one collective off the critical path."""
         L = self.L
         if nPre > L.nPre or nPost > L.nPost:
             raise ValueError("halo widths were sized for fewer sweeps")
+        pending = getattr(self, "_pending", None)
+        if pending is not None:
+            if pending is x0:
+                self._finish_exchange(x0)
+                x0_ghosts_valid = True
+            else:                              # stale prefetch: drain it, then exchange as usual
+                self.e.wait_side_stream()
+                self._pending = None
         if not x0_ghosts_valid:
             self.exchange_ghosts(x0)
         self.e.down(x0, b, nPre, alpha)
@@ -232,12 +296,12 @@ class DistributedVCycle:
             blo, bhi = L.own[nc]
             clo = blo >> self._q
             partR, partL = e.coarse_forward(own, blo, bhi)
-            self.c.torch.cat((partR[clo * mc:clo * mc + cnt], partL[(clo + 1) * mc:(clo + 1) * mc + cnt]), out=self._send2)
+            self._copy([(self._send2[:cnt], partR[clo * mc:clo * mc + cnt]),
+                        (self._send2[cnt:], partL[(clo + 1) * mc:(clo + 1) * mc + cnt])])
             self.c.all_gather(self._recv2, self._send2)
             self.exchanges += 1
             rv = self._recv2.view(P, 2, cnt)
-            partR[:P * cnt].view(P, cnt).copy_(rv[:, 0])
-            partL[mc:mc + P * cnt].view(P, cnt).copy_(rv[:, 1])
+            self._copy([(partR[:P * cnt].view(P, cnt), rv[:, 0]), (partL[mc:mc + P * cnt].view(P, cnt), rv[:, 1])])
             e.coarse_boundary_solve()
             sol_c = e.coarse_solution()
             e.coarse_backward(own, blo, bhi, sol_c[gl * mc:gl * mc + self._own_c])
@@ -248,12 +312,25 @@ class DistributedVCycle:
             sol = self.e.coarse_solve(self._rhs_global)
             lo, hi = L.loc[nc]
             self.e.set_coarse_solution(sol[lo * mc:hi * mc])
-        self.e.up(b, x_out, nPost, alpha)
+        if overlap_next and L.world > 1 and L.W[0] > 0 and getattr(self.e, "can_split_up", lambda n: False)(nPost):
+            gl0, _ = L.ghosts(0)
+            head = gl0 + L.W[0]                                   # local elements [0, head): left ghosts + first W owned
+            tail = gl0 + (L.own[0][1] - L.own[0][0]) - L.W[0]     # [tail, end): last W owned + right ghosts
+            self.e.up_split(b, x_out, nPost, alpha, head, tail, 0)       # coarser levels
+            self._begin_exchange(x_out, lambda: self.e.up_split(b, x_out, nPost, alpha, head, tail, 1))
+            self.e.up_split(b, x_out, nPost, alpha, head, tail, 2)       # the middle of the fine level
+            self.e.wait_side_ends()                                     # x_out is whole on the main stream again
+        else:
+            self.e.up(b, x_out, nPost, alpha)
 
 
 # ------------------------------------------------------------------------------------------
 # HIP engine
 # ------------------------------------------------------------------------------------------
+def main_stream_handle(eng):
+    return eng._main_handle
+
+
 class _DevView:
     """zero-copy torch view of a device buffer owned by libaggmg_hip"""
 
@@ -276,7 +353,8 @@ class HipEngine:
         self.torch = torch
         self.H, self.Hc, self.ctx = H_local, H_coarse, ctx
         self.dev = torch.device("cuda", ctx.device)
-        ctx.set_stream(torch.cuda.current_stream(self.dev).cuda_stream)
+        self._main_handle = torch.cuda.current_stream(self.dev).cuda_stream
+        ctx.set_stream(self._main_handle)
         rp, sp_, n = H_local.coarse_buffers()
         self._rhs_c = torch.as_tensor(_DevView(rp, n), device=self.dev)
         self._sol_c = torch.as_tensor(_DevView(sp_, n), device=self.dev)
@@ -336,6 +414,75 @@ class HipEngine:
 
     def up(self, b, x_out, nPost, alpha):
         self.H.vcycle_up_dev(b, x_out, nPost, alpha)
+
+    # ---- split ascent + second stream (interface exchange under the fine-level launch) --------
+    def can_split_up(self, nPost):
+        # opt-in: on one GPU with loop-back collectives the second stream's event hand-offs cost
+        # ~25 us per cycle, about what one small RCCL all-gather is expected to take
+        return bool(self.H.structured_levels()[0]) and os.environ.get("AGGMG_DIST_OVERLAP", "0") == "1"
+
+    def up_split(self, b, x_out, nPost, alpha, head, tail, part):
+        # the library launches on whatever stream is current in torch (side_stream() switches both)
+        self.H.vcycle_up_split_dev(b, x_out, head, tail, part, nPost, alpha)
+
+    def mark_side_ends(self):
+        self._ends_done.record(self._side)
+
+    def wait_side_ends(self):
+        self.torch.cuda.current_stream(self.dev).wait_event(self._ends_done)
+
+    def side_stream(self):
+        """context: torch ops and collectives issued inside go to a second stream that first waits
+        for everything enqueued on the main stream so far; leaving records the completion event"""
+        torch = self.torch
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=self.dev)
+            self._side_done = torch.cuda.Event()
+            self._ends_done = torch.cuda.Event()
+            self._main_mark = torch.cuda.Event()
+        eng = self
+
+        class _Ctx:
+            def __enter__(self_):
+                main = torch.cuda.current_stream(eng.dev)
+                eng._main_mark.record(main)
+                eng._side.wait_event(eng._main_mark)
+                self_.cm = torch.cuda.stream(eng._side)
+                self_.cm.__enter__()
+                eng.ctx.set_stream(eng._side.cuda_stream)      # library launches follow
+
+            def __exit__(self_, *exc):
+                eng._side_done.record(eng._side)
+                eng.ctx.set_stream(main_stream_handle(eng))
+                return self_.cm.__exit__(*exc)
+
+        return _Ctx()
+
+    def wait_side_stream(self):
+        if getattr(self, "_side", None) is not None:
+            self.torch.cuda.current_stream(self.dev).wait_event(self._side_done)
+
+    def copy_segments(self, pairs):
+        """dst <- src for up to four (dst, src) pairs per launch; 1-D contiguous or 2-D views with
+        unit inner stride (aggmg_copy_segments_dev)"""
+        c = self.ctx
+        for i in range(0, len(pairs), 4):
+            grp = pairs[i:i + 4]
+            n = len(grp)
+            src = (ctypes.c_void_p * n)()
+            dst = (ctypes.c_void_p * n)()
+            rows, cols = (ctypes.c_int64 * n)(), (ctypes.c_int64 * n)()
+            sld, dld = (ctypes.c_int64 * n)(), (ctypes.c_int64 * n)()
+            for g, (d, s_) in enumerate(grp):
+                if d.shape != s_.shape or d.dim() not in (1, 2) or d.stride(-1) != 1 or s_.stride(-1) != 1:
+                    raise ValueError("copy_segments: equal shapes, 1-D or 2-D, unit inner stride")
+                src[g], dst[g] = s_.data_ptr(), d.data_ptr()
+                if d.dim() == 1:
+                    rows[g], cols[g], sld[g], dld[g] = 1, d.numel(), d.numel(), d.numel()
+                else:
+                    rows[g], cols[g] = d.shape[0], d.shape[1]
+                    sld[g], dld[g] = max(s_.stride(0), d.shape[1]), max(d.stride(0), d.shape[1])
+            c.check(c.lib.aggmg_copy_segments_dev(c.handle, n, src, dst, rows, cols, sld, dld))
 
 
 def build_local_uniform(n, p, pAgg, ratios, layout, ctx, comm):
@@ -412,8 +559,10 @@ def bench_main(args, rank, world, local_rank, nPre, nPost, alpha):
     N = n * (args.p + 1)
 
     src, dst = xa, xb
+    # every cycle's output is the next cycle's x0 (the loop of multigrid, src/solvers.jl:124-126):
+    # its interface exchange is issued under the fine-level ascent (AGGMG_DIST_OVERLAP=0: in line)
     for _ in range(args.warmup):
-        dv.vcycle(src, b, dst, nPre, nPost, alpha)
+        dv.vcycle(src, b, dst, nPre, nPost, alpha, overlap_next=True)
         src, dst = dst, src
     torch.cuda.synchronize()
     comm.barrier()
@@ -421,7 +570,7 @@ def bench_main(args, rank, world, local_rank, nPre, nPost, alpha):
     ctx.profile_enable(2)   # events around the dominant kernel only (an event pair costs ~7 us of stream time)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        dv.vcycle(src, b, dst, nPre, nPost, alpha)
+        dv.vcycle(src, b, dst, nPre, nPost, alpha, overlap_next=True)
         src, dst = dst, src
     torch.cuda.synchronize()
     comm.barrier()

@@ -222,7 +222,7 @@ def main():
     import agglomerationmultigrid1d_amd as mg
     from agglomerationmultigrid1d_amd.uniform import UniformDgAggHierarchy, build_device_hierarchy
 
-    if world > 1:
+    if world > 1 or os.environ.get("AGGMG_FORCE_DIST") == "1":   # (forced: smoke of the N > 1 code path on one rank)
         from agglomerationmultigrid1d_amd import distributed as dist_mg
         return dist_mg.bench_main(args, rank, world, local_rank, nPre, nPost, alpha)
 

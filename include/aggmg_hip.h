@@ -159,6 +159,14 @@ int aggmg_vcycle_down_dev(aggmg_ctx* ctx, aggmg_hier* h, const double* x0, const
                           double alpha);
 int aggmg_vcycle_up_dev(aggmg_ctx* ctx, aggmg_hier* h, const double* b, int nPost, double alpha,
                         double* x_out);
+/* The ascent in three calls so that a partitioned run can exchange the interface elements of
+ * x_out while the rest of the fine level is still being smoothed: part 0 = the coarser levels,
+ * part 1 = the fine-level tiles holding elements [0, head_elems) and [tail_elem, ne), part 2 = the
+ * remaining fine-level tiles.  Parts 1 and 2 do not depend on each other (they may be issued on
+ * different streams, aggmg_set_stream); together they are bitwise aggmg_vcycle_up_dev.
+ * AGGMG_ERR_UNSUPPORTED unless the fine level runs the fused block-tridiagonal kernel. */
+int aggmg_vcycle_up_split_dev(aggmg_ctx* ctx, aggmg_hier* h, const double* b, int nPost, double alpha,
+                              double* x_out, int64_t head_elems, int64_t tail_elem, int part);
 int aggmg_hier_coarse_buffers(aggmg_ctx* ctx, aggmg_hier* h, void** rhs_dev, void** sol_dev,
                               int64_t* n);
 /* The device coarsest solve phase by phase, for element-partitioned runs: block cyclic reduction
@@ -183,6 +191,14 @@ int aggmg_hier_coarse_info(aggmg_ctx* ctx, const aggmg_hier* h, int* on_device, 
 /* Milliseconds the last aggmg_vcycle* call spent in the coarsest direct solve (host path:
  * D2H + solve + H2D, measured with the host clock). */
 int aggmg_hier_last_coarse_ms(aggmg_ctx* ctx, const aggmg_hier* h, double* ms);
+
+/* Up to four strided 2-D copies of device doubles in ONE launch:
+ * dst[g][i * dst_ld[g] + j] = src[g][i * src_ld[g] + j], i < rows[g], j < cols[g].  Packs / unpacks
+ * the interface DoFs around the all-gathers of an element-partitioned run (the reference has no
+ * counterpart: it is single-process). */
+int aggmg_copy_segments_dev(aggmg_ctx* ctx, int nseg, const double* const* src, double* const* dst,
+                            const int64_t* rows, const int64_t* cols, const int64_t* src_ld,
+                            const int64_t* dst_ld);
 
 /* ---- outer solver loops, device-resident -------------------------------------- */
 /* x . y and ||x||_2 of device vectors (fixed reduction tree: reproducible run to run). */

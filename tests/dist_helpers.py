@@ -55,6 +55,27 @@ class NumpyEngine:
     def set_coarse_solution(self, t):
         self.u[-1] = t.numpy().copy()
 
+    # split ascent / second stream: the schedule's bookkeeping is exercised, the work is not split
+    def can_split_up(self, nPost):
+        return True
+
+    def up_split(self, b, x_out, nPost, alpha, head, tail, part):
+        if part == 1:     # everything with the "ends" call: it is the one the exchange depends on
+            self.up(b, x_out, nPost, alpha)
+
+    def mark_side_ends(self):
+        pass
+
+    def wait_side_ends(self):
+        pass
+
+    def side_stream(self):
+        import contextlib
+        return contextlib.nullcontext()
+
+    def wait_side_stream(self):
+        pass
+
     def up(self, b, x_out, nPost, alpha):
         o, H = self.o, self.H
         for k in range(len(H.mStiffness) - 2, -1, -1):

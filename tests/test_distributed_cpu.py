@@ -114,3 +114,60 @@ def test_thin_halo_is_detected():
     the widths of halo_widths() are necessary, not just sufficient"""
     errs = [e for _, e, _, _ in run(2, 512, 3, (4, 2, 2), 3, 3, shrink=1)]
     assert max(errs) > 1e-14     # no longer equal to the last bits (errors enter damped, but they enter)
+
+
+def _worker_overlap(rank, world, port, n, p, ratios, q):
+    """two cycles, the second one's x0 interface exchange prefetched by the first
+    (overlap_next=True): schedule bookkeeping of DistributedVCycle on the CPU engine"""
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]
+    import aggmg_oracle as o
+    from dist_helpers import LocalRef, NumpyEngine
+    from agglomerationmultigrid1d_amd import distributed as D
+    from agglomerationmultigrid1d_amd.uniform import UniformDgAggHierarchy
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ms = [p + 1] + [2] * len(ratios)
+        layout = D.RankLayout(n, ratios, ms, world, rank, 3, 3)
+        U = UniformDgAggHierarchy(n, p=p, pAgg=1, ratios=ratios, elem_range=layout.loc[0])
+        Ug = UniformDgAggHierarchy(n, p=p, pAgg=1, ratios=ratios)
+        eng = NumpyEngine(o, LocalRef(o, U), Ug.stiffness_csc(Ug.nlevels - 1))
+        dv = D.DistributedVCycle(eng, layout, D.Comm(world, rank))
+        b = torch.from_numpy(U.rhs().copy())
+        x = eng.new(layout.local_dofs(0))
+        y = eng.new(layout.local_dofs(0))
+        z = eng.new(layout.local_dofs(0))
+        dv.vcycle(x, b, y, overlap_next=True)
+        assert dv._pending is y
+        dv.vcycle(y, b, z, overlap_next=True)          # consumes the prefetched exchange
+        n_after_two = dv.exchanges
+        dv.vcycle(x, b, y)                             # a different x0: the stale prefetch is drained
+        assert dv._pending is None
+        Hg = LocalRef(o, Ug)
+        xr = o.multigrid_v_cycle(Hg, np.zeros(n * (p + 1)), Ug.rhs())
+        xr2 = o.multigrid_v_cycle(Hg, xr, Ug.rhs())
+        lo, hi = layout.own[0]
+        sl = layout.owned_slice(0)
+        e2 = float(np.max(np.abs(z.numpy()[sl] - xr2[lo * (p + 1):hi * (p + 1)])) / np.max(np.abs(xr2)))
+        e1 = float(np.max(np.abs(y.numpy()[sl] - xr[lo * (p + 1):hi * (p + 1)])) / np.max(np.abs(xr)))
+        q.put((rank, e1, e2, n_after_two, dv.exchanges))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_overlapped_interface_exchange_bookkeeping():
+    world, n, p, ratios = 2, 256, 3, (4, 2, 2)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=_worker_overlap, args=(r, world, port, n, p, ratios, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    for pr in procs:
+        pr.join(300)
+    assert all(pr.exitcode == 0 for pr in procs), [pr.exitcode for pr in procs]
+    for rank, e1, e2, n2, n3 in sorted(q.get() for _ in range(world)):
+        assert e1 < 1e-12 and e2 < 1e-12, (rank, e1, e2)
+        # replicated coarsest solve at this size: (x0 + rhs gather + prefetch) + (rhs gather + prefetch)
+        assert n2 == 5 and n3 == 7

@@ -235,3 +235,36 @@ def test_randomized_hierarchies(oracle, mg, seed):
     # then relative to ||A x||, not to the initial residual
     scale = max(np.linalg.norm(b - A @ x0), np.linalg.norm(b), np.linalg.norm(A @ xr))
     assert np.linalg.norm(A @ (dz.download() - xr)) <= 3 * TOL * scale, (n, p, pAgg, first, nAgg, nPre, nPost, alpha)
+
+
+def test_split_ascent_is_bitwise_the_plain_ascent(oracle, mg):
+    """aggmg_vcycle_up_split_dev (coarser levels, fine-level tiles at the two ends, the middle) against
+    aggmg_vcycle_up_dev, for several end widths incl. empty and everything"""
+    from agglomerationmultigrid1d_amd import _lib
+    from agglomerationmultigrid1d_amd.uniform import UniformDgAggHierarchy, block_tridiag_to_csc
+    U = UniformDgAggHierarchy(4096, p=3, pAgg=1, ratios=(4, 2, 2))
+    ctx = mg.default_context()
+    n = U.nlevels
+    ops = [mg.DeviceOperator(U.stiffness_csc(k), _lib.OP_STIFFNESS, ctx) for k in range(n)]
+    sms = [mg.BlockJacobi(ops[k], U.descriptor(k).mBlockInds, ctx) for k in range(n - 1)]
+    Ls = [mg.DeviceOperator(U.interpolation_csc(k), _lib.OP_TRANSFER, ctx) for k in range(n - 1)]
+    H = mg.MeshHierarchy([U.descriptor(k) for k in range(n)], ops, sms, Ls, ctx=ctx, keep_host=False,
+                         coarse_mode=_lib.COARSE_EXTERNAL)
+    N = 4096 * 4
+    b = ctx.to_device(U.rhs())
+    x0 = ctx.to_device(oracle.splitmix_normal(N, 5))
+    H.vcycle_down_dev(x0, b)
+    rp, sp_, nc = H.coarse_buffers()
+    sol = oracle.splitmix_normal(nc, 6)
+    ctx.check(ctx.lib.aggmg_memcpy_h2d(ctx.handle, sp_, sol.ctypes.data, nc * 8))
+    ref = ctx.alloc(N)
+    H.vcycle_up_dev(b, ref)
+    ref = ref.download()
+    for head, tail in ((80 + 80, 4096 - 160), (0, 4096), (1, 4095), (4096, 4096), (0, 0), (2000, 2100), (3000, 100)):
+        H.vcycle_down_dev(x0, b)
+        ctx.check(ctx.lib.aggmg_memcpy_h2d(ctx.handle, sp_, sol.ctypes.data, nc * 8))
+        out = ctx.to_device(np.full(N, np.nan))
+        H.vcycle_up_split_dev(b, out, head, tail, 0)
+        H.vcycle_up_split_dev(b, out, head, tail, 2)     # the order of the two fine-level parts is free
+        H.vcycle_up_split_dev(b, out, head, tail, 1)
+        assert np.array_equal(out.download(), ref), (head, tail)

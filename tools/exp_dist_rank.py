@@ -94,14 +94,14 @@ def main():
     xb = engine.new(layout.local_dofs(0))
     src, dst = xa, xb
     for _ in range(args.warmup):
-        dv.vcycle(src, b, dst, nPre, nPost, alpha)
+        dv.vcycle(src, b, dst, nPre, nPost, alpha, overlap_next=True)
         src, dst = dst, src
     torch.cuda.synchronize()
     if args.profile:
         ctx.profile_enable(1)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        dv.vcycle(src, b, dst, nPre, nPost, alpha)
+        dv.vcycle(src, b, dst, nPre, nPost, alpha, overlap_next=True)
         src, dst = dst, src
     t_issue = time.perf_counter() - t0
     torch.cuda.synchronize()
