@@ -5,7 +5,8 @@ Host mirror of the reference's operator interface (api.py) over the C ABI of lib
 Context() does, and fails loudly when the HIP library or device is missing."""
 from ._lib import (AggmgError, ArgumentError, DimensionMismatch, HipError, SingularException,
                    UnsupportedError, LIB_PATH, SYMBOLS)
-from .api import (AbstractSmoother, AdditiveSchwarzSmoother, BlockDiagonal, BlockDiagonalLU, BlockJacobi, Context,
+from .api import (AbstractSmoother, AdditiveSchwarzSmoother, BlockDiagonal, BlockDiagonalLU, BlockGaussSeidel,
+                  BlockJacobi, Context,
                   DeviceOperator,
                   DeviceVector, HybridSchwarzSmoother, JacobiSmoother, MeshHierarchy,
                   apply_smoother, cg_smoother, default_context, dg_smoother,

@@ -296,6 +296,16 @@ class AdditiveSchwarzSmoother(_BlockSmoother):
     """src/smoother.jl:1-18 (same apply loop as BlockJacobi, overlapping blocks)"""
 
 
+class BlockGaussSeidel(_BlockSmoother):
+    """EXTENSION: red-black block Gauss-Seidel on a block-tridiagonal operator (C ABI kind 2 of
+    aggmg_blockjacobi_setup).  The reference has no Gauss-Seidel smoother (SURVEY.md D1);
+    BASELINE.json names one, so it is offered and checked against the oracle's restatement
+    (BlockGaussSeidelRB), not against the reference.  One sweep: even elements, then odd ones, each
+    with the newest values; V-cycles post-smooth in the reverse order.  UnsupportedError unless the
+    blocks are contiguous and the operator couples an element to its direct neighbours only."""
+    _kind = 2
+
+
 class HybridSchwarzSmoother(_BlockSmoother):
     """src/smoother.jl:24-46"""
     _kind = 1
@@ -411,6 +421,8 @@ def dg_smoother(dgMesh, A, smootherType, ctx=None):
         return JacobiSmoother(A, ctx)
     if smootherType == 'blockJac':
         return BlockJacobi(A, _mesh_block_inds(dgMesh), ctx)
+    if smootherType == 'blockGS':    # extension, see BlockGaussSeidel
+        return BlockGaussSeidel(A, _mesh_block_inds(dgMesh), ctx)
     raise ArgumentError(f"dg_smoother: unknown smoother type {smootherType!r}")
 
 
@@ -451,6 +463,8 @@ def _smoother_from_reference(S, A_op):
         return S
     if hasattr(S, "mCountingMatrix"):
         return HybridSchwarzSmoother(A_op, S.mBlockInds)
+    if type(S).__name__ == "BlockGaussSeidelRB":     # the oracle's restatement of the extension
+        return BlockGaussSeidel(A_op, S.mBlockInds)
     if hasattr(S, "mBlockInds"):
         return BlockJacobi(A_op, S.mBlockInds)
     if hasattr(S, "mJac"):

@@ -106,6 +106,7 @@ struct aggmg_smoother {
   double* counts = nullptr;    // hybrid Schwarz
   bool overlapping = false;
   bool contiguous = false;
+  bool gs = false;  // red-black block Gauss-Seidel (extension): needs the structured form
   std::shared_ptr<BtdDev> btd;  // structured fused form, or null
 };
 
@@ -793,12 +794,12 @@ extern "C" int aggmg_blockjacobi_setup(aggmg_ctx* ctx, aggmg_op* A, int64_t m, i
   if (A->m != A->n) return fail(ctx, AGGMG_ERR_DIMENSION, "aggmg_blockjacobi_setup: operator is not square");
   if (!A->host_valid) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_blockjacobi_setup: host copy of the operator was released");
   if (m <= 0 || nb < 0 || m > 64) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_blockjacobi_setup: block size must be in 1..64");
-  if (kind != 0 && kind != 1) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_blockjacobi_setup: unknown kind");
+  if (kind < 0 || kind > 2) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_blockjacobi_setup: unknown kind");
   HIPCHK(hipSetDevice(ctx->device));
   const int64_t N = A->m;
   const int64_t base = one_based ? 1 : 0;
   auto sm = std::make_unique<aggmg_smoother>();
-  sm->kind = kind == 1 ? 2 : 1;
+  sm->kind = kind == 1 ? 2 : 1;  // (kind 2, block Gauss-Seidel, shares the block data of kind 0)
   sm->A = A;
   sm->N = N;
   sm->m = m;
@@ -843,6 +844,17 @@ extern "C" int aggmg_blockjacobi_setup(aggmg_ctx* ctx, aggmg_op* A, int64_t m, i
   CHECK(dev_upload(ctx, inds, &sm->inds));
   if (sm->kind == 2) CHECK(dev_upload(ctx, counts, &sm->counts));
   if (contiguous && !overlapping && sm->kind == 1) CHECK(build_btd(ctx, sm.get(), binv));
+  if (kind == 2) {
+    // two colours order a sweep only when elements couple to their direct neighbours alone
+    if (!sm->btd) {  // reachable with ordinary input: release what was uploaded
+      for (void* p : {(void*)sm->binv, (void*)sm->inds, (void*)sm->counts})
+        if (p) (void)hipFree(p);
+      return fail(ctx, AGGMG_ERR_UNSUPPORTED,
+                  "aggmg_blockjacobi_setup: red-black block Gauss-Seidel needs contiguous blocks and a "
+                  "block-tridiagonal operator");
+    }
+    sm->gs = true;
+  }
   *out = sm.release();
   return AGGMG_OK;
 }
@@ -985,6 +997,7 @@ template <int M, bool CMP>
 static int launch_btd_t(aggmg_ctx* ctx, FusedArgs a, int halo, const TileSel& sel) {
   using T = BtdTile<M, CMP>;
   const int align = (a.lf_out || a.ld_out) ? a.rho_out : 1;
+  if (a.gs) halo += a.nsweeps;  // two half-sweeps per sweep, one element of halo each
   int owned = ((T::TE - 2 * halo) / align) * align;
   if (owned <= 0) return fail(ctx, AGGMG_ERR_UNSUPPORTED, "fused tile too small for the requested halo");
   a.owned = owned;
@@ -1009,16 +1022,25 @@ static int launch_btd_t(aggmg_ctx* ctx, FusedArgs a, int halo, const TileSel& se
   if (ntiles == 0) return AGGMG_OK;
   const size_t lds = (size_t)2 * (T::TE + 2) * M * sizeof(double);
   constexpr bool kGrp = (CMP && (M == 2 || M == 4 || M == 8)) || (!CMP && (M == 2 || M == 4));
+  const bool sym = kGrp && a.lv.bsym;
+  // four instantiations per (M, CMP): symmetric packing x smoother (block-Jacobi / red-black GS)
+  auto go = [&](auto kern) {
+    hipLaunchKernelGGL(kern, dim3((unsigned)ntiles), dim3(T::NT), lds, ctx->stream, a);
+  };
   if constexpr (kGrp) {
-    if (a.lv.bsym) {
-      hipLaunchKernelGGL((btd_fused_kernel<M, CMP, T::NS, true, T::NT>), dim3((unsigned)ntiles), dim3(T::NT), lds,
-                         ctx->stream, a);
+    if (sym) {
+      if (a.gs)
+        go(btd_fused_kernel<M, CMP, T::NS, true, T::NT, true>);
+      else
+        go(btd_fused_kernel<M, CMP, T::NS, true, T::NT, false>);
       HIPCHK(hipGetLastError());
       return AGGMG_OK;
     }
   }
-  hipLaunchKernelGGL((btd_fused_kernel<M, CMP, T::NS, false, T::NT>), dim3((unsigned)ntiles), dim3(T::NT), lds,
-                     ctx->stream, a);
+  if (a.gs)
+    go(btd_fused_kernel<M, CMP, T::NS, false, T::NT, true>);
+  else
+    go(btd_fused_kernel<M, CMP, T::NS, false, T::NT, false>);
   HIPCHK(hipGetLastError());
   return AGGMG_OK;
 }
@@ -1076,10 +1098,15 @@ static int btd_max_sweeps(const BtdDev& b, int extra) {
   return std::max(1, s);
 }
 
+// does a launch of nsweeps sweeps (+ a residual) fit the halo budget of smoother sm's tiles?
+static bool btd_fits(const aggmg_smoother& sm, int nsweeps, int residual) {
+  return (sm.gs ? 2 : 1) * nsweeps + residual <= btd_max_sweeps(*sm.btd, 0);
+}
+
 // structured: nsweeps sweeps from u_in (may be nullptr = zero) into u_out (!= u_in)
 static int btd_smooth(aggmg_ctx* ctx, const BtdDev& b, const double* u_in, const double* rhs, double alpha,
-                      int nsweeps, double* u_out, int level, int64_t N) {
-  const int smax = btd_max_sweeps(b, 0);
+                      int nsweeps, double* u_out, int level, int64_t N, int gs = 0) {
+  const int smax = std::max(1, btd_max_sweeps(b, 0) / (gs ? 2 : 1));
   const double* src = u_in;
   int left = nsweeps;
   if (left == 0) {
@@ -1105,6 +1132,7 @@ static int btd_smooth(aggmg_ctx* ctx, const BtdDev& b, const double* u_in, const
     a.u_out = dst;
     a.alpha = alpha;
     a.nsweeps = s;
+    a.gs = gs;
     {
       ProfScope ps(ctx, AGGMG_KIND_SMOOTH, level);
       CHECK(launch_btd(ctx, b, a, s));
@@ -1168,10 +1196,10 @@ extern "C" int aggmg_smooth_dev(aggmg_ctx* ctx, aggmg_op* A, aggmg_smoother* sm,
   const int64_t N = A->m;
   if (N == 0) return AGGMG_OK;
   if (sm->btd && sm->A == A) {
-    if (u_out != u_in) return btd_smooth(ctx, *sm->btd, u_in, b, alpha, nsweeps, u_out, 0, N);
+    if (u_out != u_in) return btd_smooth(ctx, *sm->btd, u_in, b, alpha, nsweeps, u_out, 0, N, sm->gs ? 1 : 0);
     double* t = nullptr;  // in-place request: stage through scratch (extra copy)
     CHECK(scratch(ctx, 2, N, &t));
-    CHECK(btd_smooth(ctx, *sm->btd, u_in, b, alpha, nsweeps, t, 0, N));
+    CHECK(btd_smooth(ctx, *sm->btd, u_in, b, alpha, nsweeps, t, 0, N, sm->gs ? 1 : 0));
     HIPCHK(hipMemcpyAsync(u_out, t, N * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
     return AGGMG_OK;
   }
@@ -1638,10 +1666,6 @@ static int cr_setup(aggmg_ctx* ctx, const HostCsr& h, int64_t N, int hint_m, CrD
     L.n = n;
     L.n_even = ne;
     L.n_odd = no;
-    // the kernels multiply by the inverted diagonal of U (a division is a ~40-instruction
-    // dependent chain on every level of the reduction)
-    for (int64_t j = 0; j < no; ++j)
-      for (int i = 0; i < m; ++i) lu[j * mm2 + i * m + i] = 1.0 / lu[j * mm2 + i * m + i];
     int st = upd(a, &L.a);
     if (st == AGGMG_OK) st = upd(c, &L.c);
     if (st == AGGMG_OK) st = upd(lu, &L.lu);
@@ -1669,7 +1693,6 @@ static int cr_setup(aggmg_ctx* ctx, const HostCsr& h, int64_t N, int hint_m, CrD
     }
     const double* p = nullptr;
     const int32_t* q = nullptr;
-    for (int i = 0; i < m; ++i) lu[i * m + i] = 1.0 / lu[i * m + i];
     int st = upd(lu, &p);
     if (st == AGGMG_OK) st = upi(perm, &q);
     if (st != AGGMG_OK) {
@@ -1775,12 +1798,12 @@ static int cr_solve_t(aggmg_ctx* ctx, CrDev& cr, const double* rhs, double* out)
     const unsigned grid = (unsigned)C.nq;
     hipLaunchKernelGGL((cr_chunk_forward_kernel<M>), dim3(std::max(grid, 1u)), dim3(kThreads), cr.chunk_lds,
                        ctx->stream, C, dl(g), cr.partR, cr.partL);
-    hipLaunchKernelGGL((cr_tail_kernel<M>), dim3(1), dim3(kCrTailThreads), cr.tail_lds, ctx->stream, T,
+    hipLaunchKernelGGL((cr_tail_kernel<M>), dim3(1), dim3(1024), cr.tail_lds, ctx->stream, T,
                        (const double*)cr.partR, (const double*)cr.partL, cr.xq);
     hipLaunchKernelGGL((cr_chunk_backward_kernel<M>), dim3(std::max(grid, 1u)), dim3(kThreads), cr.chunk_lds,
                        ctx->stream, C, dl(g), (const double*)cr.xq, xl(g));
   } else {
-    hipLaunchKernelGGL((cr_tail_kernel<M>), dim3(1), dim3(kCrTailThreads), cr.tail_lds, ctx->stream, T, dl(g),
+    hipLaunchKernelGGL((cr_tail_kernel<M>), dim3(1), dim3(1024), cr.tail_lds, ctx->stream, T, dl(g),
                        (const double*)nullptr, xl(g));
   }
   for (int l = g - 1; l >= 0; --l) {
@@ -1808,7 +1831,7 @@ static int cr_phase_t(aggmg_ctx* ctx, CrDev& cr, int phase, const double* d_owne
   T.lu_last = cr.lu_last;
   T.perm_last = cr.perm_last;
   if (phase == 1) {  // boundary system
-    hipLaunchKernelGGL((cr_tail_kernel<M>), dim3(1), dim3(kCrTailThreads), cr.tail_lds, ctx->stream, T, (const double*)partR,
+    hipLaunchKernelGGL((cr_tail_kernel<M>), dim3(1), dim3(1024), cr.tail_lds, ctx->stream, T, (const double*)partR,
                        (const double*)partL, const_cast<double*>(xq));
     HIPCHK(hipGetLastError());
     return AGGMG_OK;
@@ -2029,13 +2052,14 @@ static int vcycle_down(aggmg_ctx* ctx, aggmg_hier* h, const double* x0, const do
     const double* rhs = k == 0 ? b : l.rhs;
     const double* uin = k == 0 ? x0 : nullptr;  // u[k] = zeros for k > 1 (:29-31)
     const bool structured = l.S->btd && l.S->A == l.A;
-    if (structured && l.tb && nPre + 1 <= btd_max_sweeps(*l.S->btd, 0)) {
+    if (structured && l.tb && btd_fits(*l.S, nPre, 1)) {
       FusedArgs a = btd_args(*l.S->btd);
       a.u_in = uin;
       a.b = rhs;
       a.u_out = l.u[0];
       a.alpha = alpha;
       a.nsweeps = nPre;
+      a.gs = l.S->gs ? 1 : 0;  // pre-smoothing: even elements, then odd ones
       a.do_residual = 1;
       if (l.tb->ld)
         a.ld_out = l.tb->ld;  // restrict B^{-1} r with (L'D): the kernel then reads neither D nor L
@@ -2048,7 +2072,7 @@ static int vcycle_down(aggmg_ctx* ctx, aggmg_hier* h, const double* x0, const do
       CHECK(launch_btd(ctx, *l.S->btd, a, nPre + 1));
     } else {
       if (structured) {
-        CHECK(btd_smooth(ctx, *l.S->btd, uin, rhs, alpha, nPre, l.u[0], k, l.N));
+        CHECK(btd_smooth(ctx, *l.S->btd, uin, rhs, alpha, nPre, l.u[0], k, l.N, l.S->gs ? 1 : 0));
       } else {
         // generic sweeps, result in l.u[0]
         const double* src = uin;
@@ -2097,13 +2121,14 @@ static int vcycle_up(aggmg_ctx* ctx, aggmg_hier* h, const double* b, int nPost, 
     double* dst = k == 0 ? x_out : l.u[1];
     const double* uc = (k + 1 == n - 1) ? c.u[0] : c.u[1];
     const bool structured = l.S->btd && l.S->A == l.A;
-    if (structured && l.tb && nPost <= btd_max_sweeps(*l.S->btd, 0)) {
+    if (structured && l.tb && btd_fits(*l.S, nPost, 0)) {
       FusedArgs a = btd_args(*l.S->btd);
       a.u_in = l.u[0];
       a.b = rhs;
       a.u_out = dst;
       a.alpha = alpha;
       a.nsweeps = nPost;
+      a.gs = l.S->gs ? 2 : 0;  // post-smoothing in the reverse colour order: the cycle stays symmetric
       a.lf_in = l.tb->lf;
       a.uc = uc;
       a.mc_in = l.tb->mc;
@@ -2118,7 +2143,7 @@ static int vcycle_up(aggmg_ctx* ctx, aggmg_hier* h, const double* b, int nPost, 
         CHECK(launch_csr<kSpmvAdd>(ctx, l.L->csr, uc, nullptr, nullptr, 0.0, l.u[0]));
       }
       if (structured) {
-        CHECK(btd_smooth(ctx, *l.S->btd, l.u[0], rhs, alpha, nPost, dst, k, l.N));
+        CHECK(btd_smooth(ctx, *l.S->btd, l.u[0], rhs, alpha, nPost, dst, k, l.N, l.S->gs ? 2 : 0));
       } else {
         const double* src = l.u[0];
         if (nPost == 0) HIPCHK(hipMemcpyAsync(dst, src, l.N * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
@@ -2183,7 +2208,7 @@ extern "C" int aggmg_vcycles_dev(aggmg_ctx* ctx, aggmg_hier* h, const double* x0
   const int n = (int)h->lv.size();
   Level& l0 = h->lv[0];
   const bool fusable = n >= 2 && l0.S && l0.S->btd && l0.S->A == l0.A && l0.tb && l0.tb->ld &&
-                       nPre + nPost + 1 <= btd_max_sweeps(*l0.S->btd, 0);
+                       btd_fits(*l0.S, nPre + nPost, 1) && !l0.S->gs;
   if (!fusable || ncycles == 1) {
     // plain sequence; intermediate iterates ping-pong between two vectors owned by the hierarchy
     if (ncycles > 1)
@@ -2282,7 +2307,7 @@ extern "C" int aggmg_vcycle_up_split_dev(aggmg_ctx* ctx, aggmg_hier* h, const do
   if (x_out == b) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_vcycle_up_split_dev: x_out must not alias b");
   if (part < 0 || part > 2) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_vcycle_up_split_dev: part is 0, 1 or 2");
   Level& l = h->lv[0];
-  if (!(l.S && l.S->btd && l.S->A == l.A && l.tb && nPost <= btd_max_sweeps(*l.S->btd, 0)))
+  if (!(l.S && l.S->btd && l.S->A == l.A && l.tb && btd_fits(*l.S, nPost, 0)))
     return fail(ctx, AGGMG_ERR_UNSUPPORTED, "split ascent needs the fused block-tridiagonal fine level");
   if (part == 0) return h->lv.size() > 2 ? vcycle_up(ctx, h, b, nPost, alpha, x_out, 1) : AGGMG_OK;
   TileSel sel;
@@ -2617,8 +2642,3 @@ extern "C" int aggmg_copy_segments_dev(aggmg_ctx* ctx, int nseg, const double* c
   return AGGMG_OK;
 }
 
-#ifdef AGGMG_CR_STAMPS
-extern "C" int aggmg_debug_cr_stamps(unsigned long long* out) {
-  return hipMemcpyFromSymbol(out, HIP_SYMBOL(aggmg::g_cr_stamps), sizeof(unsigned long long) * 96) == hipSuccess ? 0 : -1;
-}
-#endif

@@ -301,6 +301,10 @@ struct FusedArgs {
   // interface elements first and exchange them under the interior launch)
   int tile_split;
   int64_t tile_skip;
+  // 0: block-Jacobi sweeps.  1 / 2: red-black block Gauss-Seidel sweeps (EXTENSION, no reference
+  // counterpart): even elements then odd ones (1), or odd then even (2); each half-sweep uses the
+  // other colour's newest values and costs one element of halo.
+  int gs;
 };
 
 __device__ __forceinline__ int64_t fused_tile(const FusedArgs& a) {
@@ -338,7 +342,9 @@ __device__ __forceinline__ double group_bcast(double v, int j) {
   return __shfl(v, j, W);
 }
 
-template <int M, bool CMP, int NS, bool SYM = false, int NT = kThreads>
+// GS: red-black block Gauss-Seidel sweeps (FusedArgs::gs gives the colour order) instead of
+// block-Jacobi ones -- a compile-time variant, so the block-Jacobi kernel carries none of it
+template <int M, bool CMP, int NS, bool SYM = false, int NT = kThreads, bool GS = false>
 __global__ __launch_bounds__(NT) void btd_fused_kernel(FusedArgs a) {
   static_assert(!SYM || M == 2 || M == 4 || M == 8, "symmetric packing needs the lane-group path");
   // GRP: the rows of one element sit in M = 2^k adjacent lanes, so element-wide sums and
@@ -534,10 +540,16 @@ __global__ __launch_bounds__(NT) void btd_fused_kernel(FusedArgs a) {
     __syncthreads();
   }
 
-  // ---- sweeps: LDS ping-pong ---------------------------------------------------------------
+  // ---- sweeps --------------------------------------------------------------------------------
+  // block-Jacobi: LDS ping-pong.  Red-black block Gauss-Seidel (GS): in place, one colour per
+  // half-sweep -- (B^{-1}(b - A u))_e = g_e - P u_{e-1} - Q u_{e+1} - u_e needs the row's own value
+  // and the two neighbouring elements, which have the other colour and are not written in this
+  // half-sweep; every thread evaluates the update, so the lane-group reductions stay convergent,
+  // and only the current colour commits it.
   double* cur = buf0;
   double* nxt = buf1;
-  for (int sw = 0; sw < a.nsweeps; ++sw) {
+  const int nhalf = GS ? 2 * a.nsweeps : a.nsweeps;
+  for (int sw = 0; sw < nhalf; ++sw) {
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
       const int x = s * EPS + le;
@@ -563,14 +575,24 @@ __global__ __launch_bounds__(NT) void btd_fused_kernel(FusedArgs a) {
         }
         double un = uu[s] + a.alpha * (acc - uu[s]);
         if (!valid[s]) un = 0.0;
-        uu[s] = un;
-        nxt[x * M + i] = un;
+        if constexpr (!GS) {
+          uu[s] = un;
+          nxt[x * M + i] = un;
+        } else {
+          const int colour = (sw & 1) ^ (a.gs == 2 ? 1 : 0);
+          if (((e0 + x) & 1) == colour) {
+            uu[s] = un;
+            cur[x * M + i] = un;
+          }
+        }
       }
     }
     __syncthreads();
-    double* t = cur;
-    cur = nxt;
-    nxt = t;
+    if constexpr (!GS) {
+      double* t = cur;
+      cur = nxt;
+      nxt = t;
+    }
   }
 
   // ---- store the iterate of the owned elements ---------------------------------------------
@@ -714,25 +736,10 @@ __global__ __launch_bounds__(NT) void btd_fused_kernel(FusedArgs a) {
 //   forward   d'_j   = d_{2j} - a_{2j} (b_{2j-1} \ d_{2j-1}) - c_{2j} (b_{2j+1} \ d_{2j+1})
 //   backward  x_{2j+1} = b_{2j+1} \ (d_{2j+1} - a_{2j+1} x_{2j} - c_{2j+1} x_{2j+2})
 // The Schur-complement blocks of the next level are formed on the host at set-up.
-#ifdef AGGMG_CR_STAMPS
-// diagnostic build only: shader-clock stamps of workgroup 0 / thread 0 (tools/exp_cr_stamps.py)
-__device__ unsigned long long g_cr_stamps[3][32];
-__device__ __forceinline__ void cr_stamp(int k, int i) {
-  if (blockIdx.x == 0 && threadIdx.x == 0 && i < 32) {
-    unsigned long long t;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-    g_cr_stamps[k][i] = t;
-  }
-}
-#define CR_STAMP(k, i) cr_stamp(k, i)
-#else
-#define CR_STAMP(k, i)
-#endif
-
 struct CrLevel {
   const double* a;     // [n][M][M]
   const double* c;     // [n][M][M]
-  const double* lu;    // [n_odd][M][M]  unit-lower L and U of the row-permuted b_{2j+1}, diag(U) inverted
+  const double* lu;    // [n_odd][M][M]  unit-lower L and U of the row-permuted b_{2j+1}
   const int32_t* perm; // [n_odd][M]     row permutation: (P b) = L U, solve uses rhs[perm[k]]
   int64_t n, n_even, n_odd;
 };
@@ -756,16 +763,15 @@ __device__ __forceinline__ void cr_lu_solve(const double* __restrict__ lu, const
     double s = y[i];
 #pragma unroll
     for (int j = i + 1; j < M; ++j) s -= lu[i * M + j] * y[j];
-    y[i] = s * lu[i * M + i];  // the diagonal of U is stored inverted
+    y[i] = s / lu[i * M + i];
   }
 }
 
-// ---- factors read in place (large blocks: 4 M^2 doubles would not fit the register file) ----
 // d'_j of the next level from this level's vector d (indexable by level-local block index);
 // neighbours outside [lo, hi] are skipped (domain ends, or chunk ends whose terms another
 // workgroup accounts for)
 template <int M>
-__device__ __forceinline__ void cr_forward_block_range_mem(const CrLevel& L, int64_t j, const double* d, double* dn,
+__device__ __forceinline__ void cr_forward_block_range(const CrLevel& L, int64_t j, const double* d, double* dn,
                                                        int64_t lo, int64_t hi) {
   double acc[M], y[M];
 #pragma unroll
@@ -790,10 +796,14 @@ __device__ __forceinline__ void cr_forward_block_range_mem(const CrLevel& L, int
   for (int i = 0; i < M; ++i) dn[j * M + i] = acc[i];
 }
 
+template <int M>
+__device__ __forceinline__ void cr_forward_block(const CrLevel& L, int64_t j, const double* d, double* dn) {
+  cr_forward_block_range<M>(L, j, d, dn, 0, L.n - 1);
+}
 
 // x of block row r (odd) given the coarser solution xn; rhs assembled in a small local array
 template <int M>
-__device__ __forceinline__ void cr_backward_block_mem(const CrLevel& L, int64_t r, const double* d, const double* xn,
+__device__ __forceinline__ void cr_backward_block(const CrLevel& L, int64_t r, const double* d, const double* xn,
                                                   double (&x)[M]) {
   const int64_t j = r >> 1;
   double rhs[M];
@@ -834,222 +844,10 @@ __device__ __forceinline__ void cr_backward_block_mem(const CrLevel& L, int64_t 
     double s = t[i];
 #pragma unroll
     for (int q = i + 1; q < M; ++q) s -= lu[i * M + q] * t[q];
-    t[i] = s * lu[i * M + i];
+    t[i] = s / lu[i * M + i];
   }
 #pragma unroll
   for (int i = 0; i < M; ++i) x[i] = t[i];
-}
-
-// The factors a thread needs for one block row do not depend on the vectors, so they are loaded
-// into registers ahead of the level they are used on (the levels of a reduction are dependent
-// steps of a few hundred nanoseconds each: a global-load round trip inside every one of them
-// would dominate).  CrFwd / CrBwd hold one block row's worth.
-// 1x1 and 2x2 blocks (every hierarchy the reference builds ends in one of the two) are held in
-// registers and a second set is fetched one level ahead; larger blocks are read in place
-template <int M>
-constexpr bool kCrHoist = (M <= 2);
-template <int M>
-constexpr bool kCrPrefetch = (M <= 2);
-
-template <int M>
-struct CrFwd {
-  static constexpr int K = kCrHoist<M> ? M : 1;
-  double A[K * K], C[K * K], luL[K * K], luR[K * K];
-  int32_t pL[K], pR[K];
-  bool hasL, hasR;
-  const CrLevel* L;  // !kCrHoist: where to read the factors from at apply time
-  int64_t lo, hi;
-};
-
-// factors for d'_j of the next level; neighbours outside [lo, hi] are skipped (domain ends, or
-// chunk ends whose terms another workgroup accounts for)
-template <int M>
-__device__ __forceinline__ void cr_fwd_load(CrFwd<M>& F, const CrLevel& L, int64_t j, int64_t lo, int64_t hi) {
-  if constexpr (!kCrHoist<M>) {
-    F.L = &L;
-    F.lo = lo;
-    F.hi = hi;
-    return;
-  } else {
-  F.hasL = 2 * j - 1 >= lo;
-  F.hasR = 2 * j + 1 <= hi;
-  // clamped so that every load is in bounds and unconditional (n_odd >= 1 on a reducing level)
-  const int64_t jl = F.hasL ? j - 1 : 0;
-  const int64_t jr = F.hasR ? j : 0;
-  const double* A = L.a + (2 * j) * M * M;
-  const double* C = L.c + (2 * j) * M * M;
-  const double* luL = L.lu + jl * M * M;
-  const double* luR = L.lu + jr * M * M;
-#pragma unroll
-  for (int k = 0; k < M * M; ++k) {
-    F.A[k] = A[k];
-    F.C[k] = C[k];
-    F.luL[k] = luL[k];
-    F.luR[k] = luR[k];
-  }
-#pragma unroll
-  for (int k = 0; k < M; ++k) {
-    F.pL[k] = L.perm[jl * M + k];
-    F.pR[k] = L.perm[jr * M + k];
-  }
-  }
-}
-
-// y = b \ r with the factors in registers; r (LDS) gathered through the row permutation
-template <int M>
-__device__ __forceinline__ void cr_lu_solve_reg(const double (&lu)[M * M], const int32_t (&perm)[M], const double* r,
-                                                double (&y)[M]) {
-#pragma unroll
-  for (int k = 0; k < M; ++k) y[k] = r[perm[k]];
-#pragma unroll
-  for (int i = 1; i < M; ++i) {
-    double s = y[i];
-#pragma unroll
-    for (int j = 0; j < i; ++j) s -= lu[i * M + j] * y[j];
-    y[i] = s;
-  }
-#pragma unroll
-  for (int i = M - 1; i >= 0; --i) {
-    double s = y[i];
-#pragma unroll
-    for (int j = i + 1; j < M; ++j) s -= lu[i * M + j] * y[j];
-    y[i] = s * lu[i * M + i];  // the diagonal of U is stored inverted
-  }
-}
-
-// d'_j of the next level from this level's vector d (indexable by level-local block index)
-template <int M>
-__device__ __forceinline__ void cr_fwd_apply(const CrFwd<M>& F, int64_t j, const double* d, double* dn) {
-  if constexpr (!kCrHoist<M>) {
-    cr_forward_block_range_mem<M>(*F.L, j, d, dn, F.lo, F.hi);
-    return;
-  } else {
-  // both neighbour solves run unconditionally on clamped operands (one basic block: the two
-  // dependent chains interleave); an absent neighbour's term is dropped by the selects
-  double acc[M], yL[M], yR[M], t[M];
-#pragma unroll
-  for (int i = 0; i < M; ++i) acc[i] = d[(2 * j) * M + i];
-  cr_lu_solve_reg<M>(F.luL, F.pL, d + (F.hasL ? 2 * j - 1 : 2 * j) * M, yL);
-  cr_lu_solve_reg<M>(F.luR, F.pR, d + (F.hasR ? 2 * j + 1 : 2 * j) * M, yR);
-#pragma unroll
-  for (int i = 0; i < M; ++i) {
-    t[i] = acc[i];
-#pragma unroll
-    for (int k = 0; k < M; ++k) t[i] -= F.A[i * M + k] * yL[k];
-    acc[i] = F.hasL ? t[i] : acc[i];
-  }
-#pragma unroll
-  for (int i = 0; i < M; ++i) {
-    t[i] = acc[i];
-#pragma unroll
-    for (int k = 0; k < M; ++k) t[i] -= F.C[i * M + k] * yR[k];
-    acc[i] = F.hasR ? t[i] : acc[i];
-  }
-#pragma unroll
-  for (int i = 0; i < M; ++i) dn[j * M + i] = acc[i];
-  }
-}
-
-template <int M>
-__device__ __forceinline__ void cr_forward_block_range(const CrLevel& L, int64_t j, const double* d, double* dn,
-                                                       int64_t lo, int64_t hi) {
-  CrFwd<M> F;
-  cr_fwd_load<M>(F, L, j, lo, hi);
-  cr_fwd_apply<M>(F, j, d, dn);
-}
-
-template <int M>
-__device__ __forceinline__ void cr_forward_block(const CrLevel& L, int64_t j, const double* d, double* dn) {
-  cr_forward_block_range<M>(L, j, d, dn, 0, L.n - 1);
-}
-
-template <int M>
-struct CrBwd {
-  static constexpr int K = kCrHoist<M> ? M : 1;
-  double A[K * K], C[K * K], lu[K * K];
-  int32_t perm[K];
-  bool hasC;
-  const CrLevel* L;
-};
-
-template <int M>
-__device__ __forceinline__ void cr_bwd_load(CrBwd<M>& F, const CrLevel& L, int64_t r) {
-  if constexpr (!kCrHoist<M>) {
-    F.L = &L;
-    return;
-  } else {
-  const int64_t j = r >> 1;
-  F.hasC = r + 1 < L.n;
-  const double* A = L.a + r * M * M;
-  const double* C = L.c + r * M * M;  // c has n rows: in bounds (and zero) on the last row
-  const double* lu = L.lu + j * M * M;
-#pragma unroll
-  for (int k = 0; k < M * M; ++k) {
-    F.A[k] = A[k];
-    F.C[k] = C[k];
-    F.lu[k] = lu[k];
-  }
-#pragma unroll
-  for (int k = 0; k < M; ++k) F.perm[k] = L.perm[j * M + k];
-  }
-}
-
-// x of block row r (odd) given the coarser solution xn
-template <int M>
-__device__ __forceinline__ void cr_bwd_apply(const CrBwd<M>& F, int64_t r, const double* d, const double* xn,
-                                             double (&x)[M]) {
-  if constexpr (!kCrHoist<M>) {
-    cr_backward_block_mem<M>(*F.L, r, d, xn, x);
-    return;
-  } else {
-  const int64_t j = r >> 1;
-  double rhs[M];
-#pragma unroll
-  for (int i = 0; i < M; ++i) rhs[i] = d[r * M + i];
-#pragma unroll
-  for (int i = 0; i < M; ++i)
-#pragma unroll
-    for (int k = 0; k < M; ++k) rhs[i] -= F.A[i * M + k] * xn[j * M + k];
-  if (F.hasC) {
-#pragma unroll
-    for (int i = 0; i < M; ++i)
-#pragma unroll
-      for (int k = 0; k < M; ++k) rhs[i] -= F.C[i * M + k] * xn[(j + 1) * M + k];
-  }
-  // permutation gather out of registers
-  double t[M];
-#pragma unroll
-  for (int k = 0; k < M; ++k) {
-    double v = rhs[0];
-#pragma unroll
-    for (int q = 1; q < M; ++q) v = (F.perm[k] == q) ? rhs[q] : v;
-    t[k] = v;
-  }
-#pragma unroll
-  for (int i = 1; i < M; ++i) {
-    double s = t[i];
-#pragma unroll
-    for (int q = 0; q < i; ++q) s -= F.lu[i * M + q] * t[q];
-    t[i] = s;
-  }
-#pragma unroll
-  for (int i = M - 1; i >= 0; --i) {
-    double s = t[i];
-#pragma unroll
-    for (int q = i + 1; q < M; ++q) s -= F.lu[i * M + q] * t[q];
-    t[i] = s * F.lu[i * M + i];
-  }
-#pragma unroll
-  for (int i = 0; i < M; ++i) x[i] = t[i];
-  }
-}
-
-template <int M>
-__device__ __forceinline__ void cr_backward_block(const CrLevel& L, int64_t r, const double* d, const double* xn,
-                                                  double (&x)[M]) {
-  CrBwd<M> F;
-  cr_bwd_load<M>(F, L, r);
-  cr_bwd_apply<M>(F, r, d, xn, x);
 }
 
 // one thread per even block row of this level -> block row of the next level
@@ -1082,7 +880,6 @@ __global__ __launch_bounds__(kThreads) void cr_backward_kernel(CrLevel L, const 
 // tail: all remaining levels (rows <= kCrTailRows) inside one workgroup, vectors in LDS
 constexpr int kCrTailRows = 2048;  // 2 * rows * 8 B of LDS stays well under the 64 KB default cap
 constexpr int kCrMaxLevels = 40;
-constexpr int kCrTailThreads = 512;  // two factor sets per thread in flight: 256 VGPRs each
 struct CrTail {
   CrLevel lv[16];
   int nlev;               // reducing levels handled here
@@ -1091,7 +888,7 @@ struct CrTail {
 };
 
 template <int M>
-__global__ __launch_bounds__(kCrTailThreads) void cr_tail_kernel(CrTail T, const double* __restrict__ d0,
+__global__ __launch_bounds__(1024) void cr_tail_kernel(CrTail T, const double* __restrict__ d0,
                                                        const double* __restrict__ d0b,
                                                        double* __restrict__ x0) {
   extern __shared__ double sh[];
@@ -1108,34 +905,12 @@ __global__ __launch_bounds__(kCrTailThreads) void cr_tail_kernel(CrTail T, const
   }
   __syncthreads();
   const int n0 = (int)(T.nlev ? T.lv[0].n : 1) * M;
-  // The first iteration of every level loop runs on factors fetched one level ahead; two
-  // register sets alternate (a copy between them would wait for the loads before the barrier).
-  CrFwd<M> F0, F1;
-  CrBwd<M> B0, B1;
-  if (T.nlev && tid < (int)T.lv[0].n_even) cr_fwd_load<M>(F0, T.lv[0], tid, 0, T.lv[0].n - 1);
   for (int t = tid; t < n0; t += blockDim.x) sh[t] = d0b ? d0[t] + d0b[t] : d0[t];
   __syncthreads();
-  // the descent ends on level nlev-1: its back-substitution factors go to the set `blast`
-  auto fwd_level = [&](int l, CrFwd<M>& cur, CrFwd<M>& nxt) __attribute__((always_inline)) {
-    const CrLevel& L = T.lv[l];
-    auto ahead = [&]() __attribute__((always_inline)) {
-      if (l + 1 < T.nlev) {
-        if (tid < (int)T.lv[l + 1].n_even) cr_fwd_load<M>(nxt, T.lv[l + 1], tid, 0, T.lv[l + 1].n - 1);
-      } else if (tid < (int)L.n && (tid & 1)) {
-        cr_bwd_load<M>(B0, L, tid);
-      }
-    };
-    if constexpr (kCrPrefetch<M>) ahead();
-    if (tid < (int)L.n_even) cr_fwd_apply<M>(cur, tid, sh + off[l], sh + off[l + 1]);
-    for (int j = tid + blockDim.x; j < (int)L.n_even; j += blockDim.x)
-      cr_forward_block<M>(L, j, sh + off[l], sh + off[l + 1]);
+  for (int l = 0; l < T.nlev; ++l) {
+    const CrLevel L = T.lv[l];
+    for (int j = tid; j < (int)L.n_even; j += blockDim.x) cr_forward_block<M>(L, j, sh + off[l], sh + off[l + 1]);
     __syncthreads();
-    if constexpr (!kCrPrefetch<M>) ahead();
-  };
-  CR_STAMP(2, 0);
-  for (int l = 0; l < T.nlev; l += 2) {
-    fwd_level(l, F0, F1);
-    if (l + 1 < T.nlev) fwd_level(l + 1, F1, F0);
   }
   if (tid == 0) {
     double y[M];
@@ -1145,22 +920,15 @@ __global__ __launch_bounds__(kCrTailThreads) void cr_tail_kernel(CrTail T, const
     for (int i = 0; i < M; ++i) dl[i] = y[i];
   }
   __syncthreads();
-  auto bwd_level = [&](int l, CrBwd<M>& cur, CrBwd<M>& nxt) __attribute__((always_inline)) {
-    const CrLevel& L = T.lv[l];
+  for (int l = T.nlev - 1; l >= 0; --l) {
+    const CrLevel L = T.lv[l];
     double* d = sh + off[l];  // becomes x of this level
     const double* xn = sh + off[l + 1];
-    auto ahead = [&]() __attribute__((always_inline)) {
-      if (l > 0 && tid < (int)T.lv[l - 1].n && (tid & 1)) cr_bwd_load<M>(nxt, T.lv[l - 1], tid);
-    };
-    if constexpr (kCrPrefetch<M>) ahead();
     // odd block rows read only their own d and xn: each thread may overwrite its own block
     for (int r = tid; r < (int)L.n; r += blockDim.x) {
       double xv[M];
       if (r & 1) {
-        if (r == tid)
-          cr_bwd_apply<M>(cur, r, d, xn, xv);
-        else
-          cr_backward_block<M>(L, r, d, xn, xv);
+        cr_backward_block<M>(L, r, d, xn, xv);
       } else {
 #pragma unroll
         for (int i = 0; i < M; ++i) xv[i] = xn[(r >> 1) * M + i];
@@ -1169,14 +937,7 @@ __global__ __launch_bounds__(kCrTailThreads) void cr_tail_kernel(CrTail T, const
       for (int i = 0; i < M; ++i) d[r * M + i] = xv[i];
     }
     __syncthreads();
-    if constexpr (!kCrPrefetch<M>) ahead();
-  };
-  CR_STAMP(2, 1);
-  for (int l = T.nlev - 1; l >= 0; l -= 2) {
-    bwd_level(l, B0, B1);
-    if (l - 1 >= 0) bwd_level(l - 1, B1, B0);
   }
-  CR_STAMP(2, 2);
   for (int t = tid; t < n0; t += blockDim.x) x0[t] = sh[t];
 }
 
@@ -1209,34 +970,17 @@ __device__ __forceinline__ void cr_chunk_forward(const CrChunk& C, int64_t c, co
   }
   const bool shared_right = ((c + 1) << q) <= C.lv[0].n - 1;
   const int cnt0 = (int)(hi[0] - lo[0] + 1) * M;
-  CrFwd<M> F0, F1;  // alternating register sets, see cr_tail_kernel
-  CR_STAMP(0, 0);
-  if (q > 0 && lo[1] + tid <= hi[1]) cr_fwd_load<M>(F0, C.lv[0], lo[1] + tid, lo[0], hi[0]);
   for (int t = tid; t < cnt0; t += blockDim.x) {
     const bool rb = shared_right && t >= cnt0 - M;  // the right boundary's own d belongs to the next chunk
     sh[off[0] + t] = rb ? 0.0 : d0[lo[0] * M + t];
   }
   __syncthreads();
-  auto level = [&](int l, CrFwd<M>& cur, CrFwd<M>& nxt) __attribute__((always_inline)) {
+  for (int l = 0; l < q; ++l) {
     const double* d = sh + off[l] - lo[l] * M;
     double* dn = sh + off[l + 1] - lo[l + 1] * M;
-    auto ahead = [&]() __attribute__((always_inline)) {
-      if (l + 1 < q && lo[l + 2] + tid <= hi[l + 2])
-        cr_fwd_load<M>(nxt, C.lv[l + 1], lo[l + 2] + tid, lo[l + 1], hi[l + 1]);
-    };
-    if constexpr (kCrPrefetch<M>) ahead();
-    int64_t j = lo[l + 1] + tid;
-    if (j <= hi[l + 1]) cr_fwd_apply<M>(cur, j, d, dn);
-    for (j += blockDim.x; j <= hi[l + 1]; j += blockDim.x)
+    for (int64_t j = lo[l + 1] + tid; j <= hi[l + 1]; j += blockDim.x)
       cr_forward_block_range<M>(C.lv[l], j, d, dn, lo[l], hi[l]);
     __syncthreads();
-    CR_STAMP(0, 2 + l);
-    if constexpr (!kCrPrefetch<M>) ahead();
-  };
-  CR_STAMP(0, 1);
-  for (int l = 0; l < q; l += 2) {
-    level(l, F0, F1);
-    if (l + 1 < q) level(l + 1, F1, F0);
   }
 }
 
@@ -1269,7 +1013,6 @@ __global__ __launch_bounds__(kThreads) void cr_chunk_forward_kernel(CrChunk C, c
     double* st = C.stack + c * (int64_t)C.stack_stride;
     for (int t = threadIdx.x; t < len; t += blockDim.x) st[t] = sh[t];
   }
-  CR_STAMP(0, 2 + C.q);
 }
 
 template <int M>
@@ -1290,7 +1033,6 @@ __global__ __launch_bounds__(kThreads) void cr_chunk_backward_kernel(CrChunk C, 
   __syncthreads();
   const int64_t c = C.c0 + blockIdx.x;
   const int q = C.q;
-  CrBwd<M> B0, B1;  // alternating register sets, see cr_tail_kernel
   if (C.stack) {
     for (int l = 0; l <= q; ++l) {
       const int64_t nl = l < q ? C.lv[l].n : C.nq;
@@ -1298,42 +1040,23 @@ __global__ __launch_bounds__(kThreads) void cr_chunk_backward_kernel(CrChunk C, 
       const int64_t h = (c + 1) << (q - l);
       hi[l] = h < nl - 1 ? h : nl - 1;
     }
-    if constexpr (kCrPrefetch<M>) {
-      if (q > 0) {
-        const int64_t r0 = lo[q - 1] + tid;
-        if (r0 <= hi[q - 1] && (r0 & 1)) cr_bwd_load<M>(B0, C.lv[q - 1], r0);
-      }
-    }
     const double* st = C.stack + c * (int64_t)C.stack_stride;
     for (int t = tid; t < off[q]; t += blockDim.x) sh[t] = st[t];
     __syncthreads();
   } else {
     cr_chunk_forward<M>(C, c, d0, sh, off, lo, hi);
   }
-  CR_STAMP(1, 0);
   const int cntq = (int)(hi[q] - lo[q] + 1) * M;
   for (int t = tid; t < cntq; t += blockDim.x) sh[off[q] + t] = xq[lo[q] * M + t];
   __syncthreads();
-  CR_STAMP(1, 1);
-  auto level = [&](int l, CrBwd<M>& cur, CrBwd<M>& nxt) __attribute__((always_inline)) {
+  for (int l = q - 1; l >= 0; --l) {
     const CrLevel& L = C.lv[l];
     double* d = sh + off[l] - lo[l] * M;  // becomes x of this level
     const double* xn = sh + off[l + 1] - lo[l + 1] * M;
-    const int64_t r0 = lo[l] + tid;
-    // level q-1 with a stack: fetched before the stack was staged
-    const bool fetched = kCrPrefetch<M> && (l < q - 1 || C.stack);
-    if (!fetched && r0 <= hi[l] && (r0 & 1)) cr_bwd_load<M>(cur, L, r0);
-    if constexpr (kCrPrefetch<M>) {
-      if (l > 0 && lo[l - 1] + tid <= hi[l - 1] && ((lo[l - 1] + tid) & 1))
-        cr_bwd_load<M>(nxt, C.lv[l - 1], lo[l - 1] + tid);
-    }
-    for (int64_t r = r0; r <= hi[l]; r += blockDim.x) {
+    for (int64_t r = lo[l] + tid; r <= hi[l]; r += blockDim.x) {
       double xv[M];
       if (r & 1) {
-        if (r == r0)
-          cr_bwd_apply<M>(cur, r, d, xn, xv);
-        else
-          cr_backward_block<M>(L, r, d, xn, xv);
+        cr_backward_block<M>(L, r, d, xn, xv);
       } else {
 #pragma unroll
         for (int i = 0; i < M; ++i) xv[i] = xn[(r >> 1) * M + i];
@@ -1342,16 +1065,10 @@ __global__ __launch_bounds__(kThreads) void cr_chunk_backward_kernel(CrChunk C, 
       for (int i = 0; i < M; ++i) d[r * M + i] = xv[i];
     }
     __syncthreads();
-    CR_STAMP(1, 2 + (q - 1 - l));
-  };
-  for (int l = q - 1; l >= 0; l -= 2) {
-    level(l, B0, B1);
-    if (l - 1 >= 0) level(l - 1, B1, B0);
   }
   const bool shared_right = ((c + 1) << q) <= C.lv[0].n - 1;
   const int cnt0 = (int)(hi[0] - lo[0] + 1 - (shared_right ? 1 : 0)) * M;
   for (int t = tid; t < cnt0; t += blockDim.x) x0[lo[0] * M + t] = sh[off[0] + t];
-  CR_STAMP(1, 2 + q);
 }
 
 }  // namespace aggmg

@@ -82,7 +82,13 @@ int aggmg_op_release_host(aggmg_ctx* ctx, aggmg_op* op);
  * column-major, 1-based when one_based != 0.  Diagonal blocks A[inds,inds] are extracted and
  * factorised with partial pivoting (exact zero pivot -> AGGMG_ERR_SINGULAR naming the block).
  * kind: 0 = BlockJacobi (also AdditiveSchwarz: same apply loop, blocks may overlap),
- *       1 = HybridSchwarz (result divided by the per-node block count, src/smoother.jl:24-46). */
+ *       1 = HybridSchwarz (result divided by the per-node block count, src/smoother.jl:24-46),
+ *       2 = red-black block Gauss-Seidel -- EXTENSION, the reference has no Gauss-Seidel smoother
+ *           (SURVEY.md D1): one sweep = for colour in (even elements, odd elements):
+ *           u_e += alpha B_e^{-1} (b - A u)_e on that colour with the newest u.  V-cycles pre-smooth
+ *           in this order and post-smooth in the reverse one.  Needs contiguous blocks and a block-
+ *           tridiagonal operator (AGGMG_ERR_UNSUPPORTED otherwise); aggmg_smoother_apply on such a
+ *           smoother applies its block-diagonal part like kind 0. */
 int aggmg_blockjacobi_setup(aggmg_ctx* ctx, aggmg_op* A, int64_t m, int64_t nb,
                             const int64_t* blockinds, int one_based, int kind,
                             aggmg_smoother** out);

@@ -1285,6 +1285,36 @@ class BlockJacobi:
 AdditiveSchwarzSmoother = BlockJacobi
 
 
+class BlockGaussSeidelRB(BlockJacobi):
+    """EXTENSION -- the reference has no Gauss-Seidel smoother; BASELINE.json's
+    north_star / config 5 name one, so the product offers a red-black block Gauss-Seidel on
+    block-tridiagonal operators and this class restates it for the tests.  No reference parity
+    claim: it is checked against this restatement only.
+
+    One sweep with damping alpha, blocks in element order, colour = element index parity
+    (0-based): for colour in (0, 1) [reverse=True: (1, 0)]:
+        r = b - A u;   u[inds_e] += alpha * (LU_e \ r[inds_e])   for every element e of that colour.
+    apply() (inherited) is the block-diagonal part alone, as for BlockJacobi."""
+
+    def sweep(self, A, u, b, alpha=1.0, reverse=False):
+        u = np.array(u, dtype=np.float64)
+        for colour in ((1, 0) if reverse else (0, 1)):
+            r = b - csc_matvec(A, u)
+            for e in range(colour, len(self.mBlocks), 2):
+                idx = self.mBlockInds[:, e] - 1
+                u[idx] += alpha * self.mBlocks[e].solve(r[idx])
+        return u
+
+
+def smooth_once(S, A, u, rhs, alpha, post=False):
+    """one smoothing step of the V-cycle.  Reference smoothers: exactly the expression of
+    src/solvers.jl:33 / :44, `u + apply_smoother(S, rhs - A*u; alpha)`.  The Gauss-Seidel extension
+    sweeps its two colours, in reverse order when post-smoothing."""
+    if isinstance(S, BlockGaussSeidelRB):
+        return S.sweep(A, u, rhs, alpha, reverse=post)
+    return u + apply_smoother(S, rhs - csc_matvec(A, u), alpha=alpha)
+
+
 class HybridSchwarzSmoother:
     """src/smoother.jl:24-46"""
 
@@ -1349,6 +1379,8 @@ def dg_smoother(dgMesh, A, smootherType):
         return JacobiSmoother(A.diagonal())
     if smootherType == 'blockJac':
         return BlockJacobi(*_element_blocks(dgMesh, A))
+    if smootherType == 'blockGS':    # EXTENSION, see BlockGaussSeidelRB
+        return BlockGaussSeidelRB(*_element_blocks(dgMesh, A))
     raise ValueError(smootherType)
 
 
@@ -1498,16 +1530,14 @@ def multigrid_v_cycle(H, x0, b, nPre=3, nPost=3, alpha=2.0 / 3.0, coarse_solve=N
         if k > 0:
             u[k] = np.zeros(H.mStiffness[k].shape[1])
         for _ in range(nPre):
-            u[k] = u[k] + apply_smoother(H.mSmoothers[k],
-                                         rhs[k] - csc_matvec(H.mStiffness[k], u[k]), alpha=alpha)
+            u[k] = smooth_once(H.mSmoothers[k], H.mStiffness[k], u[k], rhs[k], alpha)
         rhs[k + 1] = csc_adjoint_matvec(H.mInterpolation[k],
                                         rhs[k] - csc_matvec(H.mStiffness[k], u[k]))
     u[n - 1] = solve(H.mStiffness[n - 1], rhs[n - 1])
     for k in range(n - 2, -1, -1):
         u[k] = u[k] + csc_matvec(H.mInterpolation[k], u[k + 1])
         for _ in range(nPost):
-            u[k] = u[k] + apply_smoother(H.mSmoothers[k],
-                                         rhs[k] - csc_matvec(H.mStiffness[k], u[k]), alpha=alpha)
+            u[k] = smooth_once(H.mSmoothers[k], H.mStiffness[k], u[k], rhs[k], alpha, post=True)
     return u[0]
 
 
