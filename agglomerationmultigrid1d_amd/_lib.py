@@ -20,6 +20,8 @@ KIND_FUSED_DOWN, KIND_FUSED_UP, KIND_SMOOTH, KIND_RESIDUAL, KIND_RESTRICT, KIND_
 KIND_NAMES = ["fused_down", "fused_up", "smooth", "residual", "restrict", "prolong", "jacobi",
               "block_apply", "coarse", "fused_mid"]
 COARSE_HOST_BANDED, COARSE_DEVICE_CR, COARSE_AUTO, COARSE_EXTERNAL = 0, 1, 2, 3
+# aggmg_hier_set_restriction modes (include/aggmg_hip.h)
+RESTRICT_EXPLICIT, RESTRICT_PRECONDITIONED = 0, 1
 
 
 class AggmgError(RuntimeError):
@@ -95,6 +97,7 @@ SYMBOLS = {
     "aggmg_vcycle": (c_int, [_P, _P, _PD, _PD, c_int, c_int, c_double, _PD]),
     "aggmg_vcycle_dev": (c_int, [_P, _P, _P, _P, c_int, c_int, c_double, _P]),
     "aggmg_vcycles_dev": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_double, _P]),
+    "aggmg_hier_set_restriction": (c_int, [_P, _P, c_int]),
     "aggmg_vcycle_down_dev": (c_int, [_P, _P, _P, _P, c_int, c_double]),
     "aggmg_vcycle_up_dev": (c_int, [_P, _P, _P, c_int, c_double, _P]),
     "aggmg_vcycle_up_split_dev": (c_int, [_P, _P, _P, c_int, c_double, _P, c_int64, c_int64, c_int]),

@@ -558,6 +558,13 @@ class MeshHierarchy:
         c.check(c.lib.aggmg_vcycle_up_split_dev(c.handle, self.handle, _ptr(b), int(nPost), float(alpha), _ptr(x_out),
                                                 int(head_elems), int(tail_elem), int(part)))
 
+    def set_restriction(self, mode):
+        """_lib.RESTRICT_EXPLICIT (default: the reference's arithmetic for L'(rhs - A u)) or
+        _lib.RESTRICT_PRECONDITIONED (cheaper, only for cond(A) eps << 1) -- C ABI
+        aggmg_hier_set_restriction, see include/aggmg_hip.h"""
+        c = self.ctx
+        c.check(c.lib.aggmg_hier_set_restriction(c.handle, self.handle, int(mode)))
+
     def coarse_buffers(self):
         """-> (rhs_ptr, sol_ptr, n): device buffers of the coarsest level"""
         r, s_, n = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_int64(0)

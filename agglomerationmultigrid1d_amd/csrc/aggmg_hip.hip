@@ -157,9 +157,24 @@ struct aggmg_hier {
   BandedLU coarse;
   CrDev cr;
   double* cyc[2] = {nullptr, nullptr};  // iterate ping-pong for multi-cycle calls (lazy)
+  int restriction = 0;  // AGGMG_RESTRICT_EXPLICIT (default) / AGGMG_RESTRICT_PRECONDITIONED
   std::vector<double> h_coarse;
   double last_coarse_ms = 0.0;
 };
+
+// The restricted residual L'(b - A u) is formed from r = b - A u evaluated with the operator's own
+// entries (the reference's arithmetic, src/solvers.jl:36) -- AGGMG_RESTRICT_EXPLICIT, the default.
+// AGGMG_RESTRICT_PRECONDITIONED takes it from the sweeps' preconditioned residual instead,
+// (L'D) w with w = g - P u- - Q u+ - u, which reads neither the diagonal blocks nor L: equal in
+// exact arithmetic, but w inherits the rounding of the stored (symmetrically packed) B^{-1}, P, Q.
+// On the smoothest mode of the model problem that error grows like n^2 and at 2^24 fine elements
+// turns the cycle from damping (x0.5, as in reference-order arithmetic) into amplifying (x2.1):
+// measured, include/aggmg_hip.h and DESIGN.md section 5.  AGGMG_RESTRICT=preconditioned sets the
+// initial mode of new hierarchies.
+static int default_restriction() {
+  const char* e = std::getenv("AGGMG_RESTRICT");
+  return (e && std::string(e) == "preconditioned") ? AGGMG_RESTRICT_PRECONDITIONED : AGGMG_RESTRICT_EXPLICIT;
+}
 
 // ---------------------------------------------------------------------------------------------
 // host-side parallel loop for the O(n) set-up passes (block extraction / inversion, format
@@ -1977,6 +1992,7 @@ extern "C" int aggmg_hier_create(aggmg_ctx* ctx, int nlevels, aggmg_op* const* s
     return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_hier_create: unknown coarse_mode");
   HIPCHK(hipSetDevice(ctx->device));
   std::unique_ptr<aggmg_hier> h(new aggmg_hier());
+  h->restriction = default_restriction();
   h->coarse_mode = coarse_mode;
   h->lv.resize(nlevels);
   for (int k = 0; k < nlevels; ++k) {
@@ -2061,7 +2077,7 @@ static int vcycle_down(aggmg_ctx* ctx, aggmg_hier* h, const double* x0, const do
       a.nsweeps = nPre;
       a.gs = l.S->gs ? 1 : 0;  // pre-smoothing: even elements, then odd ones
       a.do_residual = 1;
-      if (l.tb->ld)
+      if (l.tb->ld && h->restriction == AGGMG_RESTRICT_PRECONDITIONED)
         a.ld_out = l.tb->ld;  // restrict B^{-1} r with (L'D): the kernel then reads neither D nor L
       else
         a.lf_out = l.tb->lf;
@@ -2207,7 +2223,7 @@ extern "C" int aggmg_vcycles_dev(aggmg_ctx* ctx, aggmg_hier* h, const double* x0
     return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_vcycles: hierarchy was created with AGGMG_COARSE_EXTERNAL");
   const int n = (int)h->lv.size();
   Level& l0 = h->lv[0];
-  const bool fusable = n >= 2 && l0.S && l0.S->btd && l0.S->A == l0.A && l0.tb && l0.tb->ld &&
+  const bool fusable = n >= 2 && l0.S && l0.S->btd && l0.S->A == l0.A && l0.tb && (l0.tb->ld || h->restriction == AGGMG_RESTRICT_EXPLICIT) &&
                        btd_fits(*l0.S, nPre + nPost, 1) && !l0.S->gs;
   if (!fusable || ncycles == 1) {
     // plain sequence; intermediate iterates ping-pong between two vectors owned by the hierarchy
@@ -2253,7 +2269,10 @@ extern "C" int aggmg_vcycles_dev(aggmg_ctx* ctx, aggmg_hier* h, const double* x0
     a.mc_in = l0.tb->mc;
     a.rho_in = l0.tb->rho;
     a.do_residual = 1;
-    a.ld_out = l0.tb->ld;
+    if (h->restriction == AGGMG_RESTRICT_PRECONDITIONED)
+      a.ld_out = l0.tb->ld;
+    else
+      a.lf_out = l0.tb->lf;
     a.rc_out = c1.rhs;
     a.mc_out = l0.tb->mc;
     a.rho_out = l0.tb->rho;
@@ -2315,6 +2334,14 @@ extern "C" int aggmg_vcycle_up_split_dev(aggmg_ctx* ctx, aggmg_hier* h, const do
   sel.head = head_elems;
   sel.tail = tail_elem;
   return vcycle_up(ctx, h, b, nPost, alpha, x_out, 0, sel);
+}
+
+extern "C" int aggmg_hier_set_restriction(aggmg_ctx* ctx, aggmg_hier* h, int mode) {
+  if (!ctx) return AGGMG_ERR_ARGUMENT;
+  if (!h || (mode != AGGMG_RESTRICT_EXPLICIT && mode != AGGMG_RESTRICT_PRECONDITIONED))
+    return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_hier_set_restriction: bad argument");
+  h->restriction = mode;
+  return AGGMG_OK;
 }
 
 extern "C" int aggmg_hier_coarse_buffers(aggmg_ctx* ctx, aggmg_hier* h, void** rhs_dev, void** sol_dev,

@@ -157,6 +157,21 @@ int aggmg_vcycle_dev(aggmg_ctx* ctx, aggmg_hier* h, const double* x0, const doub
  * one fused launch, so the fine operator is read once per cycle instead of twice. */
 int aggmg_vcycles_dev(aggmg_ctx* ctx, aggmg_hier* h, const double* x0, const double* b, int ncycles,
                       int nPre, int nPost, double alpha, double* x_out);
+/* How the fused descent forms the restricted residual L'(rhs - A u) of src/solvers.jl:36.
+ * AGGMG_RESTRICT_EXPLICIT (default): r = rhs - A u with the operator's own entries, then L' r -- the
+ * reference's arithmetic.  AGGMG_RESTRICT_PRECONDITIONED: (L'D) w from the preconditioned residual
+ * w = B^{-1} r that the sweeps already hold; equal in exact arithmetic and ~20 % cheaper per V-cycle
+ * (the descent reads neither the diagonal blocks nor L), but w carries the rounding of the stored
+ * (symmetrically packed) block inverses.  Measured on the model problem: the factor by which one
+ * V(3,3) cycle multiplies the smoothest mode grows like n^2 in every implementation -- reference-
+ * order arithmetic 0.031 / 0.125 / 0.498 at 2^22 / 2^23 / 2^24 fine elements, the explicit form
+ * the same to three digits, the preconditioned form 0.134 / 0.533 / 2.13: at 2^24 it AMPLIFIES
+ * the mode and the multigrid iteration diverges (tools/exp_smooth_mode.py).
+ * Use it at sizes well below that.  New hierarchies start in the mode named by the environment
+ * variable AGGMG_RESTRICT ("preconditioned"), explicit otherwise. */
+#define AGGMG_RESTRICT_EXPLICIT 0
+#define AGGMG_RESTRICT_PRECONDITIONED 1
+int aggmg_hier_set_restriction(aggmg_ctx* ctx, aggmg_hier* h, int mode);
 /* The two halves of the V-cycle around the coarsest solve (src/solvers.jl:28-37 and :41-47), for
  * callers that solve the coarsest system themselves (element-partitioned multi-GPU runs gather it
  * across ranks).  After _down the coarsest right-hand side is in the buffer reported by

@@ -268,3 +268,4 @@ def test_split_ascent_is_bitwise_the_plain_ascent(oracle, mg):
         H.vcycle_up_split_dev(b, out, head, tail, 2)     # the order of the two fine-level parts is free
         H.vcycle_up_split_dev(b, out, head, tail, 1)
         assert np.array_equal(out.download(), ref), (head, tail)
+

@@ -24,10 +24,11 @@ def grid(owned):
 roles = {grid(TE - 2 * 4): "fused_down_L0", grid(((TE - 2 * 3) // 1)): "fused_up_L0",
          grid(((TE - 2 * 7) // 4) * 4): "fused_mid_L0"}
 expected = {  # bytes per fine element the kernel must move
-    # symmetric operator: packed inverse 80, q row 32, b 32, u 32, L'D or L rows 64
-    "fused_down_L0": (80 + 32 + 32 + 32 + 64, 32 + 4),
+    # symmetric operator: packed inverse 80, q row 32, b 32, u 32, L rows 64; the explicit residual
+    # behind the restriction (default) also reads the diagonal block 128 and the sub-diagonal column 32
+    "fused_down_L0": (80 + 32 + 32 + 32 + 64 + 128 + 32, 32 + 4),
     "fused_up_L0": (80 + 32 + 32 + 32 + 64, 32),
-    "fused_mid_L0": (80 + 32 + 32 + 32 + 64 + 64, 32 + 4),
+    "fused_mid_L0": (80 + 32 + 32 + 32 + 64 + 64 + 128 + 32, 32 + 4),
 }
 
 
