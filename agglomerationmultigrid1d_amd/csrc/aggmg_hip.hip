@@ -108,6 +108,11 @@ struct aggmg_smoother {
   bool contiguous = false;
   bool gs = false;  // red-black block Gauss-Seidel (extension): needs the structured form
   std::shared_ptr<BtdDev> btd;  // structured fused form, or null
+  // owns its device arrays: every early return of a set-up routine releases what was uploaded
+  ~aggmg_smoother() {
+    for (void* p : {(void*)diag, (void*)binv, (void*)inds, (void*)counts})
+      if (p) (void)hipFree(p);
+  }
 };
 
 struct TransferBtd {
@@ -861,9 +866,7 @@ extern "C" int aggmg_blockjacobi_setup(aggmg_ctx* ctx, aggmg_op* A, int64_t m, i
   if (contiguous && !overlapping && sm->kind == 1) CHECK(build_btd(ctx, sm.get(), binv));
   if (kind == 2) {
     // two colours order a sweep only when elements couple to their direct neighbours alone
-    if (!sm->btd) {  // reachable with ordinary input: release what was uploaded
-      for (void* p : {(void*)sm->binv, (void*)sm->inds, (void*)sm->counts})
-        if (p) (void)hipFree(p);
+    if (!sm->btd) {  // reachable with ordinary input; sm's destructor releases what was uploaded
       return fail(ctx, AGGMG_ERR_UNSUPPORTED,
                   "aggmg_blockjacobi_setup: red-black block Gauss-Seidel needs contiguous blocks and a "
                   "block-tridiagonal operator");
@@ -935,9 +938,7 @@ extern "C" int aggmg_smoother_free(aggmg_ctx* ctx, aggmg_smoother* sm) {
   if (!ctx) return AGGMG_ERR_ARGUMENT;
   if (!sm) return AGGMG_OK;
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  for (void* p : {(void*)sm->diag, (void*)sm->binv, (void*)sm->inds, (void*)sm->counts})
-    if (p) (void)hipFree(p);
-  delete sm;
+  delete sm;  // the destructor frees the device arrays
   return AGGMG_OK;
 }
 
