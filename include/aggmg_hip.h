@@ -166,7 +166,7 @@ int aggmg_vcycles_dev(aggmg_ctx* ctx, aggmg_hier* h, const double* x0, const dou
  * V(3,3) cycle multiplies the smoothest mode grows like n^2 in every implementation -- reference-
  * order arithmetic 0.031 / 0.125 / 0.498 at 2^22 / 2^23 / 2^24 fine elements, the explicit form
  * the same to three digits, the preconditioned form 0.134 / 0.533 / 2.13: at 2^24 it AMPLIFIES
- * the mode and the multigrid iteration diverges (tools/exp_smooth_mode.py).
+ * the mode and the multigrid iteration diverges (tests/manual/exp_smooth_mode.py).
  * Use it at sizes well below that.  New hierarchies start in the mode named by the environment
  * variable AGGMG_RESTRICT ("preconditioned"), explicit otherwise. */
 #define AGGMG_RESTRICT_EXPLICIT 0

@@ -161,7 +161,7 @@ def test_config2_smoother_and_residual_properties():
 
 
 # ------------------------------------------------------------------------------------------
-# the smoothest mode at large n (found with tools/exp_smooth_mode.py): the floating-point error
+# the smoothest mode at large n (found with tests/manual/exp_smooth_mode.py): the floating-point error
 # of its residual grows like n^2; with the restricted residual taken from the operator's own
 # entries (the default, the reference's arithmetic) one V(3,3) cycle multiplies the mode by
 # 0.031 at 2^22 and 0.498 at 2^24 -- the same as the plain-C restatement in the reference's
