@@ -18,6 +18,10 @@ metric  fine-level DoF-updates/s per V-cycle = N_fine * (nPre + nPost) / t_vcycl
 roofline  dominant kernel = the fused fine-level launch; achieved = algorithmic bytes per launch
         (SURVEY.md 8d byte model, from actual nnz) / its mean HIP-event duration measured inside
         the timed region on the launch stream.
+extra fields  preconditioned_residual_restriction (the cheaper restriction form, for comparison only:
+        it is not the default because it diverges as an iteration at 2^24),
+        outer_solvers_to_1e-8 (device-resident multigrid loop and ldiv!-preconditioned CG),
+        vcycles_loop (cycles fused across the fine level), config3_2p22, config5_shape_1gpu.
 cpu_baseline  the plain-C single-thread restatement (oracle/aggmg_oracle_c.c, kind "port") on a
         bounded sample of the same workload, host cores of this box, rank 0, N = 1 only.
 """
