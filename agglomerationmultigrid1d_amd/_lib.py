@@ -22,6 +22,9 @@ KIND_NAMES = ["fused_down", "fused_up", "smooth", "residual", "restrict", "prolo
 COARSE_HOST_BANDED, COARSE_DEVICE_CR, COARSE_AUTO, COARSE_EXTERNAL = 0, 1, 2, 3
 # aggmg_hier_set_restriction modes (include/aggmg_hip.h)
 RESTRICT_EXPLICIT, RESTRICT_PRECONDITIONED = 0, 1
+# aggmg_hier_level_kind
+LEVEL_GENERIC, LEVEL_FUSED_BTD, LEVEL_FUSED_CHAIN, LEVEL_COARSEST = 0, 1, 2, 3
+LEVEL_KIND_NAMES = ["generic", "fused_btd", "fused_chain", "coarsest"]
 
 
 class AggmgError(RuntimeError):
@@ -80,6 +83,7 @@ SYMBOLS = {
                                         POINTER(_P)]),
     "aggmg_blockdiag_setup": (c_int, [_P, c_int64, c_int64, _PD, c_int, POINTER(_P)]),
     "aggmg_jacobi_setup": (c_int, [_P, _P, POINTER(_P)]),
+    "aggmg_jacobi_setup_elements": (c_int, [_P, _P, c_int64, c_int64, POINTER(c_int64), c_int, POINTER(_P)]),
     "aggmg_smoother_free": (c_int, [_P, _P]),
     "aggmg_smoother_apply": (c_int, [_P, _P, _PD, c_int64, c_int64, c_double, _PD]),
     "aggmg_smoother_is_structured": (c_int, [_P, _P, POINTER(c_int)]),
@@ -106,6 +110,7 @@ SYMBOLS = {
     "aggmg_coarse_chunk_forward_dev": (c_int, [_P, _P, _P, c_int64, c_int64, _P, _P]),
     "aggmg_coarse_boundary_solve_dev": (c_int, [_P, _P, _P, _P, _P]),
     "aggmg_coarse_chunk_backward_dev": (c_int, [_P, _P, _P, c_int64, c_int64, _P, _P]),
+    "aggmg_hier_level_kind": (c_int, [_P, _P, c_int, POINTER(c_int)]),
     "aggmg_hier_coarse_info": (c_int, [_P, _P, POINTER(c_int), POINTER(c_int), POINTER(c_double)]),
     "aggmg_hier_last_coarse_ms": (c_int, [_P, _P, POINTER(c_double)]),
     "aggmg_copy_segments_dev": (c_int, [_P, c_int, POINTER(_P), POINTER(_P), POINTER(c_int64), POINTER(c_int64),

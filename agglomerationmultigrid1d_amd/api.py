@@ -256,13 +256,27 @@ class AbstractSmoother:
 
 
 class JacobiSmoother(AbstractSmoother):
-    """JacobiSmoother{mJac::Diagonal} src/smoother.jl:52-58"""
+    """JacobiSmoother{mJac::Diagonal} src/smoother.jl:52-58.
 
-    def __init__(self, A, ctx=None):
+    mElementNodes: optional (p+1) x n matrix of the CG mesh's element node lists (1-based, column k
+    = cgMesh.mElements[k].mNodesInd, src/cg_mesh.jl:35-45) -- what cg_smoother(cgMesh, A, :jac) has at
+    hand.  Same smoother; with the lists the level also gets the element-contiguous chain form and
+    runs the fused point-Jacobi kernel (C ABI aggmg_jacobi_setup_elements)."""
+
+    def __init__(self, A, ctx=None, mElementNodes=None):
         self.A = _as_op(A, ctx=ctx)
         h = ctypes.c_void_p()
         c = self.A.ctx
-        c.check(c.lib.aggmg_jacobi_setup(c.handle, self.A.handle, ctypes.byref(h)))
+        if mElementNodes is None:
+            c.check(c.lib.aggmg_jacobi_setup(c.handle, self.A.handle, ctypes.byref(h)))
+        else:
+            inds = np.asarray(mElementNodes, dtype=np.int64)
+            if inds.ndim != 2:
+                raise ArgumentError("mElementNodes must be a ((p+1) x n) matrix")
+            m1, n = inds.shape
+            flat = np.ascontiguousarray(inds.T)     # column-major (p+1) x n == C-order n x (p+1)
+            c.check(c.lib.aggmg_jacobi_setup_elements(c.handle, self.A.handle, m1, n, flat.ctypes.data_as(_PI64), 1,
+                                                      ctypes.byref(h)))
         self.handle = h
 
 
@@ -429,7 +443,8 @@ def dg_smoother(dgMesh, A, smootherType, ctx=None):
 def cg_smoother(cgMesh, A, smootherType, ctx=None):
     """cg_smoother(mesh, A, :jac | :addSchwarz | :hybridSchwarz) src/smoother.jl:88-139"""
     if smootherType == 'jac':
-        return JacobiSmoother(A, ctx)
+        has_elements = cgMesh is not None and (hasattr(cgMesh, "mBlockInds") or hasattr(cgMesh, "mElements"))
+        return JacobiSmoother(A, ctx, _mesh_block_inds(cgMesh) if has_elements else None)
     if smootherType == 'addSchwarz':
         return AdditiveSchwarzSmoother(A, _mesh_block_inds(cgMesh), ctx)
     if smootherType == 'hybridSchwarz':
@@ -456,9 +471,20 @@ def apply_smoother(S, B, alpha=1.0):
 # --------------------------------------------------------------------------------------------
 # hierarchy (src/mesh_heirarchy.jl) and solvers (src/solvers.jl)
 # --------------------------------------------------------------------------------------------
-def _smoother_from_reference(S, A_op):
+def _is_cg_mesh(mesh):
+    """a CgMesh shares vertices between elements (src/cg_mesh.jl:37-45): n p + 1 nodes on n elements"""
+    try:
+        els = mesh.mElements
+        return mesh.mNumNodes == len(els) * mesh.mP + 1 and mesh.mP >= 1
+    except AttributeError:
+        return False
+
+
+def _smoother_from_reference(S, A_op, mesh=None):
     """Accept the reference's smoother objects (anything with `mJac`, or `mBlockInds` [+
-    `mCountingMatrix`]) as well as this module's; blocks are re-extracted from A on device."""
+    `mCountingMatrix`]) as well as this module's; blocks are re-extracted from A on device.  A
+    JacobiSmoother on a CG mesh also receives the mesh's element node lists (what
+    cg_smoother(cgMesh, A, :jac) has at hand, src/smoother.jl:88-102)."""
     if isinstance(S, AbstractSmoother):
         return S
     if hasattr(S, "mCountingMatrix"):
@@ -468,6 +494,8 @@ def _smoother_from_reference(S, A_op):
     if hasattr(S, "mBlockInds"):
         return BlockJacobi(A_op, S.mBlockInds)
     if hasattr(S, "mJac"):
+        if mesh is not None and _is_cg_mesh(mesh):
+            return JacobiSmoother(A_op, None, _mesh_block_inds(mesh))
         return JacobiSmoother(A_op)
     raise ArgumentError("unrecognised smoother object")
 
@@ -500,7 +528,9 @@ class MeshHierarchy:
         self.mGradient, self.mDivergence, self.mC = mGradient, mDivergence, mC
         self._ops = [_as_op(A, _lib.OP_STIFFNESS, self.ctx) for A in mStiffness]
         self._Ls = [_as_op(L, _lib.OP_TRANSFER, self.ctx) for L in mInterpolation]
-        self.mSmoothers = [_smoother_from_reference(mSmoothers[k], self._ops[k]) for k in range(n - 1)]
+        self.mSmoothers = [_smoother_from_reference(mSmoothers[k], self._ops[k],
+                                                    mMeshes[k] if mMeshes is not None else None)
+                           for k in range(n - 1)]
         arr = ctypes.c_void_p * n
         ops = arr(*[o.handle for o in self._ops])
         sms = arr(*([s.handle for s in self.mSmoothers] + [None]))
@@ -525,6 +555,16 @@ class MeshHierarchy:
 
     def structured_levels(self):
         return [s.structured for s in self.mSmoothers]
+
+    def level_kinds(self):
+        """which kernels run each level: 'fused_btd', 'fused_chain', 'generic', 'coarsest' (C ABI
+        aggmg_hier_level_kind)"""
+        out = []
+        for k in range(self.nlevels):
+            v = ctypes.c_int(0)
+            self.ctx.check(self.ctx.lib.aggmg_hier_level_kind(self.ctx.handle, self.handle, k, ctypes.byref(v)))
+            out.append(_lib.LEVEL_KIND_NAMES[v.value])
+        return out
 
     def vcycle_dev(self, x0, b, x_out, nPre=3, nPost=3, alpha=2.0 / 3.0):
         """Device-resident V-cycle: x0, b, x_out are DeviceVector / torch tensors / raw pointers;

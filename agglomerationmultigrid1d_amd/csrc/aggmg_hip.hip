@@ -5,297 +5,7 @@
 // extraction + partial-pivot LU inverse), launch logic for the kernels in kernels.hpp, the
 // on-device V-cycle driver and the HIP-event profiler.  No CPU compute fallback exists: every
 // hot-path entry point launches HIP kernels or fails.
-#include "../../include/aggmg_hip.h"
-
-#include <hip/hip_runtime.h>
-
-#include <algorithm>
-#include <atomic>
-#include <chrono>
-#include <cmath>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <memory>
-#include <string>
-#include <thread>
-#include <vector>
-
-#include "kernels.hpp"
-
-using namespace aggmg;
-
-// ---------------------------------------------------------------------------------------------
-// objects behind the opaque handles
-// ---------------------------------------------------------------------------------------------
-static thread_local std::string g_create_error;
-
-struct ProfEvent {
-  hipEvent_t a, b;
-  int tag;
-};
-
-struct aggmg_ctx {
-  int device = 0;
-  hipStream_t own_stream = nullptr;
-  hipStream_t stream = nullptr;
-  std::string err;
-  int profiling = 0;  // 0 off, 1 every launch, 2 only the fine-level fused-down launch (dominant kernel)
-  std::vector<ProfEvent> prof;
-  std::vector<hipEvent_t> ev_pool;
-  // scratch vectors for ping-pong / temporaries, grown on demand
-  double* scratch[3] = {nullptr, nullptr, nullptr};
-  int64_t scratch_len[3] = {0, 0, 0};
-  // outer-solver work space (aggmg_multigrid_dev, aggmg_pcg_dev, ...): vectors, dot-product
-  // partials and the device-resident scalars
-  double* solv[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-  int64_t solv_len[5] = {0, 0, 0, 0, 0};
-  double* solv_part = nullptr;
-  double* solv_sc = nullptr;
-};
-
-struct CsrDev {
-  int64_t nrows = 0, ncols = 0, nnz = 0;
-  int32_t* rowptr = nullptr;
-  int32_t* colind = nullptr;
-  double* vals = nullptr;
-  int lpr = 1;
-  int32_t* rowblk = nullptr;  // CSR-stream row blocks (short-row matrices), nblk + 1 entries
-  int64_t nblk = 0;
-  CsrView view() const { return CsrView{rowptr, colind, vals, nrows}; }
-};
-
-struct HostCsr {
-  std::vector<int32_t> rowptr, colind;
-  std::vector<double> vals;
-};
-
-// index-free block-tridiagonal form of an operator + its block-Jacobi smoother; shared by the
-// smoother that built it and the operator it describes (so aggmg_residual can use it too)
-struct BtdDev {
-  int m = 0;
-  int64_t ne = 0;
-  bool cmp = false;
-  int c_sub = 0, r_sup = 0;
-  double *binv = nullptr, *dblk = nullptr, *scol = nullptr, *pcol = nullptr, *qrow = nullptr;
-  double* bsym = nullptr;  // packed symmetric inverses (replaces binv + pcol in the kernels) or null
-  double *sub = nullptr, *sup = nullptr, *P = nullptr, *Q = nullptr;
-  ~BtdDev() {
-    for (double* p : {binv, dblk, scol, pcol, qrow, bsym, sub, sup, P, Q})
-      if (p) (void)hipFree(p);
-  }
-};
-
-struct aggmg_op {
-  int64_t m = 0, n = 0, nnz = 0;
-  int kind = AGGMG_OP_STIFFNESS;
-  CsrDev csr;   // row-gather form of the matrix
-  CsrDev csrT;  // row-gather form of its transpose (transfers only)
-  HostCsr host; // host CSR kept for smoother / structure set-up until released
-  bool host_valid = false;
-  std::shared_ptr<BtdDev> btd;  // set when a block-Jacobi smoother recognised the structure
-};
-
-struct aggmg_smoother {
-  int kind = 0;  // 0 point Jacobi, 1 block (Jacobi / additive Schwarz), 2 hybrid Schwarz
-  aggmg_op* A = nullptr;
-  int64_t N = 0, m = 0, nb = 0;
-  double* diag = nullptr;      // point Jacobi
-  double* binv = nullptr;      // [nb][m][m] row-major
-  int32_t* inds = nullptr;     // [nb][m]
-  double* counts = nullptr;    // hybrid Schwarz
-  bool overlapping = false;
-  bool contiguous = false;
-  bool gs = false;  // red-black block Gauss-Seidel (extension): needs the structured form
-  std::shared_ptr<BtdDev> btd;  // structured fused form, or null
-  // owns its device arrays: every early return of a set-up routine releases what was uploaded
-  ~aggmg_smoother() {
-    for (void* p : {(void*)diag, (void*)binv, (void*)inds, (void*)counts})
-      if (p) (void)hipFree(p);
-  }
-};
-
-struct TransferBtd {
-  int mc = 0, rho = 0;
-  double* lf = nullptr;  // [N_f][mc]  rows of L
-  double* ld = nullptr;  // [N_f][mc]  rows of (L_e' D_e)': restriction of the preconditioned residual
-};
-
-struct Level {
-  aggmg_op* A = nullptr;
-  aggmg_smoother* S = nullptr;
-  aggmg_op* L = nullptr;  // level k+1 -> k
-  int64_t N = 0;
-  double *u[2] = {nullptr, nullptr}, *rhs = nullptr, *tmp = nullptr;
-  std::unique_ptr<TransferBtd> tb;  // structured transfer to level k+1, or null
-};
-
-struct BandedLU {
-  int64_t n = 0;
-  int kl = 0, ku = 0, ldab = 0;
-  std::vector<double> ab;
-  std::vector<int32_t> ipiv;
-};
-
-// block cyclic reduction of the coarsest operator, factored once (device-resident)
-struct CrDev {
-  bool valid = false;
-  int m = 0;
-  int64_t n0 = 0, N = 0;
-  std::vector<CrLevel> lv;      // all reducing levels (device pointers)
-  std::vector<void*> owned;     // every device allocation, for free
-  const double* lu_last = nullptr;
-  const int32_t* perm_last = nullptr;
-  int nglobal = 0;              // leading levels run as their own launches (only for very large systems)
-  int q = 0;                    // next q levels run chunk-wise in LDS (one launch forward, one backward)
-  std::vector<double*> d, x;    // per-level vectors for levels 0..nglobal
-  double *partR = nullptr, *partL = nullptr, *xq = nullptr;  // chunk-boundary vectors (level nglobal+q)
-  double* stack = nullptr;      // per-chunk reduced right-hand sides of the chunk levels
-  int stack_stride = 0;
-  size_t tail_lds = 0, chunk_lds = 0;
-  double cond_est = 0.0;
-};
-
-struct aggmg_hier {
-  std::vector<Level> lv;
-  int coarse_mode = 0;
-  BandedLU coarse;
-  CrDev cr;
-  double* cyc[2] = {nullptr, nullptr};  // iterate ping-pong for multi-cycle calls (lazy)
-  int restriction = 0;  // AGGMG_RESTRICT_EXPLICIT (default) / AGGMG_RESTRICT_PRECONDITIONED
-  std::vector<double> h_coarse;
-  double last_coarse_ms = 0.0;
-};
-
-// The restricted residual L'(b - A u) is formed from r = b - A u evaluated with the operator's own
-// entries (the reference's arithmetic, src/solvers.jl:36) -- AGGMG_RESTRICT_EXPLICIT, the default.
-// AGGMG_RESTRICT_PRECONDITIONED takes it from the sweeps' preconditioned residual instead,
-// (L'D) w with w = g - P u- - Q u+ - u, which reads neither the diagonal blocks nor L: equal in
-// exact arithmetic, but w inherits the rounding of the stored (symmetrically packed) B^{-1}, P, Q.
-// On the smoothest mode of the model problem that error grows like n^2 and at 2^24 fine elements
-// turns the cycle from damping (x0.5, as in reference-order arithmetic) into amplifying (x2.1):
-// measured, include/aggmg_hip.h and DESIGN.md section 5.  AGGMG_RESTRICT=preconditioned sets the
-// initial mode of new hierarchies.
-static int default_restriction() {
-  const char* e = std::getenv("AGGMG_RESTRICT");
-  return (e && std::string(e) == "preconditioned") ? AGGMG_RESTRICT_PRECONDITIONED : AGGMG_RESTRICT_EXPLICIT;
-}
-
-// ---------------------------------------------------------------------------------------------
-// host-side parallel loop for the O(n) set-up passes (block extraction / inversion, format
-// conversion, cyclic-reduction factorisation).  Plain std::thread: no OpenMP runtime is pulled
-// into a process that already hosts numpy's and torch's.
-// ---------------------------------------------------------------------------------------------
-static int setup_threads() {
-  static int n = [] {
-    const char* e = std::getenv("AGGMG_SETUP_THREADS");
-    int v = e ? std::atoi(e) : 0;
-    if (v <= 0) {
-      v = (int)std::thread::hardware_concurrency();
-      if (const char* o = std::getenv("OMP_NUM_THREADS")) v = std::min(v, std::max(1, std::atoi(o)));
-      v = std::min(v, 16);
-    }
-    return std::max(1, v);
-  }();
-  return n;
-}
-
-template <typename F>
-static void parallel_for(int64_t n, F&& body) {  // body(begin, end)
-  const int nt = (int)std::min<int64_t>(setup_threads(), std::max<int64_t>(1, n / 4096));
-  if (nt <= 1) {
-    body((int64_t)0, n);
-    return;
-  }
-  std::vector<std::thread> th;
-  const int64_t chunk = (n + nt - 1) / nt;
-  for (int t = 0; t < nt; ++t) {
-    const int64_t b = t * chunk, e = std::min(n, b + chunk);
-    if (b >= e) break;
-    th.emplace_back([&body, b, e] { body(b, e); });
-  }
-  for (auto& t : th) t.join();
-}
-
-// ---------------------------------------------------------------------------------------------
-// error helpers
-// ---------------------------------------------------------------------------------------------
-static int fail(aggmg_ctx* ctx, int code, const std::string& msg) {
-  if (ctx)
-    ctx->err = msg;
-  else
-    g_create_error = msg;
-  return code;
-}
-
-#define HIPCHK(expr)                                                                        \
-  do {                                                                                      \
-    hipError_t _e = (expr);                                                                 \
-    if (_e != hipSuccess)                                                                   \
-      return fail(ctx, AGGMG_ERR_HIP,                                                       \
-                  std::string(#expr) + ": " + hipGetErrorString(_e) + " (" + __FILE__ + ":" + \
-                      std::to_string(__LINE__) + ")");                                      \
-  } while (0)
-
-#define CHECK(expr)             \
-  do {                          \
-    int _s = (expr);            \
-    if (_s != AGGMG_OK) return _s; \
-  } while (0)
-
-template <typename T>
-static int dev_upload(aggmg_ctx* ctx, const std::vector<T>& h, T** d) {
-  *d = nullptr;
-  size_t bytes = std::max<size_t>(h.size(), 1) * sizeof(T);
-  HIPCHK(hipMalloc((void**)d, bytes));
-  if (!h.empty())
-    HIPCHK(hipMemcpyAsync(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
-  return AGGMG_OK;
-}
-
-static int scratch(aggmg_ctx* ctx, int slot, int64_t len, double** out) {
-  if (ctx->scratch_len[slot] < len) {
-    if (ctx->scratch[slot]) {
-      HIPCHK(hipStreamSynchronize(ctx->stream));
-      HIPCHK(hipFree(ctx->scratch[slot]));
-    }
-    ctx->scratch[slot] = nullptr;
-    ctx->scratch_len[slot] = 0;
-    HIPCHK(hipMalloc((void**)&ctx->scratch[slot], (size_t)std::max<int64_t>(len, 1) * sizeof(double)));
-    ctx->scratch_len[slot] = len;
-  }
-  *out = ctx->scratch[slot];
-  return AGGMG_OK;
-}
-
-// ---------------------------------------------------------------------------------------------
-// profiler (HIP events on the launch stream)
-// ---------------------------------------------------------------------------------------------
-struct ProfScope {
-  aggmg_ctx* ctx;
-  int idx = -1;
-  ProfScope(aggmg_ctx* c, int kind, int level) : ctx(c) {
-    if (!ctx->profiling) return;
-    if (ctx->profiling == 2 && !(kind == AGGMG_KIND_FUSED_DOWN && level == 0)) return;
-    ProfEvent pe;
-    for (hipEvent_t* e : {&pe.a, &pe.b}) {
-      if (!ctx->ev_pool.empty()) {
-        *e = ctx->ev_pool.back();
-        ctx->ev_pool.pop_back();
-      } else if (hipEventCreateWithFlags(e, hipEventDisableSystemFence) != hipSuccess) {
-        return;
-      }
-    }
-    pe.tag = kind * 16 + (level & 15);
-    (void)hipEventRecord(pe.a, ctx->stream);
-    ctx->prof.push_back(pe);
-    idx = (int)ctx->prof.size() - 1;
-  }
-  ~ProfScope() {
-    if (idx >= 0) (void)hipEventRecord(ctx->prof[idx].b, ctx->stream);
-  }
-};
+#include "internal.hpp"
 
 // ---------------------------------------------------------------------------------------------
 // context
@@ -944,7 +654,7 @@ extern "C" int aggmg_smoother_free(aggmg_ctx* ctx, aggmg_smoother* sm) {
 
 extern "C" int aggmg_smoother_is_structured(aggmg_ctx* ctx, const aggmg_smoother* sm, int* out) {
   if (!ctx || !sm || !out) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_smoother_is_structured: NULL");
-  *out = sm->btd ? 1 : 0;
+  *out = (sm->btd || sm->cgt) ? 1 : 0;
   return AGGMG_OK;
 }
 
@@ -1211,6 +921,14 @@ extern "C" int aggmg_smooth_dev(aggmg_ctx* ctx, aggmg_op* A, aggmg_smoother* sm,
   if (!b || !u_out || nsweeps < 0) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_smooth: bad argument");
   const int64_t N = A->m;
   if (N == 0) return AGGMG_OK;
+  if (sm->cgt && sm->A == A) {  // CG chain form: fused point-Jacobi sweeps
+    if (u_out != u_in) return cgt_smooth_ext(ctx, *sm->cgt, u_in, b, alpha, nsweeps, u_out, 0);
+    double* t = nullptr;
+    CHECK(scratch(ctx, 2, N, &t));
+    CHECK(cgt_smooth_ext(ctx, *sm->cgt, u_in, b, alpha, nsweeps, t, 0));
+    HIPCHK(hipMemcpyAsync(u_out, t, N * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    return AGGMG_OK;
+  }
   if (sm->btd && sm->A == A) {
     if (u_out != u_in) return btd_smooth(ctx, *sm->btd, u_in, b, alpha, nsweeps, u_out, 0, N, sm->gs ? 1 : 0);
     double* t = nullptr;  // in-place request: stage through scratch (extra copy)
@@ -1254,6 +972,7 @@ extern "C" int aggmg_residual_dev(aggmg_ctx* ctx, aggmg_op* A, const double* u, 
   if (!ctx) return AGGMG_ERR_ARGUMENT;
   if (!A || !u || !b || !r_out) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_residual: NULL argument");
   ProfScope ps(ctx, AGGMG_KIND_RESIDUAL, 0);
+  if (A->cgt && r_out != u && r_out != b) return cgt_residual_ext(ctx, *A->cgt, u, b, r_out);
   if (A->btd && r_out != u && r_out != b) {  // index-free block-tridiagonal form, one fused pass
     FusedArgs a = btd_args(*A->btd);
     a.u_in = u;
@@ -1535,7 +1254,7 @@ static void lu_perm_solve(int m, const double* lu, const int32_t* perm, const do
 static void free_cr(CrDev* c) {
   for (void* p : c->owned)
     if (p) (void)hipFree(p);
-  *c = CrDev();
+  *c = CrDev();  // (clears `owned`: the hierarchy's destructor will not free these again)
 }
 
 // Returns AGGMG_OK and sets cr->valid when the operator is block-tridiagonal for some block size
@@ -1967,16 +1686,7 @@ extern "C" int aggmg_hier_free(aggmg_ctx* ctx, aggmg_hier* h) {
   if (!ctx) return AGGMG_ERR_ARGUMENT;
   if (!h) return AGGMG_OK;
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  for (auto& l : h->lv) {
-    for (double* p : {l.u[0], l.u[1], l.rhs, l.tmp})
-      if (p) (void)hipFree(p);
-    if (l.tb && l.tb->lf) (void)hipFree(l.tb->lf);
-    if (l.tb && l.tb->ld) (void)hipFree(l.tb->ld);
-  }
-  free_cr(&h->cr);
-  for (double* p : h->cyc)
-    if (p) (void)hipFree(p);
-  delete h;
+  delete h;  // the destructor frees the level vectors, transfers and the coarsest factorisation
   return AGGMG_OK;
 }
 
@@ -1996,11 +1706,14 @@ extern "C" int aggmg_hier_create(aggmg_ctx* ctx, int nlevels, aggmg_op* const* s
   h->restriction = default_restriction();
   h->coarse_mode = coarse_mode;
   h->lv.resize(nlevels);
+  for (int k = 0; k < nlevels; ++k)
+    if (!stiffness[k] || stiffness[k]->m != stiffness[k]->n)
+      return fail(ctx, AGGMG_ERR_DIMENSION, "aggmg_hier_create: stiffness must be square (and not NULL)");
   for (int k = 0; k < nlevels; ++k) {
     Level& l = h->lv[k];
     l.A = stiffness[k];
-    if (!l.A || l.A->m != l.A->n) return fail(ctx, AGGMG_ERR_DIMENSION, "aggmg_hier_create: stiffness must be square");
     l.N = l.A->m;
+    l.Nalloc = l.N;
     if (k < nlevels - 1) {
       l.S = smoothers[k];
       l.L = interpolation[k];
@@ -2009,9 +1722,12 @@ extern "C" int aggmg_hier_create(aggmg_ctx* ctx, int nlevels, aggmg_op* const* s
       if (l.L->m != l.N || l.L->n != stiffness[k + 1]->m)
         return fail(ctx, AGGMG_ERR_DIMENSION, "aggmg_hier_create: interpolation size mismatch at level " + std::to_string(k + 1));
       if (!l.L->csrT.rowptr) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_hier_create: interpolation must be uploaded with AGGMG_OP_TRANSFER");
+      if (l.S->cgt && l.S->A == l.A) l.Nalloc = std::max(l.N, l.S->cgt->ne * l.S->cgt->m);  // block order incl. padding
     }
-    for (double** p : {&l.u[0], &l.u[1], &l.rhs, &l.tmp})
-      HIPCHK(hipMalloc((void**)p, (size_t)std::max<int64_t>(l.N, 1) * sizeof(double)));
+    for (double** p : {&l.u[0], &l.u[1], &l.rhs, &l.tmp}) {
+      HIPCHK(hipMalloc((void**)p, (size_t)std::max<int64_t>(l.Nalloc, 1) * sizeof(double)));
+      HIPCHK(hipMemsetAsync(*p, 0, (size_t)std::max<int64_t>(l.Nalloc, 1) * sizeof(double), ctx->stream));
+    }
   }
   // structured transfers between consecutive levels whose fine side runs the fused kernel
   for (int k = 0; k + 1 < nlevels; ++k) {
@@ -2024,6 +1740,25 @@ extern "C" int aggmg_hier_create(aggmg_ctx* ctx, int nlevels, aggmg_op* const* s
     CHECK(build_transfer(ctx, l.L, l.A, l.S->btd->m, l.S->btd->ne, hint, tb.get(), &ok));
     if (ok) l.tb = std::move(tb);
   }
+  // CG chain levels: structured transfer to the next level; a level is fused when it has both
+  for (int k = 0; k + 1 < nlevels; ++k) {
+    Level& l = h->lv[k];
+    if (!(l.S->cgt && l.S->A == l.A)) continue;
+    const Level& c = h->lv[k + 1];
+    const CgtDev* coarse = (c.S && c.S->cgt && c.S->A == c.A) ? c.S->cgt.get() : nullptr;
+    int hint = 0;
+    if (c.S && c.S->btd && c.S->A == c.A) hint = c.S->btd->m;
+    auto tc = std::make_unique<TransferCgt>();
+    bool ok = false;
+    CHECK(cgt_build_transfer(ctx, l.L, *l.S->cgt, coarse, hint, tc.get(), &ok));
+    if (ok) {
+      l.tc = std::move(tc);
+      l.cgt_fused = true;
+    }
+  }
+  // a fused chain level below a fused chain level keeps its rhs / result in block order
+  for (int k = 0; k + 2 < nlevels; ++k)
+    if (h->lv[k].cgt_fused && h->lv[k].tc->type == kTrChain && h->lv[k + 1].cgt_fused) h->lv[k + 1].native_io = true;
   // coarsest level: factor once (unless the caller solves it elsewhere)
   if (coarse_mode != AGGMG_COARSE_EXTERNAL) {
     const aggmg_op* Ac = h->lv[nlevels - 1].A;
@@ -2068,6 +1803,10 @@ static int vcycle_down(aggmg_ctx* ctx, aggmg_hier* h, const double* x0, const do
     Level& c = h->lv[k + 1];
     const double* rhs = k == 0 ? b : l.rhs;
     const double* uin = k == 0 ? x0 : nullptr;  // u[k] = zeros for k > 1 (:29-31)
+    if (l.cgt_fused) {
+      CHECK(cgt_down(ctx, h, k, uin, rhs, nPre, alpha));
+      continue;
+    }
     const bool structured = l.S->btd && l.S->A == l.A;
     if (structured && l.tb && btd_fits(*l.S, nPre, 1)) {
       FusedArgs a = btd_args(*l.S->btd);
@@ -2137,6 +1876,12 @@ static int vcycle_up(aggmg_ctx* ctx, aggmg_hier* h, const double* b, int nPost, 
     const double* rhs = k == 0 ? b : l.rhs;
     double* dst = k == 0 ? x_out : l.u[1];
     const double* uc = (k + 1 == n - 1) ? c.u[0] : c.u[1];
+    if (l.cgt_fused) {
+      if (k == 0 && sel.mode != 0)
+        return fail(ctx, AGGMG_ERR_UNSUPPORTED, "split ascent needs the fused block-tridiagonal fine level");
+      CHECK(cgt_up(ctx, h, k, rhs, nPost, alpha, dst));
+      continue;
+    }
     const bool structured = l.S->btd && l.S->A == l.A;
     if (structured && l.tb && btd_fits(*l.S, nPost, 0)) {
       FusedArgs a = btd_args(*l.S->btd);
@@ -2367,6 +2112,20 @@ extern "C" int aggmg_vcycle(aggmg_ctx* ctx, aggmg_hier* h, const double* x0, con
   CHECK(dout.alloc(N, nullptr));
   CHECK(aggmg_vcycle_dev(ctx, h, dx.p, db.p, nPre, nPost, alpha, dout.p));
   return dout.fetch(N, x_out);
+}
+
+extern "C" int aggmg_hier_level_kind(aggmg_ctx* ctx, const aggmg_hier* h, int level, int* kind) {
+  if (!ctx || !h || !kind) return AGGMG_ERR_ARGUMENT;
+  if (level < 0 || level >= (int)h->lv.size()) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_hier_level_kind: level out of range");
+  const Level& l = h->lv[level];
+  *kind = AGGMG_LEVEL_GENERIC;
+  if (level == (int)h->lv.size() - 1)
+    *kind = AGGMG_LEVEL_COARSEST;
+  else if (l.cgt_fused)
+    *kind = AGGMG_LEVEL_FUSED_CHAIN;
+  else if (l.S && l.S->btd && l.S->A == l.A && l.tb)
+    *kind = AGGMG_LEVEL_FUSED_BTD;
+  return AGGMG_OK;
 }
 
 extern "C" int aggmg_hier_coarse_info(aggmg_ctx* ctx, const aggmg_hier* h, int* on_device, int* block_size,

@@ -1,0 +1,297 @@
+// Fused point-Jacobi kernel for continuous-Galerkin (CG) levels in element-contiguous order.
+//
+// The reference numbers a CgMesh "all vertices first, then the p-1 interior nodes of every element"
+// (src/cg_mesh.jl:37-45,59-65).  Renumbered element by element -- block e = [left vertex of
+// element e, its interior nodes], plus one trailing block holding the last vertex -- every CG
+// stiffness matrix (assembled or Galerkin-coarsened, src/mesh_heirarchy.jl:53-59) is
+// block-tridiagonal with m = p rows per block, and its off-diagonal blocks are thin:
+//
+//     Sub_e = A[block e, block e-1]  has ONE non-zero ROW    (row 0: vertex e sees all of element e-1)
+//     Sup_e = A[block e, block e+1]  has ONE non-zero COLUMN (column 0: element e sees vertex e+1)
+//
+// (the mirror image of the nodal-DG pattern of kernels.hpp).  Stored per level, fp64, no indices:
+//     dblk   [ne*M][M]  rows of the diagonal blocks        (the Jacobi diagonal is dblk[r][r % M])
+//     subrow [ne][M]    A[(e,0), (e-1, :)]
+//     supcol [ne*M]     A[(e,i), (e+1, 0)]
+// One workgroup owns a tile of blocks plus a halo, keeps the iterate in LDS (ping-pong) and its
+// operator rows in registers and runs
+//     [u += L uc]  ->  S sweeps  u += alpha * (b - A u) / diag(A)   ->  [r = b - A u  ->  rc = L' r]
+// on ONE pass over HBM (JacobiSmoother src/smoother.jl:52-58 inside the loop of src/solvers.jl:32-46).
+// The caller's vectors stay in the reference numbering: rows are fetched / stored through the
+// level's permutation where a vector crosses the library boundary, so no permutation pass exists.
+#pragma once
+#include "kernels.hpp"
+
+namespace aggmg {
+
+struct CgtLevel {
+  const double *dblk, *subrow, *supcol;
+  int64_t ne;  // blocks, the trailing (partial, identity-padded) one included
+};
+
+// which vectors of a launch live in the caller's numbering (indexed through perm)
+enum CgtExt : int { kExtUin = 1, kExtB = 2, kExtUout = 4, kExtRout = 8 };
+
+// structured transfers of a CG level (rows of L grouped per fine block; fine row r = e*M + i)
+//  chain  (CG p_hi -> CG p_lo, cg_cg_interpolation src/interpolation.jl:5-55): fine block e sees the
+//         mc DoFs of coarse block e and the first DoF of coarse block e+1 (the shared vertex):
+//         l [N][mc + 1]
+//  agg    (CG -> DG / agglomerated DG, dg_cg_ / aggdg_cg_interpolation :145-220,:330-410): fine block e
+//         sees coarse block J = e / rho; its vertex row also sees block J - 1 when e starts an
+//         agglomerate:  l [N][mc],  lp [ne][mc]
+enum CgtTransfer : int { kTrNone = 0, kTrChain = 1, kTrAgg = 2 };
+
+struct CgtXfer {
+  int type;
+  const double* l;
+  const double* lp;
+  const int32_t* cperm;  // chain only: coarse vector in the caller's numbering (null: block order)
+  int mc, rho;
+  int64_t nec;  // coarse blocks
+};
+
+struct CgtArgs {
+  CgtLevel lv;
+  const int32_t* perm;  // [ne*M] block order -> caller's numbering, -1 for padding rows
+  int ext;              // CgtExt mask
+  const double* u_in;   // nullptr: iterate starts at zero (src/solvers.jl:29-31)
+  const double* b;
+  double* u_out;        // nullptr: iterate not stored
+  double alpha;
+  int nsweeps;
+  CgtXfer tin;          // prolongation-add before the sweeps (src/solvers.jl:42)
+  const double* uc;
+  int do_residual;      // residual after the sweeps (src/solvers.jl:36)
+  double* r_out;
+  CgtXfer tout;         // restriction of that residual
+  double* rc_out;
+  int owned, halo_left;
+  int tile_split;
+  int64_t tile_skip;
+};
+
+__device__ __forceinline__ int64_t cgt_tile(const CgtArgs& a) {
+  return (int64_t)blockIdx.x + ((int)blockIdx.x >= a.tile_split ? a.tile_skip : 0);
+}
+
+template <int M, int NS, int NT>
+__global__ __launch_bounds__(NT) void cgt_fused_kernel(CgtArgs a) {
+  // GRP: a block's rows sit in M = 2^k adjacent lanes; lane i keeps entry i of the block's
+  // sub-diagonal row and the dot product with the left neighbour is a cross-lane sum
+  constexpr bool GRP = (M == 1 || M == 2 || M == 4 || M == 8);
+  constexpr int EPS = NT / M;
+  constexpr int TE = EPS * NS;
+  extern __shared__ double lds[];
+  double* buf0 = lds + M;  // index x*M + j, x in [-1, TE]
+  double* buf1 = lds + (TE + 2) * M + M;
+
+  const int tid = threadIdx.x;
+  const bool active = tid < EPS * M;
+  const int le = tid / M;
+  const int i = tid - le * M;
+  const int64_t ne = a.lv.ne;
+  const int64_t e0 = cgt_tile(a) * a.owned - a.halo_left;
+
+  if (tid < M) {
+    buf0[-M + tid] = 0.0;
+    buf0[TE * M + tid] = 0.0;
+    buf1[-M + tid] = 0.0;
+    buf1[TE * M + tid] = 0.0;
+  }
+
+  double d[NS][M], sup[NS], sr[NS][GRP ? 1 : M], dg[NS], bb[NS], uu[NS];
+  int32_t pr[NS];
+  bool valid[NS];
+
+  // ---- load phase ------------------------------------------------------------------------------
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const int x = s * EPS + le;
+    const int64_t e = e0 + x;
+    valid[s] = active && e >= 0 && e < ne;
+    const int64_t row = e * M + i;
+    uu[s] = 0.0;
+    bb[s] = 0.0;
+    sup[s] = 0.0;
+    dg[s] = 1.0;
+    pr[s] = -1;
+#pragma unroll
+    for (int j = 0; j < M; ++j) d[s][j] = 0.0;
+#pragma unroll
+    for (int j = 0; j < (GRP ? 1 : M); ++j) sr[s][j] = 0.0;
+    if (valid[s]) {
+#pragma unroll
+      for (int j = 0; j < M; ++j) d[s][j] = AGGMG_LD(a.lv.dblk[row * M + j]);
+#pragma unroll
+      for (int j = 0; j < M; ++j)
+        if (j == i) dg[s] = d[s][j];
+      sup[s] = AGGMG_LD(a.lv.supcol[row]);
+      if (GRP) {
+        sr[s][0] = AGGMG_LD(a.lv.subrow[row]);  // entry i of the block's sub-diagonal row
+      } else if (i == 0) {
+#pragma unroll
+        for (int j = 0; j < (GRP ? 1 : M); ++j) sr[s][j] = a.lv.subrow[e * M + j];
+      }
+      if (a.ext) pr[s] = a.perm[row];
+      const int64_t rb = (a.ext & kExtB) ? (int64_t)pr[s] : row;
+      if (rb >= 0) bb[s] = a.b[rb];
+      if (a.u_in) {
+        const int64_t ru = (a.ext & kExtUin) ? (int64_t)pr[s] : row;
+        if (ru >= 0) uu[s] = a.u_in[ru];
+      }
+      if (a.tin.type == kTrChain) {
+        const int mc = a.tin.mc;
+        const double* lr = a.tin.l + row * (mc + 1);
+        double add = 0.0;
+        for (int c = 0; c <= mc; ++c) {
+          // coarse block e, DoF c; the last entry is DoF 0 of coarse block e + 1
+          const int64_t cb = c < mc ? e * mc + c : (e + 1) * mc;
+          if (cb >= a.tin.nec * mc) continue;
+          const int64_t ci = a.tin.cperm ? (int64_t)a.tin.cperm[cb] : cb;
+          if (ci >= 0) add += lr[c] * a.uc[ci];
+        }
+        uu[s] += add;
+      } else if (a.tin.type == kTrAgg) {
+        const int mc = a.tin.mc;
+        const int64_t J = e / a.tin.rho;
+        double add = 0.0;
+        if (i == 0 && J >= 1 && e == J * a.tin.rho)
+          for (int c = 0; c < mc; ++c) add += a.tin.lp[e * mc + c] * a.uc[(J - 1) * mc + c];
+        if (J < a.tin.nec)
+          for (int c = 0; c < mc; ++c) add += a.tin.l[row * mc + c] * a.uc[J * mc + c];
+        uu[s] += add;
+      }
+    }
+    if (active) buf0[x * M + i] = uu[s];
+  }
+  __syncthreads();
+
+  // A u for this thread's row out of the LDS iterate `cur`, in ascending column order of the
+  // reference numbering (left block's vertex, own vertex, right vertex, then interior nodes)
+  auto row_Au = [&](int s, int x, const double* cur) -> double {
+    const double* um = cur + (x - 1) * M;
+    const double* ux = cur + x * M;
+    const double* up = cur + (x + 1) * M;
+    double t;
+    if (GRP) {
+      t = group_sum<M>(sr[s][0] * um[i]);
+      if (i != 0) t = 0.0;
+    } else {
+      t = 0.0;
+      if (i == 0) {
+#pragma unroll
+        for (int j = 0; j < (GRP ? 1 : M); ++j) t += sr[s][j] * um[j];
+      }
+    }
+    t += d[s][0] * ux[0];
+    t += sup[s] * up[0];
+#pragma unroll
+    for (int j = 1; j < M; ++j) t += d[s][j] * ux[j];
+    return t;
+  };
+
+  // ---- sweeps: u <- u + alpha * ((b - A u) / diag)   (LDS ping-pong) ------------------------------
+  double* cur = buf0;
+  double* nxt = buf1;
+  for (int sw = 0; sw < a.nsweeps; ++sw) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const int x = s * EPS + le;
+      if (active) {
+        const double r = bb[s] - row_Au(s, x, cur);
+        const double y = r / dg[s];
+        double un = uu[s] + a.alpha * y;
+        if (!valid[s]) un = 0.0;
+        uu[s] = un;
+        nxt[x * M + i] = un;
+      }
+    }
+    __syncthreads();
+    double* t = cur;
+    cur = nxt;
+    nxt = t;
+  }
+
+  // ---- store the iterate of the owned blocks -------------------------------------------------------
+  const int xo0 = a.halo_left, xo1 = a.halo_left + a.owned;
+  if (a.u_out) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const int x = s * EPS + le;
+      if (valid[s] && x >= xo0 && x < xo1) {
+        const int64_t ro = (a.ext & kExtUout) ? (int64_t)pr[s] : (e0 + x) * M + i;
+        if (ro >= 0) AGGMG_ST(a.u_out[ro], uu[s]);
+      }
+    }
+  }
+  if (!a.do_residual) return;
+
+  // ---- residual r = b - A u: owned blocks, plus the one block whose rows the restriction of an
+  // owned coarse block also touches (chain: the block on the left, agg: the vertex on the right) ----
+  const int xr0 = xo0 - (a.tout.type == kTrChain ? 1 : 0);
+  const int xr1 = xo1 + (a.tout.type == kTrAgg ? 1 : 0);
+  double rr[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const int x = s * EPS + le;
+    rr[s] = 0.0;
+    if (active) {
+      const double t = row_Au(s, x, cur);  // every lane of a group takes part in the cross-lane sum
+      if (valid[s] && x >= xr0 && x < xr1) {
+        rr[s] = bb[s] - t;
+        if (a.r_out && x >= xo0 && x < xo1) {
+          const int64_t ro = (a.ext & kExtRout) ? (int64_t)pr[s] : (e0 + x) * M + i;
+          if (ro >= 0) a.r_out[ro] = rr[s];
+        }
+      }
+    }
+  }
+  if (a.tout.type == kTrNone) return;
+
+  // ---- restriction rc = L' r: r through LDS, one thread per owned coarse DoF ------------------------
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const int x = s * EPS + le;
+    if (active) nxt[x * M + i] = rr[s];
+  }
+  __syncthreads();
+  const int mc = a.tout.mc;
+  if (a.tout.type == kTrChain) {
+    const double* L = a.tout.l;
+    const int w = mc + 1;
+    for (int t = tid; t < a.owned * mc; t += NT) {
+      const int xl = t / mc, c = t - xl * mc;
+      const int x = xo0 + xl;
+      const int64_t J = e0 + x;  // coarse block = fine block
+      if (J >= ne || J >= a.tout.nec) continue;
+      const int64_t rowb = J * M;
+      // ascending fine row of the reference numbering: own vertex, the left element's rows, own interior
+      double acc = L[rowb * w + c] * nxt[x * M];
+      if (c == 0 && J > 0)
+        for (int k = 0; k < M; ++k) acc += L[(rowb - M + k) * w + mc] * nxt[(x - 1) * M + k];
+      for (int k = 1; k < M; ++k) acc += L[(rowb + k) * w + c] * nxt[x * M + k];
+      const int64_t cb = J * mc + c;
+      const int64_t ci = a.tout.cperm ? (int64_t)a.tout.cperm[cb] : cb;
+      if (ci >= 0) a.rc_out[ci] = acc;
+    }
+  } else {
+    const int rho = a.tout.rho;
+    const int ncoarse = a.owned / rho;
+    const int64_t J0 = (cgt_tile(a) * a.owned) / rho;
+    for (int t = tid; t < ncoarse * mc; t += NT) {
+      const int Jl = t / mc, c = t - Jl * mc;
+      const int64_t J = J0 + Jl;
+      if (J >= a.tout.nec) continue;
+      const int xb = xo0 + Jl * rho;
+      const int64_t rowb = (e0 + xb) * (int64_t)M;
+      double acc = 0.0;
+      for (int k = 0; k < rho * M; ++k) acc += a.tout.l[(rowb + k) * mc + c] * nxt[xb * M + k];
+      // the vertex that closes the agglomerate on the right belongs to the next fine block
+      const int64_t en = (J + 1) * rho;
+      if (en < ne) acc += a.tout.lp[en * mc + c] * nxt[(xb + rho) * M];
+      a.rc_out[J * mc + c] = acc;
+    }
+  }
+}
+
+}  // namespace aggmg

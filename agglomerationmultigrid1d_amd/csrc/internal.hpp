@@ -1,0 +1,357 @@
+// Shared internals of libaggmg_hip: the objects behind the opaque handles of include/aggmg_hip.h
+// and the small host helpers every translation unit of the library uses (error reporting,
+// uploads, scratch vectors, the HIP-event profiler, the set-up thread pool).
+#pragma once
+#include "../../include/aggmg_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "kernels.hpp"
+#include "cgt_kernels.hpp"
+
+using namespace aggmg;
+
+// ---------------------------------------------------------------------------------------------
+// objects behind the opaque handles
+// ---------------------------------------------------------------------------------------------
+inline thread_local std::string g_create_error;
+
+struct ProfEvent {
+  hipEvent_t a, b;
+  int tag;
+};
+
+struct aggmg_ctx {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  std::string err;
+  int profiling = 0;  // 0 off, 1 every launch, 2 only the fine-level fused-down launch (dominant kernel)
+  std::vector<ProfEvent> prof;
+  std::vector<hipEvent_t> ev_pool;
+  // scratch vectors for ping-pong / temporaries, grown on demand
+  double* scratch[3] = {nullptr, nullptr, nullptr};
+  int64_t scratch_len[3] = {0, 0, 0};
+  // outer-solver work space (aggmg_multigrid_dev, aggmg_pcg_dev, ...): vectors, dot-product
+  // partials and the device-resident scalars
+  double* solv[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  int64_t solv_len[5] = {0, 0, 0, 0, 0};
+  double* solv_part = nullptr;
+  double* solv_sc = nullptr;
+};
+
+struct CsrDev {
+  int64_t nrows = 0, ncols = 0, nnz = 0;
+  int32_t* rowptr = nullptr;
+  int32_t* colind = nullptr;
+  double* vals = nullptr;
+  int lpr = 1;
+  int32_t* rowblk = nullptr;  // CSR-stream row blocks (short-row matrices), nblk + 1 entries
+  int64_t nblk = 0;
+  CsrView view() const { return CsrView{rowptr, colind, vals, nrows}; }
+};
+
+struct HostCsr {
+  std::vector<int32_t> rowptr, colind;
+  std::vector<double> vals;
+};
+
+// index-free block-tridiagonal form of an operator + its block-Jacobi smoother; shared by the
+// smoother that built it and the operator it describes (so aggmg_residual can use it too)
+struct BtdDev {
+  int m = 0;
+  int64_t ne = 0;
+  bool cmp = false;
+  int c_sub = 0, r_sup = 0;
+  double *binv = nullptr, *dblk = nullptr, *scol = nullptr, *pcol = nullptr, *qrow = nullptr;
+  double* bsym = nullptr;  // packed symmetric inverses (replaces binv + pcol in the kernels) or null
+  double *sub = nullptr, *sup = nullptr, *P = nullptr, *Q = nullptr;
+  ~BtdDev() {
+    for (double* p : {binv, dblk, scol, pcol, qrow, bsym, sub, sup, P, Q})
+      if (p) (void)hipFree(p);
+  }
+};
+
+// element-contiguous ("chain") form of a CG operator + its point-Jacobi smoother (cgt_kernels.hpp);
+// shared by the smoother that built it and the operator it describes
+struct CgtDev {
+  int m = 0;        // rows per block = p
+  int64_t ne = 0;   // blocks = elements + 1 (the trailing one holds the last vertex, identity-padded)
+  int64_t N = 0;    // DoFs of the operator; the block-ordered vectors have ne * m entries
+  double *dblk = nullptr, *subrow = nullptr, *supcol = nullptr;
+  int32_t* perm = nullptr;            // [ne*m] block order -> reference numbering, -1 = padding
+  std::vector<int32_t> h_perm, h_inv; // host copies: block order -> reference, reference -> block order
+  ~CgtDev() {
+    for (void* p : {(void*)dblk, (void*)subrow, (void*)supcol, (void*)perm})
+      if (p) (void)hipFree(p);
+  }
+};
+
+struct aggmg_op {
+  int64_t m = 0, n = 0, nnz = 0;
+  int kind = AGGMG_OP_STIFFNESS;
+  CsrDev csr;   // row-gather form of the matrix
+  CsrDev csrT;  // row-gather form of its transpose (transfers only)
+  HostCsr host; // host CSR kept for smoother / structure set-up until released
+  bool host_valid = false;
+  std::shared_ptr<BtdDev> btd;  // set when a block-Jacobi smoother recognised the structure
+  std::shared_ptr<CgtDev> cgt;  // set when a point-Jacobi smoother was given the CG element chain
+};
+
+struct aggmg_smoother {
+  int kind = 0;  // 0 point Jacobi, 1 block (Jacobi / additive Schwarz), 2 hybrid Schwarz
+  aggmg_op* A = nullptr;
+  int64_t N = 0, m = 0, nb = 0;
+  double* diag = nullptr;      // point Jacobi
+  double* binv = nullptr;      // [nb][m][m] row-major
+  int32_t* inds = nullptr;     // [nb][m]
+  double* counts = nullptr;    // hybrid Schwarz
+  bool overlapping = false;
+  bool contiguous = false;
+  bool gs = false;  // red-black block Gauss-Seidel (extension): needs the structured form
+  std::shared_ptr<BtdDev> btd;  // structured fused form, or null
+  std::shared_ptr<CgtDev> cgt;  // CG chain form (point Jacobi with the element lists), or null
+  // owns its device arrays: every early return of a set-up routine releases what was uploaded
+  ~aggmg_smoother() {
+    for (void* p : {(void*)diag, (void*)binv, (void*)inds, (void*)counts})
+      if (p) (void)hipFree(p);
+  }
+};
+
+struct TransferBtd {
+  int mc = 0, rho = 0;
+  double* lf = nullptr;  // [N_f][mc]  rows of L
+  double* ld = nullptr;  // [N_f][mc]  rows of (L_e' D_e)': restriction of the preconditioned residual
+  ~TransferBtd() {
+    if (lf) (void)hipFree(lf);
+    if (ld) (void)hipFree(ld);
+  }
+};
+
+// structured transfer of a CG chain level (CgtXfer in cgt_kernels.hpp)
+struct TransferCgt {
+  int type = 0, mc = 0, rho = 1;
+  int64_t nec = 0;
+  double *l = nullptr, *lp = nullptr;
+  int32_t* cperm = nullptr;  // chain: coarse block order -> coarse reference numbering
+  ~TransferCgt() {
+    for (void* p : {(void*)l, (void*)lp, (void*)cperm})
+      if (p) (void)hipFree(p);
+  }
+};
+
+struct Level {
+  aggmg_op* A = nullptr;
+  aggmg_smoother* S = nullptr;
+  aggmg_op* L = nullptr;  // level k+1 -> k
+  int64_t N = 0;
+  double *u[2] = {nullptr, nullptr}, *rhs = nullptr, *tmp = nullptr;
+  std::unique_ptr<TransferBtd> tb;  // structured transfer to level k+1, or null
+  std::unique_ptr<TransferCgt> tc;  // CG chain level: structured transfer to level k+1, or null
+  bool cgt_fused = false;           // the level runs cgt_fused_kernel (chain form + structured transfer)
+  bool native_io = false;           // rhs and u[1] are kept in block order (the finer level is a fused chain level)
+  int64_t Nalloc = 0;               // length of the level's vectors (ne * m for chain levels)
+};
+
+struct BandedLU {
+  int64_t n = 0;
+  int kl = 0, ku = 0, ldab = 0;
+  std::vector<double> ab;
+  std::vector<int32_t> ipiv;
+};
+
+// block cyclic reduction of the coarsest operator, factored once (device-resident)
+struct CrDev {
+  bool valid = false;
+  int m = 0;
+  int64_t n0 = 0, N = 0;
+  std::vector<CrLevel> lv;      // all reducing levels (device pointers)
+  std::vector<void*> owned;     // every device allocation, for free
+  const double* lu_last = nullptr;
+  const int32_t* perm_last = nullptr;
+  int nglobal = 0;              // leading levels run as their own launches (only for very large systems)
+  int q = 0;                    // next q levels run chunk-wise in LDS (one launch forward, one backward)
+  std::vector<double*> d, x;    // per-level vectors for levels 0..nglobal
+  double *partR = nullptr, *partL = nullptr, *xq = nullptr;  // chunk-boundary vectors (level nglobal+q)
+  double* stack = nullptr;      // per-chunk reduced right-hand sides of the chunk levels
+  int stack_stride = 0;
+  size_t tail_lds = 0, chunk_lds = 0;
+  double cond_est = 0.0;
+};
+
+struct aggmg_hier {
+  std::vector<Level> lv;
+  int coarse_mode = 0;
+  BandedLU coarse;
+  CrDev cr;
+  double* cyc[2] = {nullptr, nullptr};  // iterate ping-pong for multi-cycle calls (lazy)
+  int restriction = 0;  // AGGMG_RESTRICT_EXPLICIT (default) / AGGMG_RESTRICT_PRECONDITIONED
+  std::vector<double> h_coarse;
+  double last_coarse_ms = 0.0;
+  // owns every device allocation of its levels: an early return of aggmg_hier_create releases them
+  ~aggmg_hier() {
+    for (auto& l : lv)
+      for (double* p : {l.u[0], l.u[1], l.rhs, l.tmp})
+        if (p) (void)hipFree(p);
+    for (void* p : cr.owned)
+      if (p) (void)hipFree(p);
+    for (double* p : cyc)
+      if (p) (void)hipFree(p);
+  }
+};
+
+// The restricted residual L'(b - A u) is formed from r = b - A u evaluated with the operator's own
+// entries (the reference's arithmetic, src/solvers.jl:36) -- AGGMG_RESTRICT_EXPLICIT, the default.
+// AGGMG_RESTRICT_PRECONDITIONED takes it from the sweeps' preconditioned residual instead,
+// (L'D) w with w = g - P u- - Q u+ - u, which reads neither the diagonal blocks nor L: equal in
+// exact arithmetic, but w inherits the rounding of the stored (symmetrically packed) B^{-1}, P, Q.
+// On the smoothest mode of the model problem that error grows like n^2 and at 2^24 fine elements
+// turns the cycle from damping (x0.5, as in reference-order arithmetic) into amplifying (x2.1):
+// measured, include/aggmg_hip.h and DESIGN.md section 5.  AGGMG_RESTRICT=preconditioned sets the
+// initial mode of new hierarchies.
+inline int default_restriction() {
+  const char* e = std::getenv("AGGMG_RESTRICT");
+  return (e && std::string(e) == "preconditioned") ? AGGMG_RESTRICT_PRECONDITIONED : AGGMG_RESTRICT_EXPLICIT;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host-side parallel loop for the O(n) set-up passes (block extraction / inversion, format
+// conversion, cyclic-reduction factorisation).  Plain std::thread: no OpenMP runtime is pulled
+// into a process that already hosts numpy's and torch's.
+// ---------------------------------------------------------------------------------------------
+inline int setup_threads() {
+  static int n = [] {
+    const char* e = std::getenv("AGGMG_SETUP_THREADS");
+    int v = e ? std::atoi(e) : 0;
+    if (v <= 0) {
+      v = (int)std::thread::hardware_concurrency();
+      if (const char* o = std::getenv("OMP_NUM_THREADS")) v = std::min(v, std::max(1, std::atoi(o)));
+      v = std::min(v, 16);
+    }
+    return std::max(1, v);
+  }();
+  return n;
+}
+
+template <typename F>
+inline void parallel_for(int64_t n, F&& body) {  // body(begin, end)
+  const int nt = (int)std::min<int64_t>(setup_threads(), std::max<int64_t>(1, n / 4096));
+  if (nt <= 1) {
+    body((int64_t)0, n);
+    return;
+  }
+  std::vector<std::thread> th;
+  const int64_t chunk = (n + nt - 1) / nt;
+  for (int t = 0; t < nt; ++t) {
+    const int64_t b = t * chunk, e = std::min(n, b + chunk);
+    if (b >= e) break;
+    th.emplace_back([&body, b, e] { body(b, e); });
+  }
+  for (auto& t : th) t.join();
+}
+
+// ---------------------------------------------------------------------------------------------
+// error helpers
+// ---------------------------------------------------------------------------------------------
+inline int fail(aggmg_ctx* ctx, int code, const std::string& msg) {
+  if (ctx)
+    ctx->err = msg;
+  else
+    g_create_error = msg;
+  return code;
+}
+
+#define HIPCHK(expr)                                                                        \
+  do {                                                                                      \
+    hipError_t _e = (expr);                                                                 \
+    if (_e != hipSuccess)                                                                   \
+      return fail(ctx, AGGMG_ERR_HIP,                                                       \
+                  std::string(#expr) + ": " + hipGetErrorString(_e) + " (" + __FILE__ + ":" + \
+                      std::to_string(__LINE__) + ")");                                      \
+  } while (0)
+
+#define CHECK(expr)             \
+  do {                          \
+    int _s = (expr);            \
+    if (_s != AGGMG_OK) return _s; \
+  } while (0)
+
+template <typename T>
+inline int dev_upload(aggmg_ctx* ctx, const std::vector<T>& h, T** d) {
+  *d = nullptr;
+  size_t bytes = std::max<size_t>(h.size(), 1) * sizeof(T);
+  HIPCHK(hipMalloc((void**)d, bytes));
+  if (!h.empty())
+    HIPCHK(hipMemcpyAsync(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return AGGMG_OK;
+}
+
+inline int scratch(aggmg_ctx* ctx, int slot, int64_t len, double** out) {
+  if (ctx->scratch_len[slot] < len) {
+    if (ctx->scratch[slot]) {
+      HIPCHK(hipStreamSynchronize(ctx->stream));
+      HIPCHK(hipFree(ctx->scratch[slot]));
+    }
+    ctx->scratch[slot] = nullptr;
+    ctx->scratch_len[slot] = 0;
+    HIPCHK(hipMalloc((void**)&ctx->scratch[slot], (size_t)std::max<int64_t>(len, 1) * sizeof(double)));
+    ctx->scratch_len[slot] = len;
+  }
+  *out = ctx->scratch[slot];
+  return AGGMG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// profiler (HIP events on the launch stream)
+// ---------------------------------------------------------------------------------------------
+struct ProfScope {
+  aggmg_ctx* ctx;
+  int idx = -1;
+  ProfScope(aggmg_ctx* c, int kind, int level) : ctx(c) {
+    if (!ctx->profiling) return;
+    if (ctx->profiling == 2 && !(kind == AGGMG_KIND_FUSED_DOWN && level == 0)) return;
+    ProfEvent pe;
+    for (hipEvent_t* e : {&pe.a, &pe.b}) {
+      if (!ctx->ev_pool.empty()) {
+        *e = ctx->ev_pool.back();
+        ctx->ev_pool.pop_back();
+      } else if (hipEventCreateWithFlags(e, hipEventDisableSystemFence) != hipSuccess) {
+        return;
+      }
+    }
+    pe.tag = kind * 16 + (level & 15);
+    (void)hipEventRecord(pe.a, ctx->stream);
+    ctx->prof.push_back(pe);
+    idx = (int)ctx->prof.size() - 1;
+  }
+  ~ProfScope() {
+    if (idx >= 0) (void)hipEventRecord(ctx->prof[idx].b, ctx->stream);
+  }
+};
+
+
+// ---------------------------------------------------------------------------------------------
+// CG chain path (cgt.hip)
+// ---------------------------------------------------------------------------------------------
+int cgt_build(aggmg_ctx* ctx, aggmg_smoother* sm, const int64_t* elems, int64_t m1, int64_t nel, int one_based);
+int cgt_build_transfer(aggmg_ctx* ctx, const aggmg_op* L, const CgtDev& fine, const CgtDev* coarse, int hint_mc,
+                       TransferCgt* out, bool* ok);
+// nsweeps sweeps on external (reference-numbered) vectors; u_in may be nullptr (zero), u_out != u_in
+int cgt_smooth_ext(aggmg_ctx* ctx, const CgtDev& g, const double* u_in, const double* b, double alpha, int nsweeps,
+                   double* u_out, int level);
+int cgt_residual_ext(aggmg_ctx* ctx, const CgtDev& g, const double* u, const double* b, double* r_out);
+int cgt_down(aggmg_ctx* ctx, aggmg_hier* h, int k, const double* uin, const double* rhs, int nPre, double alpha);
+int cgt_up(aggmg_ctx* ctx, aggmg_hier* h, int k, const double* rhs, int nPost, double alpha, double* dst);

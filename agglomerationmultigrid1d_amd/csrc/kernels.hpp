@@ -153,7 +153,7 @@ __global__ __launch_bounds__(kThreads) void block_apply_kernel(const double* __r
 }
 
 // out = (u ? u : 0) + alpha * (y / (cnt ? cnt : 1))
-__global__ __launch_bounds__(kThreads) void axpy_scaled_kernel(int64_t n, const double* __restrict__ u,
+static __global__ __launch_bounds__(kThreads) void axpy_scaled_kernel(int64_t n, const double* __restrict__ u,
                                                                const double* __restrict__ y,
                                                                const double* __restrict__ cnt,
                                                                double alpha, double* __restrict__ out) {
@@ -175,7 +175,7 @@ struct CopySegs {
   int64_t rows[4], cols[4], src_ld[4], dst_ld[4];
 };
 
-__global__ __launch_bounds__(kThreads) void copy_segments_kernel(CopySegs S) {
+static __global__ __launch_bounds__(kThreads) void copy_segments_kernel(CopySegs S) {
   const int g = blockIdx.y;
   const int64_t n = S.rows[g] * S.cols[g];
   for (int64_t t = (int64_t)blockIdx.x * kThreads + threadIdx.x; t < n; t += (int64_t)gridDim.x * kThreads) {
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(kThreads) void copy_segments_kernel(CopySegs S) {
 constexpr int kDotBlocks = 1024;  // fixed grid and fixed summation tree: results are reproducible
 
 // partial[b] = sum_{i in slice b} x_i y_i   (slice = contiguous n / gridDim range)
-__global__ __launch_bounds__(kThreads) void dot_partial_kernel(int64_t n, const double* __restrict__ x,
+static __global__ __launch_bounds__(kThreads) void dot_partial_kernel(int64_t n, const double* __restrict__ x,
                                                                const double* __restrict__ y,
                                                                double* __restrict__ partial) {
   __shared__ double sh[kThreads];
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(kThreads) void dot_partial_kernel(int64_t n, const 
 }
 
 // out[0] = sum of the partials (one workgroup), optionally its square root
-__global__ __launch_bounds__(kThreads) void dot_final_kernel(int nparts, const double* __restrict__ partial,
+static __global__ __launch_bounds__(kThreads) void dot_final_kernel(int nparts, const double* __restrict__ partial,
                                                              double* __restrict__ out, int take_sqrt) {
   __shared__ double sh[kThreads];
   double acc = 0.0;
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(kThreads) void dot_final_kernel(int nparts, const d
 }
 
 // PCG step with q = -A p (the residual kernel's sign):  a = rz / (-(p.q));  x += a p;  r += a q
-__global__ __launch_bounds__(kThreads) void pcg_xr_kernel(int64_t n, double* __restrict__ x, double* __restrict__ r,
+static __global__ __launch_bounds__(kThreads) void pcg_xr_kernel(int64_t n, double* __restrict__ x, double* __restrict__ r,
                                                           const double* __restrict__ p,
                                                           const double* __restrict__ q,
                                                           const double* __restrict__ rz,
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(kThreads) void pcg_xr_kernel(int64_t n, double* __r
 }
 
 // p = z + (rz_new / rz_old) p
-__global__ __launch_bounds__(kThreads) void pcg_p_kernel(int64_t n, double* __restrict__ p,
+static __global__ __launch_bounds__(kThreads) void pcg_p_kernel(int64_t n, double* __restrict__ p,
                                                          const double* __restrict__ z,
                                                          const double* __restrict__ rz_new,
                                                          const double* __restrict__ rz_old) {

@@ -94,6 +94,19 @@ int aggmg_blockjacobi_setup(aggmg_ctx* ctx, aggmg_op* A, int64_t m, int64_t nb,
                             aggmg_smoother** out);
 /* dg_smoother / cg_smoother (..., :jac): JacobiSmoother(Diagonal(A)) src/smoother.jl:95-102,146-152 */
 int aggmg_jacobi_setup(aggmg_ctx* ctx, aggmg_op* A, aggmg_smoother** out);
+/* cg_smoother(cgMesh, A, :jac) src/smoother.jl:88-102 with the element node lists the reference's
+ * cg_smoother holds in cgMesh.mElements[k].mNodesInd (the (p+1) x n matrix its Schwarz variants store
+ * as mBlockInds, src/smoother.jl:104-134): element_nodes is that matrix, column-major, 1-based when
+ * one_based != 0, local node order [left vertex, right vertex, interior nodes] (src/cg_mesh.jl:35-45).
+ * Same smoother as aggmg_jacobi_setup (Diagonal(A)); when consecutive elements share exactly one node
+ * and every stored entry of A couples nodes of one element (true of every CG stiffness matrix and
+ * of its Galerkin coarsenings, src/mesh_heirarchy.jl:53-59) the level additionally gets the
+ * element-contiguous "chain" form and runs the LDS-tiled fused point-Jacobi kernel
+ * (aggmg_smoother_is_structured reports 1).  Vectors stay in the reference's vertices-first
+ * numbering (src/cg_mesh.jl:37-45,59-65) at every entry point.  Anything else falls back to the
+ * generic CSR kernels with identical results. */
+int aggmg_jacobi_setup_elements(aggmg_ctx* ctx, aggmg_op* A, int64_t nodes_per_element, int64_t n_elements,
+                                const int64_t* element_nodes, int one_based, aggmg_smoother** out);
 /* BlockDiagonal (factorize = 0: apply = `A * X`, mul! src/block_diagonal.jl:166-176) and
  * BlockDiagonalLU (factorize = 1: apply = `A \\ X`, ldiv! :299-309; `lu(A)` :276) as block objects of
  * the same kind as the block smoother: blocks = nb dense m x m blocks, each column-major, with the
@@ -205,6 +218,14 @@ int aggmg_coarse_boundary_solve_dev(aggmg_ctx* ctx, aggmg_hier* h, const double*
                                     double* xq);
 int aggmg_coarse_chunk_backward_dev(aggmg_ctx* ctx, aggmg_hier* h, const double* rhs_owned, int64_t blk_lo,
                                     int64_t blk_hi, const double* xq, double* x_owned);
+/* Which kernels smooth a level (level 0 = finest): the fused block-tridiagonal kernel (DG /
+ * agglomerated levels), the fused chain kernel (CG levels set up with aggmg_jacobi_setup_elements),
+ * the generic CSR kernels, or -- last level -- the coarsest direct solve. */
+#define AGGMG_LEVEL_GENERIC 0
+#define AGGMG_LEVEL_FUSED_BTD 1
+#define AGGMG_LEVEL_FUSED_CHAIN 2
+#define AGGMG_LEVEL_COARSEST 3
+int aggmg_hier_level_kind(aggmg_ctx* ctx, const aggmg_hier* h, int level, int* kind);
 /* Which coarsest solver a hierarchy uses: on_device (1 = cyclic reduction), its block size and the
  * largest pivot-block condition estimate met while factoring (0 for the host solver). */
 int aggmg_hier_coarse_info(aggmg_ctx* ctx, const aggmg_hier* h, int* on_device, int* block_size,

@@ -93,7 +93,7 @@ def test_apply_smoother_seam(oracle, mg):
     for kind in ('jac', 'addSchwarz', 'hybridSchwarz'):
         So = o.cg_smoother(cg, A, kind)
         Sg = mg.cg_smoother(cg, A, kind)
-        assert not Sg.structured
+        assert Sg.structured == (kind == 'jac')   # the CG mesh's element lists give :jac the chain form
         for alpha in (1.0, 0.5):
             assert rel(mg.apply_smoother(Sg, B[:, 0], alpha), o.apply_smoother(So, B[:, 0], alpha)) < TOL
             Y = mg.apply_smoother(Sg, B, alpha)
@@ -311,11 +311,16 @@ def test_vcycle_dg_p_hierarchy(oracle, mg):
 
 
 def test_vcycle_config1_cg_plus_dg0(oracle, mg):
-    """BASELINE config 1: CG n=1024 p=1, point-Jacobi, + DG p=0 coarse level (generic CSR path)."""
+    """BASELINE config 1: CG n=1024 p=1, point-Jacobi, + DG p=0 coarse level.  With the mesh's element
+    lists the CG level runs the fused chain kernel; without them (operators only) the generic CSR path."""
     o = oracle
     Ho, b = o.build_cg_hierarchy(1024, ps=(1,), nDG=1, pDG=0)
     H, x, xr = check_vcycle(o, mg, Ho, b, it_tol=1e-8)
-    assert not any(H.structured_levels())
+    assert H.level_kinds() == ['fused_chain', 'coarsest']
+    Hg = mg.MeshHierarchy(None, Ho.mStiffness, Ho.mSmoothers, Ho.mInterpolation)
+    assert Hg.level_kinds() == ['generic', 'coarsest']
+    xg = mg.multigrid_v_cycle(Hg, np.zeros(len(b)), b)
+    assert np.linalg.norm(Ho.mStiffness[0] @ (xg - xr)) <= TOL * np.linalg.norm(b)
 
 
 def test_vcycle_mixed_cg_dg_agg(oracle, mg):
