@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("AGGMG_HIP_LIB") or os.path.join(_HERE, "libaggmg_hip.
 AGGMG_OK = 0
 ERR_ARGUMENT, ERR_DIMENSION, ERR_SINGULAR, ERR_HIP, ERR_UNSUPPORTED = -1, -2, -3, -4, -5
 OP_STIFFNESS, OP_TRANSFER = 0, 1
+OPT_SYMMETRIC_PACKING = 1
 PROFILE_NTAGS = 256
 KIND_FUSED_DOWN, KIND_FUSED_UP, KIND_SMOOTH, KIND_RESIDUAL, KIND_RESTRICT, KIND_PROLONG, \
     KIND_JACOBI, KIND_BLOCK_APPLY, KIND_COARSE, KIND_FUSED_MID = range(10)
@@ -22,6 +23,7 @@ KIND_NAMES = ["fused_down", "fused_up", "smooth", "residual", "restrict", "prolo
 COARSE_HOST_BANDED, COARSE_DEVICE_CR, COARSE_AUTO, COARSE_EXTERNAL = 0, 1, 2, 3
 # aggmg_hier_set_restriction modes (include/aggmg_hip.h)
 RESTRICT_EXPLICIT, RESTRICT_PRECONDITIONED = 0, 1
+RESTRICT_PRECONDITIONED_MAX_ELEMS = 1 << 21
 # aggmg_hier_level_kind
 LEVEL_GENERIC, LEVEL_FUSED_BTD, LEVEL_FUSED_CHAIN, LEVEL_COARSEST = 0, 1, 2, 3
 LEVEL_KIND_NAMES = ["generic", "fused_btd", "fused_chain", "coarsest"]
@@ -69,6 +71,7 @@ SYMBOLS = {
     "aggmg_set_stream": (c_int, [_P, _P]),
     "aggmg_reset_stream": (c_int, [_P]),
     "aggmg_synchronize": (c_int, [_P]),
+    "aggmg_set_option": (c_int, [_P, c_int, c_int]),
     "aggmg_dev_alloc": (c_int, [_P, c_int64, POINTER(_P)]),
     "aggmg_dev_free": (c_int, [_P, _P]),
     "aggmg_memcpy_h2d": (c_int, [_P, _P, _P, c_int64]),
@@ -102,6 +105,7 @@ SYMBOLS = {
     "aggmg_vcycle_dev": (c_int, [_P, _P, _P, _P, c_int, c_int, c_double, _P]),
     "aggmg_vcycles_dev": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_double, _P]),
     "aggmg_hier_set_restriction": (c_int, [_P, _P, c_int]),
+    "aggmg_hier_get_restriction": (c_int, [_P, _P, POINTER(c_int)]),
     "aggmg_vcycle_down_dev": (c_int, [_P, _P, _P, _P, c_int, c_double]),
     "aggmg_vcycle_up_dev": (c_int, [_P, _P, _P, c_int, c_double, _P]),
     "aggmg_vcycle_up_split_dev": (c_int, [_P, _P, _P, c_int, c_double, _P, c_int64, c_int64, c_int]),

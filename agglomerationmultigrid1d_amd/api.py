@@ -73,6 +73,10 @@ class Context:
     def synchronize(self):
         self.check(self.lib.aggmg_synchronize(self.handle))
 
+    def set_option(self, option, value):
+        """context options of the C ABI (aggmg_set_option), e.g. _lib.OPT_SYMMETRIC_PACKING"""
+        self.check(self.lib.aggmg_set_option(self.handle, int(option), int(value)))
+
     def set_stream(self, hip_stream):
         """Launch on a caller-provided hipStream_t (integer / pointer), e.g.
         torch.cuda.current_stream().cuda_stream; 0 / None is the device's default stream."""
@@ -600,10 +604,16 @@ class MeshHierarchy:
 
     def set_restriction(self, mode):
         """_lib.RESTRICT_EXPLICIT (default: the reference's arithmetic for L'(rhs - A u)) or
-        _lib.RESTRICT_PRECONDITIONED (cheaper, only for cond(A) eps << 1) -- C ABI
-        aggmg_hier_set_restriction, see include/aggmg_hip.h"""
+        _lib.RESTRICT_PRECONDITIONED (cheaper; UnsupportedError above
+        _lib.RESTRICT_PRECONDITIONED_MAX_ELEMS fine elements, where its rounding error on the smoothest
+        mode would stall or reverse convergence) -- C ABI aggmg_hier_set_restriction, include/aggmg_hip.h"""
         c = self.ctx
         c.check(c.lib.aggmg_hier_set_restriction(c.handle, self.handle, int(mode)))
+
+    def get_restriction(self):
+        v = ctypes.c_int(0)
+        self.ctx.check(self.ctx.lib.aggmg_hier_get_restriction(self.ctx.handle, self.handle, ctypes.byref(v)))
+        return v.value
 
     def coarse_buffers(self):
         """-> (rhs_ptr, sol_ptr, n): device buffers of the coarsest level"""

@@ -72,6 +72,16 @@ extern "C" int aggmg_reset_stream(aggmg_ctx* ctx) {
   return AGGMG_OK;
 }
 
+extern "C" int aggmg_set_option(aggmg_ctx* ctx, int option, int value) {
+  if (!ctx) return AGGMG_ERR_ARGUMENT;
+  switch (option) {
+    case AGGMG_OPT_SYMMETRIC_PACKING:
+      ctx->sym_packing = value != 0;
+      return AGGMG_OK;
+  }
+  return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_set_option: unknown option");
+}
+
 extern "C" int aggmg_synchronize(aggmg_ctx* ctx) {
   if (!ctx) return AGGMG_ERR_ARGUMENT;
   HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -424,7 +434,7 @@ static int build_btd(aggmg_ctx* ctx, aggmg_smoother* sm, const std::vector<doubl
     // symmetric to round-off?  (B_e^{-1} symmetric, and Sub_e[:, c] == Sup_{e-1}[r, :] with c == r)
     // then the kernels read the packed upper triangle and rebuild pcol from the neighbour's q row
     const bool grp = (m == 2 || m == 4 || m == 8);
-    if (grp && c_sub == r_sup && !std::getenv("AGGMG_NO_SYM")) {
+    if (grp && c_sub == r_sup && ctx->sym_packing) {
       std::atomic<int> asym{0};
       const double tol = 1e-13;
       parallel_for(ne, [&](int64_t eb, int64_t ee) {
@@ -477,7 +487,7 @@ static int build_btd(aggmg_ctx* ctx, aggmg_smoother* sm, const std::vector<doubl
     if (st == AGGMG_OK) st = dev_upload(ctx, Q, &b->Q);
     // symmetric to round-off (B_e^{-1} symmetric, Sub_e == Sup_{e-1}')?  then the kernels read the
     // packed inverse and the super-diagonal blocks only
-    if ((m == 2 || m == 4) && !std::getenv("AGGMG_NO_SYM")) {
+    if ((m == 2 || m == 4) && ctx->sym_packing) {
       std::atomic<int> asym{0};
       const double tol = 1e-13;
       parallel_for(ne, [&](int64_t eb, int64_t ee) {
@@ -2086,7 +2096,26 @@ extern "C" int aggmg_hier_set_restriction(aggmg_ctx* ctx, aggmg_hier* h, int mod
   if (!ctx) return AGGMG_ERR_ARGUMENT;
   if (!h || (mode != AGGMG_RESTRICT_EXPLICIT && mode != AGGMG_RESTRICT_PRECONDITIONED))
     return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_hier_set_restriction: bad argument");
+  if (mode == AGGMG_RESTRICT_PRECONDITIONED) {
+    // the rounding error this form puts on the smoothest mode grows like n^2 (x0.009 per cycle at
+    // 2^20 fine elements, x0.134 at 2^22, x2.13 -- divergence -- at 2^24): refused where it would
+    // exceed ~0.05 per cycle
+    const Level& l0 = h->lv[0];
+    const int64_t ne = (l0.S && l0.S->btd) ? l0.S->btd->ne : 0;
+    if (ne > AGGMG_RESTRICT_PRECONDITIONED_MAX_ELEMS)
+      return fail(ctx, AGGMG_ERR_UNSUPPORTED,
+                  "aggmg_hier_set_restriction: AGGMG_RESTRICT_PRECONDITIONED is refused above " +
+                      std::to_string((long long)AGGMG_RESTRICT_PRECONDITIONED_MAX_ELEMS) +
+                      " fine elements (its rounding error on the smoothest mode grows like n^2 and makes the "
+                      "multigrid iteration diverge at 2^24); this hierarchy has " + std::to_string((long long)ne));
+  }
   h->restriction = mode;
+  return AGGMG_OK;
+}
+
+extern "C" int aggmg_hier_get_restriction(aggmg_ctx* ctx, const aggmg_hier* h, int* mode) {
+  if (!ctx || !h || !mode) return AGGMG_ERR_ARGUMENT;
+  *mode = h->restriction;
   return AGGMG_OK;
 }
 
@@ -2287,8 +2316,9 @@ extern "C" int aggmg_multigrid_dev(aggmg_ctx* ctx, aggmg_hier* h, const double* 
   int done = 0, checks = 0;
   *n_cycles = 0;
   *n_checks = 0;
-  if (maxiter == 0) {
-    HIPCHK(hipMemcpyAsync(x_out, x0, N * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+  if (maxiter == 0) {  // the reference returns its initial `x = zeros(length(x0))` (src/solvers.jl:119)
+    HIPCHK(hipMemsetAsync(x_out, 0, N * sizeof(double), ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
     return AGGMG_OK;
   }
   while (done < maxiter) {

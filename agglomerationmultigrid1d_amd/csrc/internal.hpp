@@ -38,6 +38,7 @@ struct aggmg_ctx {
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
   std::string err;
+  bool sym_packing = true;  // AGGMG_OPT_SYMMETRIC_PACKING
   int profiling = 0;  // 0 off, 1 every launch, 2 only the fine-level fused-down launch (dominant kernel)
   std::vector<ProfEvent> prof;
   std::vector<hipEvent_t> ev_pool;
@@ -213,18 +214,15 @@ struct aggmg_hier {
 };
 
 // The restricted residual L'(b - A u) is formed from r = b - A u evaluated with the operator's own
-// entries (the reference's arithmetic, src/solvers.jl:36) -- AGGMG_RESTRICT_EXPLICIT, the default.
-// AGGMG_RESTRICT_PRECONDITIONED takes it from the sweeps' preconditioned residual instead,
-// (L'D) w with w = g - P u- - Q u+ - u, which reads neither the diagonal blocks nor L: equal in
-// exact arithmetic, but w inherits the rounding of the stored (symmetrically packed) B^{-1}, P, Q.
-// On the smoothest mode of the model problem that error grows like n^2 and at 2^24 fine elements
-// turns the cycle from damping (x0.5, as in reference-order arithmetic) into amplifying (x2.1):
-// measured, include/aggmg_hip.h and DESIGN.md section 5.  AGGMG_RESTRICT=preconditioned sets the
-// initial mode of new hierarchies.
-inline int default_restriction() {
-  const char* e = std::getenv("AGGMG_RESTRICT");
-  return (e && std::string(e) == "preconditioned") ? AGGMG_RESTRICT_PRECONDITIONED : AGGMG_RESTRICT_EXPLICIT;
-}
+// entries (the reference's arithmetic, src/solvers.jl:36) -- AGGMG_RESTRICT_EXPLICIT, the default of
+// every new hierarchy.  AGGMG_RESTRICT_PRECONDITIONED takes it from the sweeps' preconditioned
+// residual instead, (L'D) w with w = g - P u- - Q u+ - u, which reads neither the diagonal blocks nor
+// L: equal in exact arithmetic, but w inherits the rounding of the stored block inverses.  On the
+// smoothest mode of the model problem that error grows like n^2 and at 2^24 fine elements turns the
+// cycle from damping (x0.5, as in reference-order arithmetic) into amplifying (x2.1): measured,
+// include/aggmg_hip.h and DESIGN.md section 5 -- aggmg_hier_set_restriction therefore refuses it above
+// AGGMG_RESTRICT_PRECONDITIONED_MAX_ELEMS fine elements.
+inline int default_restriction() { return AGGMG_RESTRICT_EXPLICIT; }
 
 // ---------------------------------------------------------------------------------------------
 // host-side parallel loop for the O(n) set-up passes (block extraction / inversion, format

@@ -152,11 +152,11 @@ __global__ __launch_bounds__(kThreads) void block_apply_kernel(const double* __r
     y[id[i]] = acc;
 }
 
-// out = (u ? u : 0) + alpha * (y / (cnt ? cnt : 1))
-static __global__ __launch_bounds__(kThreads) void axpy_scaled_kernel(int64_t n, const double* __restrict__ u,
-                                                               const double* __restrict__ y,
-                                                               const double* __restrict__ cnt,
-                                                               double alpha, double* __restrict__ out) {
+// out = (u ? u : 0) + alpha * (y / (cnt ? cnt : 1)); out may alias u (block smoothers update in place)
+static __global__ __launch_bounds__(kThreads) void axpy_scaled_kernel(int64_t n, const double* u,
+                                                                      const double* __restrict__ y,
+                                                                      const double* __restrict__ cnt,
+                                                                      double alpha, double* out) {
   const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
   if (i >= n) return;
   double v = y[i];

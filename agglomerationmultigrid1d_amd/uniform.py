@@ -200,7 +200,7 @@ class UniformDgAggHierarchy:
         self._build_fine()
         self.levels = [dict(m=p + 1, ne=self.n, G=(self.Gl, self.Gd), D=(self.Dd, self.Du), C=self.Cd,
                             M=self.M, A=self._stiffness_blocks(self.Gl, self.Gd, self.Dd, self.Du,
-                                                               self.Cd, self.M))]
+                                                               self.Cd, self.M, self.Minv))]
         self.transfers = []     # Lb[k]: (ne_f, m_f, m_c) rows of L per fine element, rho
         self._build_agglomerated()
         self._rhs_full = self._rhs_padded()
@@ -265,6 +265,8 @@ class UniformDgAggHierarchy:
             Gd[-1, nR, nR] += -1.0
         self.Gd, self.Gl, self.Dd, self.Du, self.Cd = Gd, Gl, Dd, Du, Cd
         self.M = self.J[:, None, None] * ref.mass[None, :, :]
+        # mass blocks are J_e * M_ref (src/dg_mesh.jl:69-79): their inverses cost one small inversion
+        self.Minv = (1.0 / self.J)[:, None, None] * np.linalg.inv(ref.mass)[None, :, :]
 
     def rhs(self):
         """b = f - D*(M\\r) with (f, r) = dg_flux_rhs (src/dg_mesh.jl:342-457;
@@ -293,16 +295,34 @@ class UniformDgAggHierarchy:
                 r[-1, nR] += rv
             else:
                 f[-1, nR] += rv
-        y = np.linalg.solve(self.M, r[:, :, None])[:, :, 0]
+        y = np.matmul(self.Minv, r[:, :, None])[:, :, 0]
         Dy = np.einsum('kij,kj->ki', self.Dd, y) + np.einsum('kij,kj->ki', self.Du, _shift_up(y))
         return (f - Dy).reshape(-1)
 
     @staticmethod
-    def _stiffness_blocks(Gl, Gd, Dd, Du, Cd, M):
+    def _bsolve(M, X):
+        """batched M[k] \\ X[k] for small blocks: by division (1 x 1) or the adjugate (2 x 2), LAPACK
+        beyond that (equal to the reference's per-block LU solve up to round-off)"""
+        m = M.shape[-1]
+        if m == 1:
+            return X / M
+        if m == 2:
+            det = M[:, 0, 0] * M[:, 1, 1] - M[:, 0, 1] * M[:, 1, 0]
+            out = np.empty(np.broadcast_shapes(M.shape[:1] + X.shape[1:], X.shape))
+            out[:, 0] = (M[:, 1, 1, None] * X[:, 0] - M[:, 0, 1, None] * X[:, 1]) / det[:, None]
+            out[:, 1] = (M[:, 0, 0, None] * X[:, 1] - M[:, 1, 0, None] * X[:, 0]) / det[:, None]
+            return out
+        return np.linalg.solve(M, X)
+
+    @classmethod
+    def _stiffness_blocks(cls, Gl, Gd, Dd, Du, Cd, M, Minv=None):
         """Blocks of A = C - D*(M \\ G) for block-lower-bidiagonal G (Gl, Gd), block-upper-
-        bidiagonal D (Dd, Du), block-diagonal C and M.  -> (sub, diag, sup)"""
-        XGd = np.linalg.solve(M, Gd)
-        XGl = np.linalg.solve(M, Gl)
+        bidiagonal D (Dd, Du), block-diagonal C and M.  -> (sub, diag, sup).  Minv: explicit block
+        inverses when they are cheap to come by (the nodal DG mass blocks are J_e * M_ref)."""
+        if Minv is not None:
+            XGd, XGl = np.matmul(Minv, Gd), np.matmul(Minv, Gl)
+        else:
+            XGd, XGl = cls._bsolve(M, Gd), cls._bsolve(M, Gl)
         diag = Cd - (Dd @ XGd + Du @ _shift_up(XGl))
         sub = -(Dd @ XGl)
         sup = -(Du @ _shift_up(XGd))
@@ -357,7 +377,7 @@ class UniformDgAggHierarchy:
                 for k in range(bpf):
                     for l in range(len(gw)):
                         N += (Jf[:, k] * gw[l])[:, None, None] * fphi[:, k, l, :, None] * cphi[:, k, l, None, :]
-                Lb = np.linalg.solve(prev['M'], N)
+                Lb = self._bsolve(prev['M'], N)
             self.transfers.append(dict(Lb=Lb, rho=rho, mc=mc))
             # Galerkin products on the block-bidiagonal G, D and block-diagonal C
             Gl, Gd = prev['G']
@@ -472,12 +492,13 @@ class UniformCgDgHierarchy:
     """CgMesh(p) for p in `ps` (p-coarsening by nodal injection, Galerkin operators, point-Jacobi)
     followed by one re-discretised DgMesh(p=0) level reached through the lumped-mass L2 transfer
     (interpFlag = 1), as MeshHierarchy(mMeshes, mesh, bdConds, A; nCG, nDG=1, CDir) builds it
-    (src/mesh_heirarchy.jl:30-73).  O(n) / vectorised:
+    (src/mesh_heirarchy.jl:30-73).  O(n): every matrix is written straight into its CSC arrays from
+    per-element blocks, no sparse products and no COO sort --
 
-        cg_stiffness_and_rhs      src/cg_mesh.jl:125-185
-        cg_cg_interpolation       src/interpolation.jl:5-55
+        cg_stiffness_and_rhs       src/cg_mesh.jl:125-185      -> element matrices K_e, rhs
+        cg_cg_interpolation        src/interpolation.jl:5-55   -> L (same for every element but the last)
+        L'*A*L                     src/mesh_heirarchy.jl:57    -> K_e^c = L_e' K_e L_e element by element
         dg_cg_interpolation(...,1) src/interpolation.jl:145-220
-        L'*A*L                    src/mesh_heirarchy.jl:57
 
     CG numbering: vertices 1..n+1, then the p-1 interior nodes of every element in element order
     (src/cg_mesh.jl:37-45,59-65); node indices here are 0-based."""
@@ -495,19 +516,18 @@ class UniformCgDgHierarchy:
         self.J = self.h / 2.0
         self.refs = [RefElement(p) for p in self.ps]
         self.A, self.L = [], []
-        A0, self.b = self._cg_stiffness_and_rhs(self.ps[0], self.refs[0])
-        self.A.append(A0)
+        Ke, extra, dirv, self.b = self._cg_element_matrices_and_rhs(self.ps[0], self.refs[0])
+        self.A.append(self._assemble(self.ps[0], Ke, extra, dirv))
         for k in range(1, len(self.ps)):
-            L = self._cg_cg(self.ps[k], self.ps[k - 1], self.refs[k], self.refs[k - 1])
-            self.L.append(L)
-            self.A.append((L.T @ self.A[-1] @ L).tocsc())
+            lowVal = self._low_val(self.refs[k], self.refs[k - 1])
+            self.L.append(self._cg_cg(self.ps[k], self.ps[k - 1], lowVal))
+            Ke, extra = self._galerkin(Ke, extra, lowVal)
+            self.A.append(self._assemble(self.ps[k], Ke, extra, None))
         # DG p = 0 level: re-discretised operator, lumped-mass transfer from the last CG level
         dg0 = UniformDgAggHierarchy(n, p=0, pAgg=0, ratios=(), CDir=self.CDir, xin=xin, xout=xout, bc=self.bc,
                                     func=func)
         self.L.append(self._dg0_cg(self.ps[-1], self.refs[-1]))
         self.A.append(dg0.stiffness_csc(0))
-        for M in self.A + self.L:
-            M.sort_indices()
 
     def nodes(self, p):
         """(n, p+1) 0-based node numbers per element in local order [left, right, interior...]"""
@@ -518,6 +538,11 @@ class UniformCgDgHierarchy:
         for j in range(p - 1):
             out[:, 2 + j] = (n + 1) + k * (p - 1) + j
         return out
+
+    def element_nodes(self, k):
+        """mElements[e].mNodesInd of CG level k as the (p+1) x n matrix (1-based) that
+        cg_smoother(cgMesh, A, ...) has at hand -- the hint of aggmg_jacobi_setup_elements"""
+        return np.ascontiguousarray(self.nodes(self.ps[k]).T) + 1
 
     def num_nodes(self, p):
         return self.n * p + 1
@@ -530,66 +555,208 @@ class UniformCgDgHierarchy:
             d.append((self.n, self.bc[1][1]))
         return d
 
-    def _cg_stiffness_and_rhs(self, p, ref):
+    def _cg_element_matrices_and_rhs(self, p, ref):
+        """-> K_e (n, p+1, p+1) with the Dirichlet rows / columns zeroed, the identity entries of the
+        Dirichlet vertices as a vertex vector, the Dirichlet vertex mask and the right-hand side"""
         n = self.n
-        nd = self.nodes(p)
         N = self.num_nodes(p)
         m = p + 1
-        K = np.zeros((n, m, m))
-        invJ = 1.0 / self.J
-        for l in range(len(ref.gw)):          # temp[i,j] += (1/J) * w_l * dphi_i * dphi_j, in loop order
-            K += ((invJ * ref.gw[l])[:, None] * ref.dphi[l][None, :])[:, :, None] * ref.dphi[l][None, None, :]
+        # temp[i,j] += (1/J) * w_l * dphi_i * dphi_j (src/cg_mesh.jl:140-150): the l-sum is formed once on
+        # the reference element and scaled per element (equal to the loop order up to round-off)
+        Kref = np.zeros((m, m))
+        for l in range(len(ref.gw)):
+            Kref += (ref.gw[l] * ref.dphi[l])[:, None] * ref.dphi[l][None, :]
+        K = (1.0 / self.J)[:, None, None] * Kref[None, :, :]
         xq = self.xc[:, None] + self.h[:, None] / 2.0 * ref.gq[None, :]
         fq = self.func(xq)
         fe = np.zeros((n, m))
         for l in range(len(ref.gw)):
             fe += (self.J[:, None] * ref.gw[l]) * ref.phi[l][None, :] * fq[:, l][:, None]
         f = np.zeros(N)
-        np.add.at(f, nd.reshape(-1), fe.reshape(-1))
+        f[1:n + 1] += fe[:, 1]          # element v-1 reaches vertex v before element v does
+        f[0:n] += fe[:, 0]
+        if p > 1:
+            f[n + 1:] = fe[:, 2:].reshape(-1)
         (lk, lv), (rk, rv) = self.bc
         if lk == 'neu':
             f[0] += -lv
         if rk == 'neu':
             f[n] += rv
-        rows = np.repeat(nd, m, axis=1).reshape(-1)           # nd[k,i] for (i,j)
-        cols = np.tile(nd, (1, m)).reshape(-1)                # nd[k,j]
-        vals = K.reshape(-1)
+        extra = np.zeros(n + 1)
+        dirv = np.zeros(n + 1, dtype=bool)
         dirs = self._dir_nodes()
-        if dirs:
-            # f += -A[:, dir] * dirVals on the unconstrained matrix, then the strong rows / columns
-            for node, val in dirs:
-                sel = cols == node
-                np.add.at(f, rows[sel], -vals[sel] * val)
-            for node, val in dirs:
-                f[node] = val
-            dn = np.array([d[0] for d in dirs])
-            keep = ~(np.isin(rows, dn) | np.isin(cols, dn))
-            rows = np.concatenate([rows[keep], dn])
-            cols = np.concatenate([cols[keep], dn])
-            vals = np.concatenate([vals[keep], np.ones(len(dn))])
-        A = sp.coo_matrix((vals, (rows, cols)), shape=(N, N)).tocsc()
-        A.sum_duplicates()
-        return A, f
+        nd = self.nodes(p)
+        for node, val in dirs:                 # f += -A[:, dir] * dirVals on the unconstrained matrix
+            for e, loc in ((node - 1, 1), (node, 0)):
+                if 0 <= e < n:
+                    f[nd[e]] += -K[e][:, loc] * val
+        for node, val in dirs:
+            f[node] = val
+            extra[node] = 1.0
+            dirv[node] = True
+            for e, loc in ((node - 1, 1), (node, 0)):
+                if 0 <= e < n:
+                    K[e][loc, :] = 0.0
+                    K[e][:, loc] = 0.0
+        return K, extra, dirv, f
 
-    def _cg_cg(self, p_lo, p_hi, ref_lo, ref_hi):
-        """prolongation CG(p_lo) -> CG(p_hi): interior fine nodes x all coarse nodes of the element,
-        plus the vertex identity pairs (the last element to touch a vertex writes its value)."""
-        lowVal = np.array([[np.dot(ref_lo.coeff[:, j], legendre_vandermonde(ref_hi.nodes, p_lo)[i])
-                            for j in range(p_lo + 1)] for i in range(p_hi + 1)])
+    def _low_val(self, ref_lo, ref_hi):
+        """coarse nodal basis at the fine nodes: lowVal[i, j] (src/interpolation.jl:10)"""
+        V = legendre_vandermonde(ref_hi.nodes, ref_lo.p)
+        return np.array([[np.dot(ref_lo.coeff[:, j], V[i]) for j in range(ref_lo.p + 1)]
+                         for i in range(ref_hi.p + 1)])
+
+    def _vertex_l(self, lowVal):
+        """value of L at (fine vertex v, coarse vertex v): the last element to touch a vertex writes it
+        (src/interpolation.jl:47-52): local node 1 of the last element for vertex n, local node 0 otherwise"""
+        vv = np.full(self.n + 1, lowVal[0, 0])
+        vv[self.n] = lowVal[1, 1]
+        return vv
+
+    def _galerkin(self, Ke, extra, lowVal):
+        """element matrices of L'*A*L: K_e^c = L_e' K_e L_e with L_e = rows of L at the element's
+        fine nodes (vertex rows carry the vertex entry of L, interior rows the coarse basis values)"""
         n = self.n
-        hi, lo = self.nodes(p_hi), self.nodes(p_lo)
-        rows, cols, vals = [], [], []
-        if p_hi >= 2:
-            r = np.repeat(hi[:, 2:], p_lo + 1, axis=1).reshape(-1)
-            c = np.tile(lo, (1, p_hi - 1)).reshape(-1)
-            v = np.tile(lowVal[2:, :].reshape(-1), n)
-            rows.append(r), cols.append(c), vals.append(v)
-        vtx = np.arange(n + 1, dtype=np.int64)
-        vv = np.full(n + 1, lowVal[0, 0])
-        vv[n] = lowVal[1, 1]
-        rows.append(vtx), cols.append(vtx), vals.append(vv)
-        L = sp.coo_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))),
-                          shape=(self.num_nodes(p_hi), self.num_nodes(p_lo))).tocsc()
+        vv = self._vertex_l(lowVal)
+        Le = np.broadcast_to(lowVal, (n,) + lowVal.shape).copy()
+        Le[:, 0, :] = 0.0
+        Le[:, 1, :] = 0.0
+        Le[:, 0, 0] = vv[:-1]
+        Le[:, 1, 1] = vv[1:]
+        Kc = np.matmul(Le.transpose(0, 2, 1), np.matmul(Ke, Le))
+        return Kc, vv * (extra * vv)
+
+    @staticmethod
+    def _pack_columns(rows, vals, keep_rows):
+        """CSC pieces of a strip array (ncols, W): column c stores rows[c, :] / vals[c, :], except the
+        columns listed in keep_rows = {c: bool mask of length W}.  Runs of regular columns are taken
+        with one reshape each, so no boolean pass over the whole strip is needed.
+        -> (counts per column, list of row pieces, list of value pieces)"""
+        nc, W = rows.shape
+        counts = np.full(nc, W, dtype=np.int64)
+        rparts, vparts = [], []
+        a = 0
+        for c in sorted(keep_rows):
+            if c > a:
+                rparts.append(rows[a:c].reshape(-1)), vparts.append(vals[a:c].reshape(-1))
+            k = keep_rows[c]
+            rparts.append(rows[c][k]), vparts.append(vals[c][k])
+            counts[c] = int(k.sum())
+            a = c + 1
+        if a < nc:
+            rparts.append(rows[a:].reshape(-1)), vparts.append(vals[a:].reshape(-1))
+        return counts, rparts, vparts
+
+    def _assemble(self, p, Ke, extra, dirv):
+        """CSC of sum_e P_e' K_e P_e + diag(extra) in the vertices-first numbering.  dirv (fine level):
+        Dirichlet vertices whose rows / columns are removed from the pattern, as the reference's
+        sparse setindex! does (src/cg_mesh.jl:177-182); Galerkin levels keep every entry."""
+        n = self.n
+        q = p - 1
+        N = self.num_nodes(p)
+        v = np.arange(n + 1, dtype=np.int64)
+        W = 3 + 2 * q
+        dirs = [] if dirv is None else [int(d) for d in np.flatnonzero(dirv)]
+        # ---- vertex columns: rows v-1, v, v+1, interior of element v-1, interior of element v ----
+        rows = np.empty((n + 1, W), dtype=np.int64)
+        vals = np.zeros((n + 1, W))
+        rows[:, 0], rows[:, 1], rows[:, 2] = v - 1, v, v + 1
+        vals[1:, 0] = Ke[:, 0, 1]
+        vals[1:, 1] = Ke[:, 1, 1]
+        vals[:-1, 1] += Ke[:, 0, 0]
+        vals[:, 1] += extra
+        vals[:-1, 2] = Ke[:, 1, 0]
+        if q:
+            jj = np.arange(q, dtype=np.int64)
+            rows[:, 3:3 + q] = (n + 1) + (v[:, None] - 1) * q + jj[None, :]
+            rows[:, 3 + q:] = (n + 1) + v[:, None] * q + jj[None, :]
+            vals[1:, 3:3 + q] = Ke[:, 2:, 1]
+            vals[:-1, 3 + q:] = Ke[:, 2:, 0]
+        irregular = {}
+
+        def vmask(c):
+            if c not in irregular:
+                k = np.ones(W, dtype=bool)
+                if c == 0:
+                    k[0] = False
+                    k[3:3 + q] = False
+                if c == n:
+                    k[2] = False
+                    k[3 + q:] = False
+                irregular[c] = k
+            return irregular[c]
+
+        vmask(0), vmask(n)
+        for d in dirs:
+            k = vmask(d)
+            k[:] = False
+            k[1] = True                                   # the identity entry
+            if d + 1 <= n:
+                vmask(d + 1)[0] = False                   # row v-1 is a Dirichlet row
+            if d - 1 >= 0:
+                vmask(d - 1)[2] = False
+        counts, rparts, vparts = self._pack_columns(rows, vals, irregular)
+        counts = [counts]
+        # ---- interior columns (e, j): rows v_e, v_e+1, interior of element e ----
+        if q:
+            e = np.arange(n, dtype=np.int64)
+            irows = np.empty((n, q, p + 1), dtype=np.int64)
+            irows[:, :, 0] = e[:, None]
+            irows[:, :, 1] = e[:, None] + 1
+            irows[:, :, 2:] = (n + 1) + e[:, None, None] * q + np.arange(q, dtype=np.int64)[None, None, :]
+            ivals = np.ascontiguousarray(Ke[:, :, 2:].transpose(0, 2, 1))
+            irr = {}
+            for d in dirs:
+                for el, loc in ((d - 1, 1), (d, 0)):       # elements touching the Dirichlet vertex
+                    if 0 <= el < n:
+                        for j in range(q):
+                            k = irr.setdefault(el * q + j, np.ones(p + 1, dtype=bool))
+                            k[loc] = False
+            c2, r2, v2 = self._pack_columns(irows.reshape(n * q, p + 1), ivals.reshape(n * q, p + 1), irr)
+            counts.append(c2)
+            rparts += r2
+            vparts += v2
+        colptr = np.zeros(N + 1, dtype=np.int64)
+        np.cumsum(np.concatenate(counts), out=colptr[1:])
+        A = sp.csc_matrix((np.concatenate(vparts), np.concatenate(rparts), colptr), shape=(N, N))
+        A.has_sorted_indices = True
+        return A
+
+    def _cg_cg(self, p_lo, p_hi, lowVal):
+        """prolongation CG(p_lo) -> CG(p_hi): interior fine nodes x all coarse nodes of the element,
+        plus the vertex identity pairs"""
+        n = self.n
+        qf, qc = p_hi - 1, p_lo - 1
+        Nf, Nc = self.num_nodes(p_hi), self.num_nodes(p_lo)
+        v = np.arange(n + 1, dtype=np.int64)
+        jf = np.arange(qf, dtype=np.int64)
+        # coarse vertex column v: fine vertex v, fine interior of element v-1 (its local node 1), of element v (node 0)
+        W = 1 + 2 * qf
+        rows = np.empty((n + 1, W), dtype=np.int64)
+        vals = np.empty((n + 1, W))
+        rows[:, 0] = v
+        vals[:, 0] = self._vertex_l(lowVal)
+        rows[:, 1:1 + qf] = (n + 1) + (v[:, None] - 1) * qf + jf[None, :]
+        rows[:, 1 + qf:] = (n + 1) + v[:, None] * qf + jf[None, :]
+        vals[:, 1:1 + qf] = lowVal[2:, 1][None, :]
+        vals[:, 1 + qf:] = lowVal[2:, 0][None, :]
+        k0, kn = np.ones(W, dtype=bool), np.ones(W, dtype=bool)
+        k0[1:1 + qf] = False
+        kn[1 + qf:] = False
+        if n == 0:
+            raise ValueError("need at least one element")
+        counts, rparts, vparts = self._pack_columns(rows, vals, {0: k0, n: kn})
+        counts = [counts]
+        if qc:   # coarse interior column (e, j): fine interior of element e
+            e = np.arange(n, dtype=np.int64)
+            irows = np.broadcast_to(((n + 1) + e[:, None, None] * qf + jf[None, None, :]), (n, qc, qf))
+            ivals = np.broadcast_to(lowVal[2:, 2:].T[None, :, :], (n, qc, qf))
+            counts.append(np.full(n * qc, qf, dtype=np.int64))
+            rparts.append(irows.reshape(-1)), vparts.append(ivals.reshape(-1))
+        colptr = np.zeros(Nc + 1, dtype=np.int64)
+        np.cumsum(np.concatenate(counts), out=colptr[1:])
+        L = sp.csc_matrix((np.concatenate(vparts), np.concatenate(rparts), colptr), shape=(Nf, Nc))
+        L.has_sorted_indices = True
         return L
 
     def _dg0_cg(self, p_hi, ref_hi):
@@ -597,24 +764,40 @@ class UniformCgDgHierarchy:
         n = self.n
         nd = self.nodes(p_hi)
         m = p_hi + 1
+        q = p_hi - 1
         gq, gw = gauss_quad(0 + p_hi)
         hiV = np.array([[np.dot(ref_hi.coeff[:, i], legendre_vandermonde(gq, p_hi)[l]) for i in range(m)]
                         for l in range(len(gq))])
         T = np.zeros((n, m))
         for l in range(len(gq)):               # temp[i,0] += J * w_l * hiV[l,i] * 1.0
             T += (self.J[:, None] * gw[l]) * hiV[l][None, :] * 1.0
-        rows = nd.reshape(-1)
-        cols = np.repeat(np.arange(n, dtype=np.int64), m)
-        Nm = sp.coo_matrix((T.reshape(-1), (rows, cols)), shape=(self.num_nodes(p_hi), n)).tocsc()
-        # lumped mass: row sums of the CG mass matrix (ascending column order within the row)
+        # lumped mass: row sums of the assembled CG mass matrix in ascending column order; the matrix
+        # is symmetric, so the sums run down the columns of its vertices-first strips
         Me = self.J[:, None, None] * ref_hi.mass[None, :, :]
-        Mr = np.repeat(nd, m, axis=1).reshape(-1)
-        Mc = np.tile(nd, (1, m)).reshape(-1)
-        Mm = sp.coo_matrix((Me.reshape(-1), (Mr, Mc)), shape=(self.num_nodes(p_hi),) * 2).tocsr()
-        Mm.sum_duplicates()
-        Mm.sort_indices()
-        lumped = np.add.reduceat(Mm.data, Mm.indptr[:-1])
-        Nm.data = Nm.data / lumped[Nm.indices]
+        lumped = np.zeros(self.num_nodes(p_hi))
+        sv = np.zeros((n + 1, 3 + 2 * q))
+        sv[1:, 0] = Me[:, 0, 1]
+        sv[1:, 1] = Me[:, 1, 1]
+        sv[:-1, 1] += Me[:, 0, 0]
+        sv[:-1, 2] = Me[:, 1, 0]
+        if q:
+            sv[1:, 3:3 + q] = Me[:, 2:, 1]
+            sv[:-1, 3 + q:] = Me[:, 2:, 0]
+        acc = np.zeros(n + 1)
+        for c in range(sv.shape[1]):
+            acc += sv[:, c]
+        lumped[:n + 1] = acc
+        if q:
+            si = Me[:, :, 2:].transpose(0, 2, 1)           # (n, q, m): column (e, j), rows v_e, v_e+1, interior
+            acc = np.zeros((n, q))
+            for c in range(m):
+                acc += si[:, :, c]
+            lumped[n + 1:] = acc.reshape(-1)
+        # column e of N: rows v_e, v_e+1, interior of element e (ascending)
+        vals = T / lumped[nd]
+        colptr = np.arange(n + 1, dtype=np.int64) * m
+        Nm = sp.csc_matrix((vals.reshape(-1), nd.reshape(-1), colptr), shape=(self.num_nodes(p_hi), n))
+        Nm.has_sorted_indices = True
         return Nm
 
     @property
@@ -638,11 +821,13 @@ class UniformCgDgHierarchy:
         return out
 
 
-def build_device_cg_hierarchy(U, ctx=None, keep_host=False):
+def build_device_cg_hierarchy(U, ctx=None, keep_host=False, chain=True):
     """UniformCgDgHierarchy -> product MeshHierarchy (CG levels :jac, src/mesh_heirarchy.jl:51,58)"""
     from . import _lib
     from .api import DeviceOperator, JacobiSmoother, MeshHierarchy
     ops = [DeviceOperator(A, _lib.OP_STIFFNESS, ctx) for A in U.A]
-    sms = [JacobiSmoother(ops[k], ctx) for k in range(U.nlevels - 1)]
+    # cg_smoother(cgMesh, A, :jac) with the mesh's element node lists (chain form, fused kernel);
+    # chain=False is the operators-only route through the generic CSR kernels
+    sms = [JacobiSmoother(ops[k], ctx, U.element_nodes(k) if chain else None) for k in range(U.nlevels - 1)]
     Ls = [DeviceOperator(L, _lib.OP_TRANSFER, ctx) for L in U.L]
     return MeshHierarchy(None, ops, sms, Ls, ctx=ctx, keep_host=keep_host)

@@ -9,25 +9,31 @@ BASELINE.json config-3/4 hierarchy: DG p=3 fine level (2^E elements) -> AggDG pA
 AggDG (2:1) -> AggDG (2:1), all operators and vectors resident in HBM before the timed region.
 Default E = 24: the size BASELINE.json's north_star / BASELINE.md section 2 quote the 1-vs-8-GPU
 target on ("2^24-element p=3 DG hierarchy"), so that `--gpus 1,2,4,8` is one strong-scaling
-series; at N = 1 the same line also carries the literal config-3 size (2^22) as `config3_2p22`.
-For N > 1 the hierarchy is partitioned by contiguous element range (config 4).  Rank 0 prints
-ONE JSON line.
+series; at N = 1 the same line also carries the literal config-3 size (2^22) as `config3_2p22` and
+BASELINE config 5's realisable shape (CG p=4 -> 2 -> 1 -> DG p=0) at its stated size,
+2^24 elements, as `config5_2p24_1gpu`.  For N > 1 the hierarchy is partitioned by contiguous element
+range (config 4).  Rank 0 prints ONE JSON line.
 
 metric  fine-level DoF-updates/s per V-cycle = N_fine * (nPre + nPost) / t_vcycle, the whole
-        cycle timed (the coarsest direct solve included; its share is reported beside it).
-roofline  dominant kernel = the fused fine-level launch; achieved = algorithmic bytes per launch
-        (SURVEY.md 8d byte model, from actual nnz) / its mean HIP-event duration measured inside
-        the timed region on the launch stream.
-extra fields  preconditioned_residual_restriction (the cheaper restriction form, for comparison only:
-        it is not the default because it diverges as an iteration at 2^24),
-        outer_solvers_to_1e-8 (device-resident multigrid loop and ldiv!-preconditioned CG),
-        vcycles_loop (cycles fused across the fine level), config3_2p22, config5_shape_1gpu.
-cpu_baseline  the plain-C single-thread restatement (oracle/aggmg_oracle_c.c, kind "port") on a
-        bounded sample of the same workload, host cores of this box, rank 0, N = 1 only.
+        cycle timed (the coarsest direct solve included; its share is reported beside it).  `value`
+        comes from the K-step bracket the driver contract prescribes; `median_ms_per_step` (K more
+        steps, each timed on its own) rides along.
+roofline  dominant kernel = the fused fine-level descent launch.  achieved / frac follow SURVEY.md
+        8(d): ALGORITHMIC bytes per launch (CSR int32 + fp64 byte model, every sweep re-reading the
+        operator, from the actual nnz) / its mean HIP-event duration measured inside the timed region
+        on the launch stream -- `frac_basis` says so: the fused kernel reads the operator once per
+        launch for 3 sweeps + residual + restriction, so this figure exceeds 1.  `traffic` = PMC bytes
+        per launch of exactly this launch role (profiles/traffic.json, written by
+        tools/summarize_profiles.py from a profile that runs only default-mode cycles);
+        physical_frac = traffic / duration / 8 TB/s is the fraction of the HBM roofline actually used.
+cpu_baseline  the plain-C restatement (oracle/aggmg_oracle_c.c, kind "port") on the config-3 hierarchy at
+        its literal size (2^22 fine elements): 1 thread, and the OpenMP variant on all host cores of
+        this box (count stated), rank 0, N = 1 only.
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -48,69 +54,97 @@ def parse():
     ap.add_argument("--also-log2-elems", type=int, default=22,
                     help="N = 1 only: second, untimed-region run at this size (config 3 literal: 22); 0 = off")
     ap.add_argument("--p", type=int, default=3)
-    ap.add_argument("--cpu-log2-elems", type=int, default=20, help="size of the CPU-baseline sample")
+    ap.add_argument("--cpu-log2-elems", type=int, default=22, help="size of the CPU-baseline run (config 3 literal: 22)")
     ap.add_argument("--cpu-cycles", type=int, default=4)
-    ap.add_argument("--cg-log2-elems", type=int, default=20,
-                    help="N = 1 only: extra V-cycle on the CG p=4,2,1 -> DG p=0 hierarchy (config 5 shape) at 2^E "
-                         "elements, generic CSR kernels; 0 = off")
+    ap.add_argument("--cg-log2-elems", type=int, default=24,
+                    help="N = 1 only: V-cycle on the CG p=4,2,1 -> DG p=0 hierarchy (config 5 shape) at 2^E elements; 0 = off")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-smoother-bench", action="store_true")
     return ap.parse_args()
 
 
 def cpu_baseline(args, nPre, nPost, alpha):
-    """Plain-C port of the reference algorithm, 1 thread, on a 2^cpu_log2_elems-element instance
-    of the same hierarchy (same p, ratios, BCs).  Checker code: only timed, never shipped."""
+    """Plain-C port of the reference algorithm on the config-3 hierarchy at 2^cpu_log2_elems fine elements
+    (same p, ratios, BCs): 1 thread in the reference's operation order, and the OpenMP row-gather variant
+    on every host core.  Checker code: only timed, never shipped."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ctypes
+
     import c_oracle
     from agglomerationmultigrid1d_amd.uniform import UniformDgAggHierarchy
     n = 2 ** args.cpu_log2_elems
     U = UniformDgAggHierarchy(n, p=args.p, pAgg=1, ratios=(4, 2, 2))
-    C = c_oracle.COracleHierarchy([U.stiffness_csc(k) for k in range(U.nlevels)],
-                                  [U.interpolation_csc(k) for k in range(U.nlevels - 1)],
-                                  [U.levels[k]['m'] for k in range(U.nlevels - 1)])
+    As = [U.stiffness_csc(k) for k in range(U.nlevels)]
+    Ls = [U.interpolation_csc(k) for k in range(U.nlevels - 1)]
+    C = c_oracle.COracleHierarchy(As, Ls, [U.levels[k]['m'] for k in range(U.nlevels - 1)])
     b = U.rhs()
-    x = np.zeros(len(b))
-    tot = coarse = 0.0
+    N = len(b)
+    x = np.zeros(N)
+    ts, coarse = [], 0.0
     for _ in range(args.cpu_cycles):
         x, dt, cs = C.vcycle(x, b, nPre, nPost, alpha)
-        tot += dt
+        ts.append(dt)
         coarse += cs
-    N = len(b)
-    # same cycle, OpenMP row-gather variant on the cores this box gives one GPU job
-    import ctypes
-    nthreads = min(16, os.cpu_count() or 1)
+    ncores = os.cpu_count() or 1
     try:
         omp = ctypes.CDLL("libgomp.so.1")
-        omp.omp_set_num_threads(nthreads)
-        C.enable_omp([U.stiffness_csc(k) for k in range(U.nlevels)], [U.interpolation_csc(k) for k in range(U.nlevels - 1)])
-        xo = np.zeros(N)
-        xo, _, _ = C.vcycle_omp(xo, b, nPre, nPost, alpha)
-        tomp = 0.0
-        for _ in range(args.cpu_cycles):
+        C.enable_omp(As, Ls)
+        # the box may grant this job fewer CPUs than the host has (a CPU quota does not show in
+        # os.cpu_count()): one cycle per candidate thread count, all host cores first, keep the fastest
+        cand = sorted({t for t in (ncores, ncores // 2, ncores // 4, ncores // 8, 32, 16, 8) if 1 <= t <= ncores}, reverse=True)
+        sweep = {}
+        for t in cand:
+            omp.omp_set_num_threads(t)
+            xo, _, _ = C.vcycle_omp(np.zeros(N), b, nPre, nPost, alpha)
             xo, dto, _ = C.vcycle_omp(xo, b, nPre, nPost, alpha)
-            tomp += dto
-        omp_line = {"value": N * (nPre + nPost) * args.cpu_cycles / tomp, "unit": "DoF-updates/s", "cores": nthreads,
-                    "kind": "port", "sample": "same sample, OpenMP row-gather variant of the C restatement"}
+            sweep[t] = dto
+            if dto > 4.0 * min(sweep.values()) and len(sweep) >= 3:
+                break
+        best = min(sweep, key=sweep.get)
+        omp.omp_set_num_threads(best)
+        xo = np.zeros(N)
+        to = []
+        for _ in range(2 * args.cpu_cycles):
+            xo, dto, _ = C.vcycle_omp(xo, b, nPre, nPost, alpha)
+            to.append(dto)
+        omp_line = {"value": N * (nPre + nPost) / statistics.median(to), "unit": "DoF-updates/s", "cores": best,
+                    "kind": "port", "ms_per_cycle": 1e3 * statistics.median(to), "host_cores": ncores,
+                    "ms_per_cycle_by_threads": {str(t): round(1e3 * v, 1) for t, v in sweep.items()},
+                    "sample": f"same hierarchy and size, OpenMP row-gather variant of the C restatement; host has {ncores} "
+                              f"cores, thread counts {sorted(sweep)} tried with one cycle each and the fastest ({best}) "
+                              f"kept (the job's CPU share can be smaller than the host), median of {len(to)} cycles"}
     except Exception as exc:  # no libgomp: the serial line stands alone
         omp_line = {"error": str(exc)}
     return {
         "openmp": omp_line,
-        "value": N * (nPre + nPost) * args.cpu_cycles / tot,
+        "value": N * (nPre + nPost) / statistics.median(ts),
         "unit": "DoF-updates/s",
         "cores": 1,
         "kind": "port",
-        "sample": f"{args.cpu_cycles} V(3,3) cycles, same hierarchy at 2^{args.cpu_log2_elems} fine elements "
-                  f"(N_fine={N}), plain-C restatement, 1 thread of {os.cpu_count()} host cores; "
-                  f"coarsest solve {1e3 * coarse / args.cpu_cycles:.1f} ms of {1e3 * tot / args.cpu_cycles:.1f} ms per cycle",
-        "ms_per_cycle": 1e3 * tot / args.cpu_cycles,
+        "sample": f"median of {args.cpu_cycles} V(3,3) cycles, config-3 hierarchy at 2^{args.cpu_log2_elems} fine elements "
+                  f"(N_fine={N}), plain-C restatement in the reference's operation order, 1 thread of {ncores} host cores "
+                  f"(the Julia reference adds ~6 heap allocations and one LAPACK call per block per sweep and "
+                  f"re-factorises the coarsest level every cycle); coarsest solve {1e3 * coarse / args.cpu_cycles:.1f} ms "
+                  f"of {1e3 * statistics.median(ts):.1f} ms per cycle",
+        "ms_per_cycle": 1e3 * statistics.median(ts),
     }
 
 
+def _time_loop(ctx, fn, reps):
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    fn(reps)
+    ctx.synchronize()
+    return time.perf_counter() - t0
+
+
 def smoother_bench(mg, ctx, args, alpha):
-    """BASELINE config 2: DG n=2^20 p=3, 100 fused block-Jacobi sweeps and 100 residuals."""
-    from agglomerationmultigrid1d_amd.uniform import UniformDgAggHierarchy
+    """BASELINE config 2: DG n=2^20 p=3, 100 fused block-Jacobi sweeps and 100 residuals; the generic
+    CSR kernels on the same matrix; the chain kernel against the generic kernels on a CG p=4 matrix."""
+    from agglomerationmultigrid1d_amd.uniform import UniformDgAggHierarchy, UniformCgDgHierarchy
     from agglomerationmultigrid1d_amd import _lib
+    from agglomerationmultigrid1d_amd.api import _ptr
+    lib = ctx.lib
     n = 2 ** 20
     U = UniformDgAggHierarchy(n, p=args.p, pAgg=1, ratios=())
     op = mg.DeviceOperator(U.stiffness_csc(0), _lib.OP_STIFFNESS, ctx)
@@ -120,97 +154,168 @@ def smoother_bench(mg, ctx, args, alpha):
     u = ctx.to_device(np.zeros(N))
     v = ctx.alloc(N)
     r = ctx.alloc(N)
-    lib = ctx.lib
-    from agglomerationmultigrid1d_amd.api import _ptr
     out = {}
     nnzA = op.nnz
     S_bytes = 12 * nnzA + 4 * (N + 1) + 8 * 4 * N + 24 * N
     R_bytes = 12 * nnzA + 4 * (N + 1) + 24 * N
+
+    def sweeps(oph, smh, per_launch, uu, vv, bb):
+        def run(reps):
+            src, dst = uu, vv
+            for _ in range(reps):
+                ctx.check(lib.aggmg_smooth_dev(ctx.handle, oph, smh, _ptr(src), _ptr(bb), alpha, per_launch, _ptr(dst)))
+                src, dst = dst, src
+        return run
+
+    def resid(oph, uu, bb, rr):
+        def run(reps):
+            for _ in range(reps):
+                ctx.check(lib.aggmg_residual_dev(ctx.handle, oph, _ptr(uu), _ptr(bb), _ptr(rr)))
+        return run
+
     for label, per_launch in (("sweeps_1_per_launch", 1), ("sweeps_4_per_launch", 4), ("sweeps_8_per_launch", 8)):
         reps = 100 // per_launch
-        for _ in range(2):
-            ctx.check(lib.aggmg_smooth_dev(ctx.handle, op.handle, S.handle, _ptr(u), _ptr(b), alpha, per_launch, _ptr(v)))
-        ctx.synchronize()
-        t0 = time.perf_counter()
-        src, dst = u, v
-        for _ in range(reps):
-            ctx.check(lib.aggmg_smooth_dev(ctx.handle, op.handle, S.handle, _ptr(src), _ptr(b), alpha, per_launch, _ptr(dst)))
-            src, dst = dst, src
-        ctx.synchronize()
-        dt = time.perf_counter() - t0
-        sweeps = reps * per_launch
-        out[label] = {"dof_updates_per_s": N * sweeps / dt, "us_per_sweep": 1e6 * dt / sweeps,
-                      "algorithmic_GBs": S_bytes * sweeps / dt / 1e9,
-                      "frac_of_8TBs": S_bytes * sweeps / dt / 1e9 / HBM_PEAK_GBS}
-    ctx.check(lib.aggmg_residual_dev(ctx.handle, op.handle, _ptr(u), _ptr(b), _ptr(r)))
-    ctx.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(100):
-        ctx.check(lib.aggmg_residual_dev(ctx.handle, op.handle, _ptr(u), _ptr(b), _ptr(r)))
-    ctx.synchronize()
-    dt = time.perf_counter() - t0
+        fn = sweeps(op.handle, S.handle, per_launch, u, v, b)
+        fn(2)
+        dt = _time_loop(ctx, fn, reps)
+        nsw = reps * per_launch
+        out[label] = {"dof_updates_per_s": N * nsw / dt, "us_per_sweep": 1e6 * dt / nsw,
+                      "algorithmic_GBs": S_bytes * nsw / dt / 1e9, "frac_of_8TBs": S_bytes * nsw / dt / 1e9 / HBM_PEAK_GBS}
+    fn = resid(op.handle, u, b, r)
+    fn(1)
+    dt = _time_loop(ctx, fn, 100)
     out["residual"] = {"us_per_residual": 1e6 * dt / 100, "algorithmic_GBs": R_bytes * 100 / dt / 1e9,
                        "frac_of_8TBs": R_bytes * 100 / dt / 1e9 / HBM_PEAK_GBS}
     out["workload"] = f"config 2: DG n=2^20 p={args.p}, block-Jacobi m={args.p + 1}, N={N}, nnz(A)={nnzA}"
-    # the generic CSR kernels (what CG levels and unstructured operators run) on the same matrix:
-    # fused point-Jacobi sweep (K2) and CSR residual, int32 indices + fp64 values actually read
+    # the generic CSR kernels (unstructured operators) on the same matrix: fused point-Jacobi sweep and CSR
+    # residual, int32 indices + fp64 values actually read
     op2 = mg.DeviceOperator(U.stiffness_csc(0), _lib.OP_STIFFNESS, ctx)
     J = mg.JacobiSmoother(op2, ctx)
     Sj_bytes = 12 * nnzA + 4 * (N + 1) + 8 * N + 24 * N
-    for _ in range(2):
-        ctx.check(lib.aggmg_smooth_dev(ctx.handle, op2.handle, J.handle, _ptr(u), _ptr(b), alpha, 1, _ptr(v)))
-    ctx.synchronize()
-    t0 = time.perf_counter()
-    src, dst = u, v
-    for _ in range(100):
-        ctx.check(lib.aggmg_smooth_dev(ctx.handle, op2.handle, J.handle, _ptr(src), _ptr(b), alpha, 1, _ptr(dst)))
-        src, dst = dst, src
-    ctx.synchronize()
-    dt = time.perf_counter() - t0
+    fn = sweeps(op2.handle, J.handle, 1, u, v, b)
+    fn(2)
+    dt = _time_loop(ctx, fn, 100)
     out["generic_csr_point_jacobi"] = {"us_per_sweep": 1e6 * dt / 100, "algorithmic_GBs": Sj_bytes * 100 / dt / 1e9,
                                        "frac_of_8TBs": Sj_bytes * 100 / dt / 1e9 / HBM_PEAK_GBS}
-    ctx.check(lib.aggmg_residual_dev(ctx.handle, op2.handle, _ptr(u), _ptr(b), _ptr(r)))
-    ctx.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(100):
-        ctx.check(lib.aggmg_residual_dev(ctx.handle, op2.handle, _ptr(u), _ptr(b), _ptr(r)))
-    ctx.synchronize()
-    dt = time.perf_counter() - t0
+    fn = resid(op2.handle, u, b, r)
+    fn(1)
+    dt = _time_loop(ctx, fn, 100)
     out["generic_csr_residual"] = {"us_per_residual": 1e6 * dt / 100, "algorithmic_GBs": R_bytes * 100 / dt / 1e9,
                                    "frac_of_8TBs": R_bytes * 100 / dt / 1e9 / HBM_PEAK_GBS}
+    del op, op2, S, J, U
+    # CG p=4, n=2^20 (config 5's fine-level operator at 1/16 size): point-Jacobi through the chain kernel
+    # (element lists given) and through the generic CSR kernel (operator only), smoother + residual
+    C = UniformCgDgHierarchy(n, ps=(4,))
+    A = C.A[0]
+    Nc, nnzc = A.shape[0], A.nnz
+    Sc = 12 * nnzc + 4 * (Nc + 1) + 8 * Nc + 24 * Nc
+    Rc = 12 * nnzc + 4 * (Nc + 1) + 24 * Nc
+    bc, uc, vc, rc = ctx.to_device(C.rhs()), ctx.to_device(np.zeros(Nc)), ctx.alloc(Nc), ctx.alloc(Nc)
+    cg = {"workload": f"CG n=2^20 p=4 point-Jacobi, N={Nc}, nnz(A)={nnzc}"}
+    for label, elems in (("chain", C.element_nodes(0)), ("generic_csr", None)):
+        opc = mg.DeviceOperator(A, _lib.OP_STIFFNESS, ctx)
+        Jc = mg.JacobiSmoother(opc, ctx, elems)
+        for per_launch in (1, 3):
+            reps = 99 // per_launch
+            fn = sweeps(opc.handle, Jc.handle, per_launch, uc, vc, bc)
+            fn(2)
+            dt = _time_loop(ctx, fn, reps)
+            nsw = reps * per_launch
+            cg[f"{label}_sweeps_{per_launch}_per_launch"] = {
+                "us_per_sweep": 1e6 * dt / nsw, "algorithmic_GBs": Sc * nsw / dt / 1e9,
+                "frac_of_8TBs": Sc * nsw / dt / 1e9 / HBM_PEAK_GBS}
+        fn = resid(opc.handle, uc, bc, rc)
+        fn(1)
+        dt = _time_loop(ctx, fn, 100)
+        cg[f"{label}_residual"] = {"us_per_residual": 1e6 * dt / 100, "algorithmic_GBs": Rc * 100 / dt / 1e9,
+                                   "frac_of_8TBs": Rc * 100 / dt / 1e9 / HBM_PEAK_GBS}
+        del opc, Jc
+    out["cg_p4_point_jacobi"] = cg
     return out
 
 
+def _traffic(role, tag):
+    tfile = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(tfile):
+        return None
+    try:
+        return json.load(open(tfile)).get(f"{role}_{tag}")
+    except Exception:
+        return None
+
+
 def cg_bench(mg, ctx, args, nPre, nPost, alpha):
-    """BASELINE config 5's realisable shape on ONE GPU: CG p=4 -> 2 -> 1 (point-Jacobi,
-    Galerkin operators) -> DG p=0, V(3,3); every level runs the generic CSR kernels."""
+    """BASELINE config 5's realisable shape at its stated size on ONE GPU: CG p=4 -> 2 -> 1
+    (point-Jacobi, Galerkin operators) -> DG p=0, V(3,3); the CG levels run the fused chain kernel."""
     from agglomerationmultigrid1d_amd.uniform import UniformCgDgHierarchy, build_device_cg_hierarchy
-    n = 2 ** args.cg_log2_elems
+    E = args.cg_log2_elems
+    n = 2 ** E
     t0 = time.perf_counter()
     U = UniformCgDgHierarchy(n, ps=(4, 2, 1))
+    t_gen = time.perf_counter() - t0
+    t0 = time.perf_counter()
     H = build_device_cg_hierarchy(U, ctx)
+    ctx.synchronize()
+    t_lib = time.perf_counter() - t0
+    kinds = H.level_kinds()
     N = U.A[0].shape[0]
+    nnz0 = U.A[0].nnz
     bm = U.algorithmic_bytes(nPre, nPost)
     b = ctx.to_device(U.rhs())
+    del U
     xa, xb = ctx.to_device(np.zeros(N)), ctx.alloc(N)
-    t_setup = time.perf_counter() - t0
-    steps = max(5, args.steps // 2)
-    for _ in range(2):
-        H.vcycle_dev(xa, b, xb, nPre, nPost, alpha)
-        xa, xb = xb, xa
+    steps = args.steps
+    state = [xa, xb]
+
+    def run(reps):
+        for _ in range(reps):
+            H.vcycle_dev(state[0], b, state[1], nPre, nPost, alpha)
+            state[0], state[1] = state[1], state[0]
+
+    run(args.warmup)
     ctx.synchronize()
-    t0 = time.perf_counter()
+    ctx.profile_enable(2)
+    dt = _time_loop(ctx, run, steps)
+    ctx.profile_enable(False)
+    dom = ctx.profile_collect()
+    per = []
     for _ in range(steps):
-        H.vcycle_dev(xa, b, xb, nPre, nPost, alpha)
-        xa, xb = xb, xa
+        per.append(_time_loop(ctx, run, 1))
+    ctx.profile_enable(1)
+    run(steps)
     ctx.synchronize()
-    dt = time.perf_counter() - t0
+    ctx.profile_enable(False)
+    prof = ctx.profile_collect()
+    prof.update(dom)
     vb = sum(l["vcycle"] for l in bm)
-    return {"workload": f"CG n=2^{args.cg_log2_elems} p=4 -> 2 -> 1 -> DG p=0, point-Jacobi, V(3,3), N_fine={N}, "
-                        f"nnz(A_1)={U.A[0].nnz}",
+    kern = {f"{k}_L{l}": {"ms_per_launch": v[0] / v[1], "launches": v[1]} for (k, l), v in sorted(prof.items())}
+    (dkind, dlevel), (dms, dcnt) = list(dom.items())[0]
+    lm = bm[0]
+    per_launch = nPre * lm['sweep'] + lm['residual'] + lm['restrict']
+    achieved = per_launch / (dms / dcnt * 1e-3) / 1e9
+    traffic = _traffic("chain_down_L0", f"cg_log2n{E}")
+    coarse_ms = kern.get("coarse_L3", {}).get("ms_per_launch", 0.0)
+    outer = {}
+    try:
+        t2 = time.perf_counter()
+        _, ncyc, res = mg.multigrid_dev(H, ctx.to_device(np.zeros(N)), b, 200, 1e-8, check_every=4)
+        outer["multigrid"] = {"cycles": ncyc, "ms": 1e3 * (time.perf_counter() - t2), "final_residual": res[-1]}
+    except Exception as e:
+        outer["error"] = repr(e)
+    H.free()
+    return {"workload": f"config 5 shape on 1 GPU: CG n=2^{E} p=4 -> 2 -> 1 -> DG p=0, point-Jacobi, V(3,3), alpha=2/3, "
+                        f"N_fine={N}, nnz(A_1)={nnz0}; level kernels {kinds}",
             "value": N * (nPre + nPost) * steps / dt, "unit": "DoF-updates/s", "ms_per_step": 1e3 * dt / steps,
-            "achieved_algorithmic_GBs_vcycle": vb * steps / dt / 1e9, "frac_of_8TBs": vb * steps / dt / 1e9 / HBM_PEAK_GBS,
-            "coarse_solve": H.coarse_info(), "setup_s": t_setup}
+            "median_ms_per_step": 1e3 * statistics.median(per),
+            "achieved_algorithmic_GBs_vcycle": vb * steps / dt / 1e9, "frac_of_8TBs_vcycle": vb * steps / dt / 1e9 / HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "cgt_fused_kernel<4> fused_down level 1 (3 sweeps + residual + restriction)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "frac_basis": "algorithmic", "traffic": traffic, "algorithmic_bytes_per_launch": per_launch,
+                         "physical_GBs": (traffic / (dms / dcnt * 1e-3) / 1e9) if traffic else None,
+                         "physical_frac": (traffic / (dms / dcnt * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                         "ms_per_launch": dms / dcnt, "launches_timed": dcnt},
+            "kernels": kern, "coarse_solve_ms_per_step": coarse_ms, "outer_solvers_to_1e-8": outer,
+            "setup_s": t_gen + t_lib, "setup_generator_s": t_gen, "setup_library_s": t_lib}
 
 
 def main():
@@ -236,9 +341,13 @@ def main():
         """build the hierarchy at 2^E fine elements, run `steps` timed V-cycles and the same count
         through the multi-cycle entry point"""
         n = 2 ** E
-        t_setup = time.perf_counter()
+        t0 = time.perf_counter()
         U = UniformDgAggHierarchy(n, p=args.p, pAgg=1, ratios=(4, 2, 2))
+        t_gen = time.perf_counter() - t0
+        t0 = time.perf_counter()
         H = build_device_hierarchy(U, ctx)
+        ctx.synchronize()
+        t_lib = time.perf_counter() - t0
         bytes_model = U.algorithmic_bytes(nPre, nPost)
         N = U.levels[0]['m'] * U.levels[0]['ne']
         b_host = U.rhs()
@@ -247,62 +356,39 @@ def main():
         xb = ctx.alloc(N)
         level_sizes = [lv['m'] * lv['ne'] for lv in U.levels]
         del U
-        t_setup = time.perf_counter() - t_setup
-        assert all(H.structured_levels()), "fused HIP kernels were not selected"
-        src, dst = xa, xb
-        for _ in range(warmup):
-            H.vcycle_dev(src, b, dst, nPre, nPost, alpha)
-            src, dst = dst, src
+        assert H.level_kinds() == ['fused_btd'] * (len(level_sizes) - 1) + ['coarsest'], "fused HIP kernels were not selected"
+        state = [xa, xb]
+
+        def run(reps):
+            for _ in range(reps):
+                H.vcycle_dev(state[0], b, state[1], nPre, nPost, alpha)
+                state[0], state[1] = state[1], state[0]
+
+        run(warmup)
         ctx.synchronize()
         if profile:
             ctx.profile_enable(2)   # the timed region carries events for the dominant kernel only
-        coarse_ms = 0.0
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            H.vcycle_dev(src, b, dst, nPre, nPost, alpha)
-            coarse_ms += H.last_coarse_ms()
-            src, dst = dst, src
-        ctx.synchronize()
-        dt = time.perf_counter() - t0
-        prof = None
+        dt = _time_loop(ctx, run, steps)
+        prof = prof_dom = None
         if profile:
             ctx.profile_enable(False)
-            prof = ctx.profile_collect()
-            # per-kernel table: a second, untimed pass with events around every launch (an event
-            # pair costs ~7 us of stream time, which would otherwise sit inside `value`)
+            prof_dom = ctx.profile_collect()
+        # median of >= 20 repetitions, each timed on its own
+        per = [_time_loop(ctx, run, 1) for _ in range(steps)]
+        if profile:
+            # per-kernel table: an untimed pass with events around every launch (an event pair costs
+            # ~7 us of stream time, which would otherwise sit inside `value`)
             ctx.profile_enable(1)
-            for _ in range(steps):
-                H.vcycle_dev(src, b, dst, nPre, nPost, alpha)
-                src, dst = dst, src
+            run(steps)
             ctx.synchronize()
             ctx.profile_enable(False)
-            prof_all = ctx.profile_collect()
-            prof_all.update(prof)     # the dominant kernel keeps its in-region measurement
-            prof_dom, prof = prof, prof_all
+            prof = ctx.profile_collect()
+            prof.update(prof_dom)     # the dominant kernel keeps its in-region measurement
         # the same K cycles through the multi-cycle entry point (the loop body of multigrid(),
         # src/solvers.jl:124-126): consecutive cycles share one fused fine-level launch.  Reported
         # beside `value`, which stays K independent multigrid_v_cycle calls.
-        H.vcycles_dev(src, b, dst, steps, nPre, nPost, alpha)
-        ctx.synchronize()
-        t1 = time.perf_counter()
-        H.vcycles_dev(src, b, dst, steps, nPre, nPost, alpha)
-        ctx.synchronize()
-        dt_loop = time.perf_counter() - t1
-        # the cheaper form of the restricted residual (AGGMG_RESTRICT_PRECONDITIONED), timed beside
-        # the default: NOT `value` -- at 2^24 it turns the multigrid iteration divergent
-        from agglomerationmultigrid1d_amd import _lib as _l
-        H.set_restriction(_l.RESTRICT_PRECONDITIONED)
-        for _ in range(warmup):
-            H.vcycle_dev(src, b, dst, nPre, nPost, alpha)
-            src, dst = dst, src
-        ctx.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(steps):
-            H.vcycle_dev(src, b, dst, nPre, nPost, alpha)
-            src, dst = dst, src
-        ctx.synchronize()
-        dt_fast = time.perf_counter() - t1
-        H.set_restriction(_l.RESTRICT_EXPLICIT)
+        H.vcycles_dev(state[0], b, state[1], steps, nPre, nPost, alpha)
+        dt_loop = _time_loop(ctx, lambda reps: H.vcycles_dev(state[0], b, state[1], reps, nPre, nPost, alpha), steps)
         info = H.coarse_info()
         # the device-resident outer loops, outside the timed region: multigrid()
         # (src/solvers.jl:116-139, residual check every 8 cycles) and CG preconditioned with
@@ -319,34 +405,27 @@ def main():
         except Exception as e:  # reported, never fatal for the bench line
             outer["error"] = repr(e)
         H.free()
-        return dict(N=N, dt=dt, dt_loop=dt_loop, prof=prof, prof_dom=(prof_dom if profile else None),
-                    bytes_model=bytes_model, level_sizes=level_sizes,
-                    coarse_ms=coarse_ms, t_setup=t_setup, coarse_info=info, outer=outer, dt_fast=dt_fast)
+        return dict(N=N, dt=dt, per=per, dt_loop=dt_loop, prof=prof, prof_dom=prof_dom,
+                    bytes_model=bytes_model, level_sizes=level_sizes, t_gen=t_gen, t_lib=t_lib,
+                    coarse_info=info, outer=outer)
 
     R = run_size(args.log2_elems, args.steps, args.warmup, True)
     N, dt, dt_loop, prof, bytes_model = R["N"], R["dt"], R["dt_loop"], R["prof"], R["bytes_model"]
-    level_sizes, coarse_ms, t_setup = R["level_sizes"], R["coarse_ms"], R["t_setup"]
+    level_sizes = R["level_sizes"]
 
     ms_per_step = 1e3 * dt / args.steps
     value = N * (nPre + nPost) * args.steps / dt
     vcycle_bytes = sum(l['vcycle'] for l in bytes_model)
-    # dominant kernel by total event time
     dom = list(R["prof_dom"].items())[0]   # the fine-level fused-down launch, timed inside the region
     (dkind, dlevel), (dms, dcnt) = dom
     lm = bytes_model[dlevel]
     per_launch = {"fused_down": nPre * lm['sweep'] + lm['residual'] + lm['restrict'],
                   "fused_up": nPost * lm['sweep'] + lm['prolong']}.get(dkind, lm['sweep'])
     achieved = per_launch / (dms / dcnt * 1e-3) / 1e9
-    traffic = None
-    tfile = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tfile):
-        try:
-            traffic = json.load(open(tfile)).get(f"{dkind}_L{dlevel}_log2n{args.log2_elems}")
-        except Exception:
-            traffic = None
+    traffic = _traffic(f"{dkind}_L{dlevel}", f"dg_log2n{args.log2_elems}")
     kern_ms = {f"{k}_L{l}": {"ms_per_launch": v[0] / v[1], "launches": v[1]} for (k, l), v in sorted(prof.items())}
     coarse_dev = [v["ms_per_launch"] for k, v in kern_ms.items() if k.startswith("coarse_")]
-    coarse_step_ms = (coarse_dev[0] if (R["coarse_info"].get("on_device") and coarse_dev) else coarse_ms / args.steps)
+    coarse_step_ms = coarse_dev[0] if coarse_dev else 0.0
     out = {
         "metric": "fine_level_dof_updates_per_s_per_vcycle",
         "value": value,
@@ -355,6 +434,7 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
+        "median_ms_per_step": 1e3 * statistics.median(R["per"]),
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
@@ -373,44 +453,37 @@ def main():
                                  "V-cycles (bitwise), post-smoothing of cycle i and pre-smoothing of cycle i+1 in one "
                                  "fine-level launch"},
         "outer_solvers_to_1e-8": R["outer"],
-        "preconditioned_residual_restriction": {
-            "value": N * (nPre + nPost) * args.steps / R["dt_fast"], "unit": "DoF-updates/s",
-            "ms_per_step": 1e3 * R["dt_fast"] / args.steps,
-            "note": "aggmg_hier_set_restriction(AGGMG_RESTRICT_PRECONDITIONED): L'(b - A u) taken from the sweeps' "
-                    "preconditioned residual instead of the operator's own entries; cheaper, but its rounding error on "
-                    "the smoothest mode grows like n^2 and at 2^24 fine elements the multigrid iteration diverges "
-                    "(x2.1 per cycle on that mode against x0.5 for the default and for reference-order arithmetic). "
-                    "Reported for comparison only; `value` is the default (explicit) form."},
         "coarse_solve": R["coarse_info"],
-        "coarse_solve_host_ms_per_step": coarse_ms / args.steps,
-        # SURVEY 8d times the coarsest solve separately: on the device its duration is the `coarse`
-        # entry of the per-kernel table (HIP events, untimed second pass), on the host path the host clock
+        # SURVEY 8d times the coarsest solve separately: the `coarse` entry of the per-kernel table
+        # (HIP events, untimed second pass)
         "coarse_solve_ms_per_step": coarse_step_ms,
         "value_excl_coarse_solve": N * (nPre + nPost) / max(1e-3 * (ms_per_step - coarse_step_ms), 1e-12),
         "roofline": {"bound": "hbm", "kernel": f"btd_fused_kernel<{args.p + 1},cmp> {dkind} level {dlevel + 1}",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "frac_basis": "algorithmic",
                      "traffic": traffic, "algorithmic_bytes_per_launch": per_launch,
                      "physical_GBs": (traffic / (dms / dcnt * 1e-3) / 1e9) if traffic else None,
                      "physical_frac": (traffic / (dms / dcnt * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                      "ms_per_launch": dms / dcnt, "launches_timed": dcnt,
-                     "note": "achieved = algorithmic bytes (SURVEY 8d model: CSR int32 + fp64, every sweep re-reading "
-                             "the operator) / HIP-event duration; the fused kernel reads the operator once per launch, "
-                             "so achieved exceeds what the launch physically moves: traffic = PMC bytes per launch "
-                             "(2*FETCH_SIZE + WRITE_SIZE, profiles/), physical_* = traffic / the same duration"},
+                     "note": "achieved / frac: ALGORITHMIC bytes per launch (SURVEY 8d model: CSR int32 + fp64, every "
+                             "sweep re-reading the operator) / HIP-event duration; the fused kernel reads the operator "
+                             "once per launch, so this exceeds 1.  traffic = PMC bytes per launch of this launch role "
+                             "(2*FETCH_SIZE + WRITE_SIZE, profiles/), physical_frac = traffic / duration / peak: the "
+                             "fraction of the HBM roofline the launch actually uses"},
         "kernels": kern_ms,
-        "setup_s": t_setup,
+        "setup_s": R["t_gen"] + R["t_lib"], "setup_generator_s": R["t_gen"], "setup_library_s": R["t_lib"],
     }
     if args.also_log2_elems and args.also_log2_elems != args.log2_elems:
         R2 = run_size(args.also_log2_elems, args.steps, args.warmup, False)
         out[f"config3_2p{args.also_log2_elems}"] = {
             "workload": f"config 3: same hierarchy at 2^{args.also_log2_elems} fine elements (N_fine={R2['N']})",
             "value": R2["N"] * (nPre + nPost) * args.steps / R2["dt"], "unit": "DoF-updates/s",
-            "ms_per_step": 1e3 * R2["dt"] / args.steps,
-            "vcycles_loop_ms_per_cycle": 1e3 * R2["dt_loop"] / args.steps, "setup_s": R2["t_setup"],
-            "preconditioned_residual_restriction_ms_per_step": 1e3 * R2["dt_fast"] / args.steps,
+            "ms_per_step": 1e3 * R2["dt"] / args.steps, "median_ms_per_step": 1e3 * statistics.median(R2["per"]),
+            "vcycles_loop_ms_per_cycle": 1e3 * R2["dt_loop"] / args.steps,
+            "setup_s": R2["t_gen"] + R2["t_lib"], "setup_generator_s": R2["t_gen"], "setup_library_s": R2["t_lib"],
             "outer_solvers_to_1e-8": R2["outer"]}
     if args.cg_log2_elems:
-        out["config5_shape_1gpu"] = cg_bench(mg, ctx, args, nPre, nPost, alpha)
+        out[f"config5_2p{args.cg_log2_elems}_1gpu"] = cg_bench(mg, ctx, args, nPre, nPost, alpha)
     if not args.no_smoother_bench:
         out["smoother_only"] = smoother_bench(mg, ctx, args, alpha)
     if not args.no_cpu_baseline:

@@ -50,6 +50,17 @@ const char* aggmg_last_error(aggmg_ctx* ctx); /* ctx may be NULL: last error of 
 int aggmg_set_stream(aggmg_ctx* ctx, void* hip_stream);
 int aggmg_reset_stream(aggmg_ctx* ctx);
 int aggmg_synchronize(aggmg_ctx* ctx);
+/* Context options (take effect for smoothers set up afterwards).
+ * AGGMG_OPT_SYMMETRIC_PACKING (default 1): when a block-tridiagonal operator is symmetric to round-off
+ * (|B^{-1} - B^{-T}| <= 1e-13 |B^{-1}| block by block and Sub_e == Sup_{e-1}' to the same tolerance --
+ * every operator the reference builds is) the SWEEPS of the fused kernel read the packed upper
+ * triangle of (B^{-1} + B^{-T}) / 2 and rebuild B^{-1} Sub_e from the neighbour's super-diagonal
+ * block instead of reading B^{-1} and B^{-1} Sub_e: 35 % fewer operator bytes per sweep launch.  This
+ * changes the smoother's block inverses by <= 1e-13 relative -- the smoothed iterate moves at round-off
+ * level, as between any two LU implementations; residuals and restrictions always use the operator's
+ * own entries.  0 switches it off (the kernels then read B^{-1} and B^{-1} Sub as factored). */
+#define AGGMG_OPT_SYMMETRIC_PACKING 1
+int aggmg_set_option(aggmg_ctx* ctx, int option, int value);
 /* Raw device memory owned by the context's device (plumbing for harnesses without torch). */
 int aggmg_dev_alloc(aggmg_ctx* ctx, int64_t nbytes, void** out);
 int aggmg_dev_free(aggmg_ctx* ctx, void* ptr);
@@ -171,20 +182,23 @@ int aggmg_vcycle_dev(aggmg_ctx* ctx, aggmg_hier* h, const double* x0, const doub
 int aggmg_vcycles_dev(aggmg_ctx* ctx, aggmg_hier* h, const double* x0, const double* b, int ncycles,
                       int nPre, int nPost, double alpha, double* x_out);
 /* How the fused descent forms the restricted residual L'(rhs - A u) of src/solvers.jl:36.
- * AGGMG_RESTRICT_EXPLICIT (default): r = rhs - A u with the operator's own entries, then L' r -- the
- * reference's arithmetic.  AGGMG_RESTRICT_PRECONDITIONED: (L'D) w from the preconditioned residual
- * w = B^{-1} r that the sweeps already hold; equal in exact arithmetic and ~20 % cheaper per V-cycle
- * (the descent reads neither the diagonal blocks nor L), but w carries the rounding of the stored
- * (symmetrically packed) block inverses.  Measured on the model problem: the factor by which one
+ * AGGMG_RESTRICT_EXPLICIT (the default of every hierarchy): r = rhs - A u with the operator's own
+ * entries, then L' r -- the reference's arithmetic.  AGGMG_RESTRICT_PRECONDITIONED: (L'D) w from the
+ * preconditioned residual w = B^{-1} r that the sweeps already hold; equal in exact arithmetic and
+ * ~20 % cheaper per V-cycle (the descent reads neither the diagonal blocks nor L), but w carries the
+ * rounding of the stored block inverses.  Measured on the model problem: the factor by which one
  * V(3,3) cycle multiplies the smoothest mode grows like n^2 in every implementation -- reference-
- * order arithmetic 0.031 / 0.125 / 0.498 at 2^22 / 2^23 / 2^24 fine elements, the explicit form
- * the same to three digits, the preconditioned form 0.134 / 0.533 / 2.13: at 2^24 it AMPLIFIES
- * the mode and the multigrid iteration diverges (tests/manual/exp_smooth_mode.py).
- * Use it at sizes well below that.  New hierarchies start in the mode named by the environment
- * variable AGGMG_RESTRICT ("preconditioned"), explicit otherwise. */
+ * order arithmetic 0.002 / 0.031 / 0.498 at 2^20 / 2^22 / 2^24 fine elements, the explicit form the
+ * same to three digits, the preconditioned form 0.009 / 0.134 / 2.13: at 2^24 it AMPLIFIES the mode
+ * and the multigrid iteration diverges (tests/manual/exp_smooth_mode.py).
+ * aggmg_hier_set_restriction therefore returns AGGMG_ERR_UNSUPPORTED for the preconditioned form on
+ * hierarchies with more than AGGMG_RESTRICT_PRECONDITIONED_MAX_ELEMS fine elements (where the
+ * extrapolated factor passes ~0.05).  No environment variable selects the mode. */
 #define AGGMG_RESTRICT_EXPLICIT 0
 #define AGGMG_RESTRICT_PRECONDITIONED 1
+#define AGGMG_RESTRICT_PRECONDITIONED_MAX_ELEMS (1 << 21)
 int aggmg_hier_set_restriction(aggmg_ctx* ctx, aggmg_hier* h, int mode);
+int aggmg_hier_get_restriction(aggmg_ctx* ctx, const aggmg_hier* h, int* mode);
 /* The two halves of the V-cycle around the coarsest solve (src/solvers.jl:28-37 and :41-47), for
  * callers that solve the coarsest system themselves (element-partitioned multi-GPU runs gather it
  * across ranks).  After _down the coarsest right-hand side is in the buffer reported by

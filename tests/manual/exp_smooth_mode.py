@@ -46,7 +46,11 @@ def main():
         ctx = mg.Context(0)
         H = build_device_hierarchy(U, ctx, keep_host=False)
         for name, mode in (("explicit", _lib.RESTRICT_EXPLICIT), ("preconditioned", _lib.RESTRICT_PRECONDITIONED)):
-            H.set_restriction(mode)
+            try:
+                H.set_restriction(mode)
+            except mg.UnsupportedError:        # refused above _lib.RESTRICT_PRECONDITIONED_MAX_ELEMS fine elements
+                line += f"  | HIP {name}: refused at this size"
+                continue
             x, y, z = ctx.to_device(mode_vec), ctx.alloc(N), ctx.to_device(zero_h)
             f = []
             prev = np.linalg.norm(mode_vec)

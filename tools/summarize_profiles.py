@@ -1,74 +1,151 @@
 #!/usr/bin/env python3
-"""Turn the rocprofv3 outputs of one profiled bench run (gpurun_out/<dir>/{kt,fetch,write}) into the
-committed summaries under profiles/: kernel-trace stats CSV, a PMC table (HBM bytes = 2*FETCH_SIZE +
-WRITE_SIZE per MI355X_MICROARCH.md) and profiles/traffic.json, which bench.py reads for
-roofline.traffic.   usage: summarize_profiles.py gpurun_out/prof2 r01 22"""
-import collections
+"""Turn the rocprofv3 outputs of one profiled `tools/profile_vcycle.py` run into the committed summaries
+under profiles/.
+
+    summarize_profiles.py <dir> <tag> <kind> <log2_elems>
+    <dir> holds three passes of the SAME command: kt/ (--kernel-trace --stats), fetch/ (--pmc FETCH_SIZE),
+    write/ (--pmc WRITE_SIZE), all with --output-format csv
+
+The profiled command runs nothing but default-mode V-cycles, so the library's kernel dispatches repeat
+with the period of one cycle; a dispatch's role is its position in that period: fused launches before the
+coarsest-solve kernels are the descent of levels 1, 2, ..., those after it the ascent in reverse order.
+Written: profiles/<tag>_<kind>_2p<E>_kernel_stats.csv (rocprofv3's own stats table),
+profiles/<tag>_<kind>_2p<E>_roles.md (per-role duration from the kernel trace + PMC bytes), and the
+per-role HBM bytes in profiles/traffic.json (HBM bytes = 2*FETCH_SIZE + WRITE_SIZE, the gfx950 correction
+of MI355X_MICROARCH.md section HBM), which bench.py reads for roofline.traffic."""
 import csv
 import glob
 import json
 import os
 import shutil
+import statistics
 import sys
 
-src, tag, E = sys.argv[1], sys.argv[2], int(sys.argv[3])
+src, tag, kind, E = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4])
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ne = 2 ** E
-TE, M = 128, 4   # BtdTile<4, true>: 256 threads x 2 slabs
 
 
-def grid(owned):
-    return ((ne + owned - 1) // owned) * 256
+def short(name):
+    return name.split("(")[0].replace("void ", "").replace("aggmg::", "")
 
 
-roles = {grid(TE - 2 * 4): "fused_down_L0", grid(((TE - 2 * 3) // 1)): "fused_up_L0",
-         grid(((TE - 2 * 7) // 4) * 4): "fused_mid_L0"}
-expected = {  # bytes per fine element the kernel must move
-    # symmetric operator: packed inverse 80, q row 32, b 32, u 32, L rows 64; the explicit residual
-    # behind the restriction (default) also reads the diagonal block 128 and the sub-diagonal column 32
-    "fused_down_L0": (80 + 32 + 32 + 32 + 64 + 128 + 32, 32 + 4),
-    "fused_up_L0": (80 + 32 + 32 + 32 + 64, 32),
-    "fused_mid_L0": (80 + 32 + 32 + 32 + 64 + 64 + 128 + 32, 32 + 4),
-}
+def is_ours(name):
+    return "aggmg::" in name and "dot_" not in name
 
 
-def load(kind):
-    f = glob.glob(os.path.join(src, kind, "*", "*counter_collection.csv"))[0]
-    agg = collections.defaultdict(list)
-    for r in csv.DictReader(open(f)):
-        agg[(r["Kernel_Name"], int(r["Grid_Size"]))].append(float(r["Counter_Value"]))
-    return {k: (sum(v) / len(v), len(v)) for k, v in agg.items()}
+def period(seq):
+    """smallest S with the last three windows of length S equal"""
+    for S in range(1, len(seq) // 3 + 1):
+        if seq[-S:] == seq[-2 * S:-S] == seq[-3 * S:-2 * S]:
+            return S
+    raise SystemExit("no periodic dispatch pattern found")
 
 
-shutil.copy(glob.glob(os.path.join(src, "kt", "*", "*kernel_stats.csv"))[0],
-            os.path.join(ROOT, "profiles", f"{tag}_bench_kernel_stats_2p{E}.csv"))
-F, W = load("fetch"), load("write")
-lines = [f"# rocprofv3 PMC summary {tag} -- `python bench.py --steps 5 --warmup 1` (config 3/4 hierarchy, 2^{E} fine elements, MI355X)",
+def roles_of(window):
+    """window: list of short kernel names of one cycle"""
+    fused = [i for i, k in enumerate(window) if "fused_kernel" in k]
+    coarse = [i for i, k in enumerate(window) if "cr_" in k]
+    first_c = coarse[0] if coarse else len(window)
+    names = []
+    down = [i for i in fused if i < first_c]
+    up = [i for i in fused if i > first_c]
+    for i, k in enumerate(window):
+        if i in down:
+            names.append(f"fused_down_L{down.index(i)}")
+        elif i in up:
+            names.append(f"fused_up_L{len(up) - 1 - up.index(i)}")
+        elif i in coarse:
+            names.append(f"coarse_{coarse.index(i)}:{k.split('<')[0]}")
+        else:
+            names.append(f"other_{i}:{k.split('<')[0]}")
+    return names
+
+
+def load_trace(path):
+    rows = [r for r in csv.DictReader(open(path)) if is_ours(r["Kernel_Name"])]
+    rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+    return rows
+
+
+def per_role(rows, value):
+    seq = [(short(r["Kernel_Name"]), r.get("Grid_Size_X", r.get("Grid_Size"))) for r in rows]
+    S = period(seq)
+    ncyc = 0
+    while (ncyc + 1) * S <= len(seq) and seq[-(ncyc + 1) * S:len(seq) - ncyc * S] == seq[-S:]:
+        ncyc += 1
+    names = roles_of([k for k, _ in seq[-S:]])
+    out = {}
+    for pos, nm in enumerate(names):
+        vals = [value(rows[len(rows) - (c + 1) * S + pos]) for c in range(ncyc)]
+        out[nm] = (vals, seq[len(seq) - S + pos])
+    return out, ncyc, names
+
+
+kt = glob.glob(os.path.join(src, "kt", "*", "*kernel_trace.csv"))[0]
+stats = glob.glob(os.path.join(src, "kt", "*", "*kernel_stats.csv"))[0]
+base = f"{tag}_{kind}_2p{E}"
+shutil.copy(stats, os.path.join(ROOT, "profiles", f"{base}_kernel_stats.csv"))
+dur, ncyc, names = per_role(load_trace(kt), lambda r: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6)
+vgpr = {}
+for r in load_trace(kt):
+    vgpr[short(r["Kernel_Name"])] = (r["VGPR_Count"], r["LDS_Block_Size"])
+
+
+def pmc(which):
+    f = glob.glob(os.path.join(src, which, "*", "*counter_collection.csv"))
+    if not f:
+        return None
+    rows = load_trace(f[0])
+    return per_role(rows, lambda r: float(r["Counter_Value"]))[0]
+
+
+F, W = pmc("fetch"), pmc("write")
+
+# bytes the kernel's arrays hold per launch (known counts, halo re-reads not included): the calibration
+# of the PMC figures on this access pattern
+if kind == "dg":
+    # per fine element (m = 4): packed symmetric inverse 80, q row 32, b 32, u 32, L rows 64; the explicit
+    # residual behind the restriction also reads the diagonal block 128 and the sub-diagonal column 32
+    expected = {"fused_down_L0": ((80 + 32 + 32 + 32 + 64 + 128 + 32) * ne, (32 + 4) * ne),
+                "fused_up_L0": ((80 + 32 + 32 + 32 + 64 + 4) * ne, 32 * ne)}
+else:
+    # per fine block of 4 rows: dblk 128 + subrow 32 + supcol 32, b 32, u 32, perm 16, L rows 96 (3 per row)
+    expected = {"fused_down_L0": ((192 + 32 + 32 + 16 + 96) * ne, (32 + 16) * ne),
+                "fused_up_L0": ((192 + 32 + 32 + 16 + 96 + 16) * ne, 32 * ne)}
+
+lines = [f"# rocprofv3 summary {tag}: `python tools/profile_vcycle.py --kind {kind} --log2-elems {E}` on MI355X",
          "",
-         "Separate passes `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (`--output-format csv`), KiB per dispatch,",
-         "mean over the pass.  gfx950: FETCH_SIZE counts half the bytes of a coalesced streaming read",
-         "(MI355X_MICROARCH.md, HBM), so HBM bytes = 2*FETCH_SIZE + WRITE_SIZE; the 'expected' columns are the bytes the",
-         "kernel's arrays hold per launch (known counts, halo re-reads not included) -- the calibration on this access pattern.",
+         f"Roles = position of a dispatch in the cycle's launch sequence ({len(names)} launches per V(3,3) cycle, "
+         f"{ncyc} cycles in the trace).  Duration: `--kernel-trace` pass (End - Start, ms).  FETCH / WRITE: separate",
+         "`--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes, KiB per dispatch.  gfx950: FETCH_SIZE counts half the bytes of a",
+         "coalesced streaming read (MI355X_MICROARCH.md, HBM), so HBM bytes = 2*FETCH_SIZE + WRITE_SIZE.  `expected` = the",
+         "bytes the launch's arrays hold (halo re-reads not included).",
          "",
-         "| kernel | role (grid threads) | launches | FETCH KiB | WRITE KiB | HBM bytes 2F+W | expected read | expected write |",
-         "|---|---|---|---|---|---|---|---|"]
+         "| role | kernel (grid threads) | VGPR | LDS B | ms mean | ms median | ms min | FETCH KiB | WRITE KiB | HBM bytes 2F+W | TB/s at mean | expected read | expected write |",
+         "|---|---|---|---|---|---|---|---|---|---|---|---|---|"]
 traffic = {}
-for (k, g), (f, n) in sorted(F.items(), key=lambda kv: -kv[1][0]):
-    if "btd_fused" not in k and "cr_" not in k:
-        continue
-    w = W.get((k, g), (0.0, 0))[0]
-    role = roles.get(g, "")
-    hb = (2 * f + w) * 1024
-    er, ew = ("", "")
-    if role in expected:
-        er, ew = (expected[role][0] * ne, expected[role][1] * ne)
-        traffic[f"{role}_log2n{E}"] = hb
-    name = k.split("(")[0].replace("void ", "")
-    lines.append(f"| `{name}` | {role} ({g}) | {n} | {f:.1f} | {w:.1f} | {hb:.4g} | {er} | {ew} |")
-lines += ["", f"Kernel-trace stats of the same command: profiles/{tag}_bench_kernel_stats_2p{E}.csv."]
-open(os.path.join(ROOT, "profiles", f"{tag}_pmc_summary_2p{E}.md"), "w").write("\n".join(lines) + "\n")
+for nm in names:
+    vals, (k, g) = dur[nm]
+    f = statistics.mean(F[nm][0]) if F and nm in F else None
+    w = statistics.mean(W[nm][0]) if W and nm in W else None
+    hb = (2 * f + w) * 1024 if f is not None and w is not None else None
+    er, ew = expected.get(nm, ("", ""))
+    vg, ld = vgpr.get(k, ("", ""))
+    tbs = f"{hb / (statistics.mean(vals) * 1e-3) / 1e12:.2f}" if hb else ""
+    lines.append(f"| {nm} | `{k}` ({g}) | {vg} | {ld} | {statistics.mean(vals):.4f} | {statistics.median(vals):.4f} | "
+                 f"{min(vals):.4f} | {f if f is None else round(f, 1)} | {w if w is None else round(w, 1)} | "
+                 f"{'' if hb is None else f'{hb:.4g}'} | {tbs} | {er} | {ew} |")
+    if hb is not None and nm.startswith("fused_"):
+        key = nm.replace("fused_", "chain_") if kind == "cg" else nm
+        traffic[f"{key}_{kind}_log2n{E}"] = hb
+tot = sum(statistics.mean(dur[nm][0]) for nm in names)
+lines += ["", f"Sum of the mean kernel durations of one cycle: {tot:.4f} ms.",
+          f"rocprofv3's own per-kernel stats of the same trace: profiles/{base}_kernel_stats.csv."]
+open(os.path.join(ROOT, "profiles", f"{base}_roles.md"), "w").write("\n".join(lines) + "\n")
 tf = os.path.join(ROOT, "profiles", "traffic.json")
 old = json.load(open(tf)) if os.path.exists(tf) else {}
+old = {k: v for k, v in old.items() if "_log2n" in k and ("_dg_" in k or "_cg_" in k)}   # drop pre-r02 keys
 old.update(traffic)
 json.dump(old, open(tf, "w"), indent=1)
 print("\n".join(lines))
