@@ -26,6 +26,9 @@ RESTRICT_EXPLICIT, RESTRICT_PRECONDITIONED = 0, 1
 RESTRICT_PRECONDITIONED_MAX_ELEMS = 1 << 21
 # aggmg_hier_level_kind
 LEVEL_GENERIC, LEVEL_FUSED_BTD, LEVEL_FUSED_CHAIN, LEVEL_COARSEST = 0, 1, 2, 3
+RCCL_ID_BYTES = 128
+DIST_X0_GHOSTS_VALID, DIST_OVERLAP_NEXT, DIST_GRAPH = 1, 2, 4
+ALLGATHER_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p, c_void_p, c_int64, c_void_p)
 LEVEL_KIND_NAMES = ["generic", "fused_btd", "fused_chain", "coarsest"]
 
 
@@ -119,6 +122,18 @@ SYMBOLS = {
     "aggmg_hier_last_coarse_ms": (c_int, [_P, _P, POINTER(c_double)]),
     "aggmg_copy_segments_dev": (c_int, [_P, c_int, POINTER(_P), POINTER(_P), POINTER(c_int64), POINTER(c_int64),
                                         POINTER(c_int64), POINTER(c_int64)]),
+    "aggmg_dist_create": (c_int, [_P, _P, _P, c_int, c_int, c_int, POINTER(c_int64), POINTER(c_int64), POINTER(c_int64),
+                                  POINTER(c_int64), POINTER(c_int64), POINTER(c_int32), POINTER(c_int32), POINTER(_P)]),
+    "aggmg_dist_free": (c_int, [_P, _P]),
+    "aggmg_rccl_unique_id": (c_int, [_P, _P, c_int]),
+    "aggmg_dist_init_rccl": (c_int, [_P, _P, _P, c_int, POINTER(c_int)]),
+    "aggmg_dist_set_allgather": (c_int, [_P, _P, _P, _P]),
+    "aggmg_dist_set_loopback": (c_int, [_P, _P]),
+    "aggmg_dist_allgather_dev": (c_int, [_P, _P, _P, _P, c_int64]),
+    "aggmg_dist_exchange_ghosts_dev": (c_int, [_P, _P, _P, c_int]),
+    "aggmg_dist_vcycle_dev": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_double, c_int]),
+    "aggmg_dist_info": (c_int, [_P, _P, POINTER(c_int64), POINTER(c_int), POINTER(c_int)]),
+    "aggmg_dist_graph_info": (c_int, [_P, _P, POINTER(c_int64), POINTER(c_int), POINTER(c_int)]),
     "aggmg_dot_dev": (c_int, [_P, _P, _P, c_int64, POINTER(c_double)]),
     "aggmg_norm2_dev": (c_int, [_P, _P, c_int64, POINTER(c_double)]),
     "aggmg_residual_norm_dev": (c_int, [_P, _P, _P, _P, POINTER(c_double)]),

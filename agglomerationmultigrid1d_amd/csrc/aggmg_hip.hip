@@ -146,50 +146,6 @@ extern "C" int aggmg_profile_collect(aggmg_ctx* ctx, double* total_ms, int64_t* 
 // ---------------------------------------------------------------------------------------------
 // operators
 // ---------------------------------------------------------------------------------------------
-static int pick_lpr(int64_t nnz, int64_t nrows) {
-  double avg = nrows > 0 ? (double)nnz / (double)nrows : 1.0;
-  int lpr = 1;
-  while (lpr < 64 && (double)lpr * 1.5 < avg) lpr *= 2;
-  return lpr;
-}
-
-static int upload_csr(aggmg_ctx* ctx, int64_t nrows, int64_t ncols, const std::vector<int32_t>& rowptr,
-                      const std::vector<int32_t>& colind, const std::vector<double>& vals, CsrDev* d) {
-  d->nrows = nrows;
-  d->ncols = ncols;
-  d->nnz = (int64_t)colind.size();
-  d->lpr = pick_lpr(d->nnz, nrows);
-  CHECK(dev_upload(ctx, rowptr, &d->rowptr));
-  CHECK(dev_upload(ctx, colind, &d->colind));
-  CHECK(dev_upload(ctx, vals, &d->vals));
-  // short rows: cut the rows into blocks of <= kStreamNnz entries and <= 4 * kThreads rows for the
-  // CSR-stream kernel; long-row matrices keep the lanes-per-row kernel
-  if (nrows > 0 && (double)d->nnz / (double)nrows <= 48.0) {
-    std::vector<int32_t> blk;
-    blk.push_back(0);
-    int64_t r = 0;
-    while (r < nrows) {
-      int64_t e = r + 1;  // a block always takes at least one row (a long row stands alone)
-      const int64_t base = rowptr[r];
-      while (e < nrows && e - r < 4 * kThreads && rowptr[e + 1] - base <= kStreamNnz) ++e;
-      if (rowptr[r + 1] - base > kStreamNnz) e = r + 1;
-      blk.push_back((int32_t)e);
-      r = e;
-    }
-    d->nblk = (int64_t)blk.size() - 1;
-    CHECK(dev_upload(ctx, blk, &d->rowblk));
-  }
-  return AGGMG_OK;
-}
-
-static void free_csr(CsrDev* d) {
-  if (d->rowptr) (void)hipFree(d->rowptr);
-  if (d->colind) (void)hipFree(d->colind);
-  if (d->vals) (void)hipFree(d->vals);
-  if (d->rowblk) (void)hipFree(d->rowblk);
-  *d = CsrDev();
-}
-
 extern "C" int aggmg_csc_upload(aggmg_ctx* ctx, int64_t m, int64_t n, const int64_t* colptr,
                                 const int64_t* rowval, const double* nzval, int one_based, int kind,
                                 aggmg_op** out) {
@@ -206,50 +162,15 @@ extern "C" int aggmg_csc_upload(aggmg_ctx* ctx, int64_t m, int64_t n, const int6
   if (kind != AGGMG_OP_STIFFNESS && kind != AGGMG_OP_TRANSFER)
     return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_csc_upload: unknown kind");
   HIPCHK(hipSetDevice(ctx->device));
-
-  // the CSC arrays, 0-based int32: this IS the CSR of the transpose
-  std::vector<int32_t> cptr(n + 1), rval(nnz);
-  for (int64_t j = 0; j <= n; ++j) {
-    int64_t v = colptr[j] - base;
-    if (v < 0 || v > nnz || (j > 0 && v < cptr[j - 1]))
-      return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_csc_upload: colptr not monotone");
-    cptr[j] = (int32_t)v;
-  }
-  for (int64_t j = 0; j < n; ++j) {
-    for (int32_t p = cptr[j]; p < cptr[j + 1]; ++p) {
-      int64_t r = rowval[p] - base;
-      if (r < 0 || r >= m) return fail(ctx, AGGMG_ERR_DIMENSION, "aggmg_csc_upload: row index out of range");
-      if (p > cptr[j] && r <= rval[p - 1])
-        return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_csc_upload: row indices not strictly ascending in a column");
-      rval[p] = (int32_t)r;
-    }
-  }
-  std::vector<double> cval(nzval, nzval + nnz);
-
-  // transpose to the row-gather CSR (counting sort; ascending columns inside every row)
+  // the arrays go to the device as they are; validation, the Int64 -> int32 conversion and everything
+  // derived from them later (smoother blocks, structured forms, the row-gather CSR where a generic
+  // kernel needs it) are computed there (setup.hip)
   auto op = std::make_unique<aggmg_op>();
   op->m = m;
   op->n = n;
   op->nnz = nnz;
   op->kind = kind;
-  HostCsr& h = op->host;
-  h.rowptr.assign(m + 1, 0);
-  h.colind.resize(nnz);
-  h.vals.resize(nnz);
-  for (int64_t p = 0; p < nnz; ++p) h.rowptr[rval[p] + 1]++;
-  for (int64_t i = 0; i < m; ++i) h.rowptr[i + 1] += h.rowptr[i];
-  {
-    std::vector<int32_t> next(h.rowptr.begin(), h.rowptr.end() - 1);
-    for (int64_t j = 0; j < n; ++j)
-      for (int32_t p = cptr[j]; p < cptr[j + 1]; ++p) {
-        int32_t q = next[rval[p]]++;
-        h.colind[q] = (int32_t)j;
-        h.vals[q] = cval[p];
-      }
-  }
-  op->host_valid = true;
-  CHECK(upload_csr(ctx, m, n, h.rowptr, h.colind, h.vals, &op->csr));
-  if (kind == AGGMG_OP_TRANSFER) CHECK(upload_csr(ctx, n, m, cptr, rval, cval, &op->csrT));
+  CHECK(setup_csc_upload(ctx, m, n, colptr, rowval, nzval, one_based, &op->csc));
   *out = op.release();
   return AGGMG_OK;
 }
@@ -258,9 +179,7 @@ extern "C" int aggmg_op_free(aggmg_ctx* ctx, aggmg_op* op) {
   if (!ctx) return AGGMG_ERR_ARGUMENT;
   if (!op) return AGGMG_OK;
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  free_csr(&op->csr);
-  free_csr(&op->csrT);
-  delete op;
+  delete op;  // the destructor frees the device arrays
   return AGGMG_OK;
 }
 
@@ -272,11 +191,14 @@ extern "C" int aggmg_op_shape(aggmg_ctx* ctx, const aggmg_op* op, int64_t* m, in
   return AGGMG_OK;
 }
 
-extern "C" int aggmg_op_download(aggmg_ctx* ctx, const aggmg_op* op, int transposed, int32_t* rowptr,
+extern "C" int aggmg_op_download(aggmg_ctx* ctx, const aggmg_op* op_, int transposed, int32_t* rowptr,
                                  int32_t* colind, double* vals) {
-  if (!ctx || !op) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_op_download: NULL");
-  const CsrDev& d = transposed ? op->csrT : op->csr;
-  if (!d.rowptr) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_op_download: orientation not stored for this op");
+  if (!ctx || !op_) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_op_download: NULL");
+  aggmg_op* op = const_cast<aggmg_op*>(op_);
+  if (transposed && op->kind != AGGMG_OP_TRANSFER)
+    return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_op_download: orientation not stored for this op");
+  if (!transposed) CHECK(op_ensure_csr(ctx, op));  // the row-gather form is built on first use
+  const CsrDev& d = transposed ? op->csc : op->csr;
   if (rowptr) HIPCHK(hipMemcpyAsync(rowptr, d.rowptr, (d.nrows + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
   if (colind && d.nnz) HIPCHK(hipMemcpyAsync(colind, d.colind, d.nnz * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
   if (vals && d.nnz) HIPCHK(hipMemcpyAsync(vals, d.vals, d.nnz * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
@@ -284,309 +206,37 @@ extern "C" int aggmg_op_download(aggmg_ctx* ctx, const aggmg_op* op, int transpo
   return AGGMG_OK;
 }
 
+// (kept for ABI compatibility: the library holds no host copy of an operator any more)
 extern "C" int aggmg_op_release_host(aggmg_ctx* ctx, aggmg_op* op) {
   if (!ctx || !op) return AGGMG_ERR_ARGUMENT;
-  op->host = HostCsr();
-  op->host_valid = false;
   return AGGMG_OK;
 }
 
 // ---------------------------------------------------------------------------------------------
-// small dense helpers (host, set-up only)
+// smoothers (set-up on the device: setup.hip)
 // ---------------------------------------------------------------------------------------------
-// In-place LU with partial pivoting (the arithmetic of LAPACK getf2), then the explicit inverse
-// by solving for the identity columns.  a, inv: m x m row-major.  false on an exactly-zero pivot
-// (Julia: SingularException, src/smoother.jl:160).
-static bool invert_block(int m, std::vector<double>& a, std::vector<double>& inv, std::vector<int>& piv) {
-  piv.resize(m);
-  for (int k = 0; k < m; ++k) {
-    int p = k;
-    double best = std::fabs(a[k * m + k]);
-    for (int i = k + 1; i < m; ++i) {
-      double v = std::fabs(a[i * m + k]);
-      if (v > best) {
-        best = v;
-        p = i;
-      }
-    }
-    piv[k] = p;
-    if (a[p * m + k] == 0.0) return false;
-    if (p != k)
-      for (int j = 0; j < m; ++j) std::swap(a[k * m + j], a[p * m + j]);
-    const double rp = 1.0 / a[k * m + k];
-    for (int i = k + 1; i < m; ++i) a[i * m + k] *= rp;
-    for (int i = k + 1; i < m; ++i) {
-      const double l = a[i * m + k];
-      for (int j = k + 1; j < m; ++j) a[i * m + j] -= l * a[k * m + j];
-    }
-  }
-  inv.assign((size_t)m * m, 0.0);
-  std::vector<double> x(m);
-  for (int c = 0; c < m; ++c) {
-    for (int i = 0; i < m; ++i) x[i] = (i == c) ? 1.0 : 0.0;
-    for (int k = 0; k < m; ++k)
-      if (piv[k] != k) std::swap(x[k], x[piv[k]]);
-    for (int i = 1; i < m; ++i) {
-      double s = x[i];
-      for (int j = 0; j < i; ++j) s -= a[i * m + j] * x[j];
-      x[i] = s;
-    }
-    for (int i = m - 1; i >= 0; --i) {
-      double s = x[i];
-      for (int j = i + 1; j < m; ++j) s -= a[i * m + j] * x[j];
-      x[i] = s / a[i * m + i];
-    }
-    for (int i = 0; i < m; ++i) inv[i * m + c] = x[i];
-  }
-  return true;
-}
-
-static double host_entry(const HostCsr& h, int64_t r, int64_t c) {
-  const int32_t* b = h.colind.data() + h.rowptr[r];
-  const int32_t* e = h.colind.data() + h.rowptr[r + 1];
-  const int32_t* it = std::lower_bound(b, e, (int32_t)c);
-  if (it != e && *it == (int32_t)c) return h.vals[it - h.colind.data()];
-  return 0.0;
-}
-
-// ---------------------------------------------------------------------------------------------
-// smoothers
-// ---------------------------------------------------------------------------------------------
-static bool btd_supported(int m, bool cmp) {
-  if (cmp) return m >= 2 && m <= 9;
-  return m >= 1 && m <= 5;
-}
-
-// Recognise "block-tridiagonal with contiguous aligned m-blocks" and build the fused-kernel form.
-static int build_btd(aggmg_ctx* ctx, aggmg_smoother* sm, const std::vector<double>& binv_all) {
-  const HostCsr& h = sm->A->host;
-  const int m = (int)sm->m;
-  const int64_t ne = sm->nb, N = sm->N;
-  for (int64_t r = 0; r < N; ++r) {
-    const int64_t e = r / m;
-    const int64_t lo = std::max<int64_t>(0, (e - 1) * m), hi = std::min<int64_t>(N, (e + 2) * m);
-    for (int32_t p = h.rowptr[r]; p < h.rowptr[r + 1]; ++p)
-      if (h.colind[p] < lo || h.colind[p] >= hi) return AGGMG_OK;  // not block-tridiagonal
-  }
-  std::vector<double> dblk((size_t)N * m, 0.0), sub((size_t)N * m, 0.0), sup((size_t)N * m, 0.0);
-  parallel_for(N, [&](int64_t rb, int64_t re) {
-    for (int64_t r = rb; r < re; ++r) {
-      const int64_t e = r / m;
-      for (int32_t p = h.rowptr[r]; p < h.rowptr[r + 1]; ++p) {
-        const int64_t c = h.colind[p];
-        const int64_t ce = c / m;
-        const int j = (int)(c - ce * m);
-        if (ce == e)
-          dblk[r * m + j] = h.vals[p];
-        else if (ce == e - 1)
-          sub[r * m + j] = h.vals[p];
-        else
-          sup[r * m + j] = h.vals[p];
-      }
-    }
-  });
-  // compressed pattern: Sub_e non-zero in one common column, Sup_e in one common row
-  int c_sub = -1, r_sup = -1;
-  bool cmp = m >= 2;
-  for (int64_t r = 0; r < N && cmp; ++r) {
-    const int i = (int)(r % m);
-    for (int j = 0; j < m; ++j) {
-      if (sub[r * m + j] != 0.0) {
-        if (c_sub < 0) c_sub = j;
-        if (c_sub != j) cmp = false;
-      }
-      if (sup[r * m + j] != 0.0) {
-        if (r_sup < 0) r_sup = i;
-        if (r_sup != i) cmp = false;
-      }
-    }
-  }
-  if (c_sub < 0) c_sub = 0;
-  if (r_sup < 0) r_sup = 0;
-  if (cmp && !btd_supported(m, true)) cmp = false;
-  if (!cmp && !btd_supported(m, false)) return AGGMG_OK;  // generic path
-
-  auto b = std::make_shared<BtdDev>();
-  b->m = m;
-  b->ne = ne;
-  b->cmp = cmp;
-  b->c_sub = c_sub;
-  b->r_sup = r_sup;
-  // binv_all is [nb][m][m] row-major == [N][m]
-  int st = dev_upload(ctx, binv_all, &b->binv);
-  if (st == AGGMG_OK) st = dev_upload(ctx, dblk, &b->dblk);
-  if (cmp) {
-    std::vector<double> scol(N), pcol(N), qrow((size_t)ne * m);
-    for (int64_t r = 0; r < N; ++r) scol[r] = sub[r * m + c_sub];
-    parallel_for(ne, [&](int64_t eb, int64_t ee) {
-      for (int64_t e = eb; e < ee; ++e) {
-        for (int j = 0; j < m; ++j) qrow[e * m + j] = sup[(e * m + r_sup) * m + j];
-        for (int i = 0; i < m; ++i) {
-          double acc = 0.0;
-          for (int j = 0; j < m; ++j) acc += binv_all[(e * m + i) * m + j] * scol[e * m + j];
-          pcol[e * m + i] = acc;
-        }
-      }
-    });
-    if (st == AGGMG_OK) st = dev_upload(ctx, scol, &b->scol);
-    if (st == AGGMG_OK) st = dev_upload(ctx, pcol, &b->pcol);
-    if (st == AGGMG_OK) st = dev_upload(ctx, qrow, &b->qrow);
-    // symmetric to round-off?  (B_e^{-1} symmetric, and Sub_e[:, c] == Sup_{e-1}[r, :] with c == r)
-    // then the kernels read the packed upper triangle and rebuild pcol from the neighbour's q row
-    const bool grp = (m == 2 || m == 4 || m == 8);
-    if (grp && c_sub == r_sup && ctx->sym_packing) {
-      std::atomic<int> asym{0};
-      const double tol = 1e-13;
-      parallel_for(ne, [&](int64_t eb, int64_t ee) {
-        for (int64_t e = eb; e < ee && !asym.load(std::memory_order_relaxed); ++e) {
-          double scale = 0.0, qs = 0.0;
-          for (int q = 0; q < m * m; ++q) scale = std::max(scale, std::fabs(binv_all[e * m * m + q]));
-          for (int i = 0; i < m; ++i)
-            for (int j = i + 1; j < m; ++j)
-              if (std::fabs(binv_all[(e * m + i) * m + j] - binv_all[(e * m + j) * m + i]) > tol * scale) asym.store(1);
-          if (e > 0) {
-            for (int j = 0; j < m; ++j) qs = std::max(qs, std::fabs(qrow[(e - 1) * m + j]));
-            for (int j = 0; j < m; ++j)
-              if (std::fabs(scol[e * m + j] - qrow[(e - 1) * m + j]) > tol * qs) asym.store(1);
-          }
-        }
-      });
-      if (!asym.load()) {
-        const int T = m * (m + 1) / 2;
-        std::vector<double> bsym((size_t)ne * T);
-        parallel_for(ne, [&](int64_t eb, int64_t ee) {
-          for (int64_t e = eb; e < ee; ++e) {
-            int q = 0;
-            for (int i = 0; i < m; ++i)
-              for (int j = i; j < m; ++j)
-                bsym[e * T + q++] = 0.5 * (binv_all[(e * m + i) * m + j] + binv_all[(e * m + j) * m + i]);
-          }
-        });
-        if (st == AGGMG_OK) st = dev_upload(ctx, bsym, &b->bsym);
-      }
-    }
-  } else {
-    std::vector<double> P((size_t)N * m), Q((size_t)N * m);
-    parallel_for(ne, [&](int64_t eb, int64_t ee) {
-      for (int64_t e = eb; e < ee; ++e)
-        for (int i = 0; i < m; ++i)
-          for (int j = 0; j < m; ++j) {
-            double p = 0.0, q = 0.0;
-            for (int k = 0; k < m; ++k) {
-              const double bi = binv_all[(e * m + i) * m + k];
-              p += bi * sub[(e * m + k) * m + j];
-              q += bi * sup[(e * m + k) * m + j];
-            }
-            P[(e * m + i) * m + j] = p;
-            Q[(e * m + i) * m + j] = q;
-          }
-    });
-    if (st == AGGMG_OK) st = dev_upload(ctx, sub, &b->sub);
-    if (st == AGGMG_OK) st = dev_upload(ctx, sup, &b->sup);
-    if (st == AGGMG_OK) st = dev_upload(ctx, P, &b->P);
-    if (st == AGGMG_OK) st = dev_upload(ctx, Q, &b->Q);
-    // symmetric to round-off (B_e^{-1} symmetric, Sub_e == Sup_{e-1}')?  then the kernels read the
-    // packed inverse and the super-diagonal blocks only
-    if ((m == 2 || m == 4) && ctx->sym_packing) {
-      std::atomic<int> asym{0};
-      const double tol = 1e-13;
-      parallel_for(ne, [&](int64_t eb, int64_t ee) {
-        for (int64_t e = eb; e < ee && !asym.load(std::memory_order_relaxed); ++e) {
-          double scale = 0.0, ss = 0.0;
-          for (int q = 0; q < m * m; ++q) scale = std::max(scale, std::fabs(binv_all[e * m * m + q]));
-          for (int i = 0; i < m; ++i)
-            for (int j = i + 1; j < m; ++j)
-              if (std::fabs(binv_all[(e * m + i) * m + j] - binv_all[(e * m + j) * m + i]) > tol * scale) asym.store(1);
-          if (e > 0) {
-            for (int q = 0; q < m * m; ++q) ss = std::max(ss, std::fabs(sup[(e - 1) * m * m + q]));
-            for (int i = 0; i < m; ++i)
-              for (int j = 0; j < m; ++j)
-                if (std::fabs(sub[(e * m + i) * m + j] - sup[((e - 1) * m + j) * m + i]) > tol * ss) asym.store(1);
-          }
-        }
-      });
-      if (!asym.load()) {
-        const int T = m * (m + 1) / 2;
-        std::vector<double> bsym((size_t)ne * T);
-        parallel_for(ne, [&](int64_t eb, int64_t ee) {
-          for (int64_t e = eb; e < ee; ++e) {
-            int q = 0;
-            for (int i = 0; i < m; ++i)
-              for (int j = i; j < m; ++j)
-                bsym[e * T + q++] = 0.5 * (binv_all[(e * m + i) * m + j] + binv_all[(e * m + j) * m + i]);
-          }
-        });
-        if (st == AGGMG_OK) st = dev_upload(ctx, bsym, &b->bsym);
-      }
-    }
-  }
-  if (st != AGGMG_OK) return st;
-  sm->btd = b;
-  sm->A->btd = b;
-  return AGGMG_OK;
-}
-
 extern "C" int aggmg_blockjacobi_setup(aggmg_ctx* ctx, aggmg_op* A, int64_t m, int64_t nb,
                                        const int64_t* blockinds, int one_based, int kind,
                                        aggmg_smoother** out) {
   if (!ctx || !A || !out || !blockinds) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_blockjacobi_setup: NULL argument");
   *out = nullptr;
   if (A->m != A->n) return fail(ctx, AGGMG_ERR_DIMENSION, "aggmg_blockjacobi_setup: operator is not square");
-  if (!A->host_valid) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_blockjacobi_setup: host copy of the operator was released");
   if (m <= 0 || nb < 0 || m > 64) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_blockjacobi_setup: block size must be in 1..64");
   if (kind < 0 || kind > 2) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_blockjacobi_setup: unknown kind");
+  if (nb * m >= ((int64_t)1 << 31)) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_blockjacobi_setup: nb * m >= 2^31");
   HIPCHK(hipSetDevice(ctx->device));
-  const int64_t N = A->m;
-  const int64_t base = one_based ? 1 : 0;
   auto sm = std::make_unique<aggmg_smoother>();
   sm->kind = kind == 1 ? 2 : 1;  // (kind 2, block Gauss-Seidel, shares the block data of kind 0)
   sm->A = A;
-  sm->N = N;
+  sm->N = A->m;
   sm->m = m;
   sm->nb = nb;
-  std::vector<int32_t> inds((size_t)nb * m);
-  std::vector<double> counts(N, 0.0);
-  bool contiguous = (nb * m == N);
-  for (int64_t k = 0; k < nb; ++k)
-    for (int64_t i = 0; i < m; ++i) {
-      int64_t v = blockinds[k * m + i] - base;
-      if (v < 0 || v >= N) return fail(ctx, AGGMG_ERR_DIMENSION, "aggmg_blockjacobi_setup: block index out of range");
-      inds[k * m + i] = (int32_t)v;
-      counts[v] += 1.0;
-      if (v != k * m + i) contiguous = false;
-    }
-  bool overlapping = false;
-  for (int64_t i = 0; i < N; ++i)
-    if (counts[i] > 1.0) overlapping = true;
-  sm->overlapping = overlapping;
-  sm->contiguous = contiguous;
-
-  std::vector<double> binv((size_t)nb * m * m);
-  std::atomic<int64_t> singular{-1};
-  parallel_for(nb, [&](int64_t kb, int64_t ke) {
-    std::vector<double> blk((size_t)m * m), inv;
-    std::vector<int> piv;
-    for (int64_t k = kb; k < ke; ++k) {
-      for (int64_t i = 0; i < m; ++i)
-        for (int64_t j = 0; j < m; ++j) blk[i * m + j] = host_entry(A->host, inds[k * m + i], inds[k * m + j]);
-      if (!invert_block((int)m, blk, inv, piv)) {
-        int64_t expect = -1;
-        singular.compare_exchange_strong(expect, k);
-        return;
-      }
-      std::copy(inv.begin(), inv.end(), binv.begin() + k * m * m);
-    }
-  });
-  if (singular.load() >= 0)
-    return fail(ctx, AGGMG_ERR_SINGULAR,
-                "aggmg_blockjacobi_setup: singular block " + std::to_string(singular.load() + 1) + " (SingularException)");
-  CHECK(dev_upload(ctx, binv, &sm->binv));
-  CHECK(dev_upload(ctx, inds, &sm->inds));
-  if (sm->kind == 2) CHECK(dev_upload(ctx, counts, &sm->counts));
-  if (contiguous && !overlapping && sm->kind == 1) CHECK(build_btd(ctx, sm.get(), binv));
+  // index lists -> blocks A[inds, inds] -> pivoted LU -> inverses, and the fused block-tridiagonal form where
+  // the lists are contiguous and the operator fits (hybrid Schwarz never takes the fused form)
+  CHECK(setup_block_smoother(ctx, sm.get(), blockinds, one_based, sm->kind == 1));
   if (kind == 2) {
     // two colours order a sweep only when elements couple to their direct neighbours alone
-    if (!sm->btd) {  // reachable with ordinary input; sm's destructor releases what was uploaded
+    if (!sm->btd) {  // reachable with ordinary input; sm's destructor releases what was allocated
       return fail(ctx, AGGMG_ERR_UNSUPPORTED,
                   "aggmg_blockjacobi_setup: red-black block Gauss-Seidel needs contiguous blocks and a "
                   "block-tridiagonal operator");
@@ -617,22 +267,27 @@ extern "C" int aggmg_blockdiag_setup(aggmg_ctx* ctx, int64_t m, int64_t nb, cons
   sm->contiguous = true;
   std::vector<int32_t> inds((size_t)nb * m);
   for (int64_t i = 0; i < nb * m; ++i) inds[i] = (int32_t)i;
-  std::vector<double> mats((size_t)nb * m * m), blk((size_t)m * m), inv;
-  std::vector<int> piv;
-  for (int64_t k = 0; k < nb; ++k) {
-    for (int64_t i = 0; i < m; ++i)
-      for (int64_t j = 0; j < m; ++j) blk[i * m + j] = blocks[k * m * m + j * m + i];  // column- to row-major
-    if (factorize) {
-      if (!invert_block((int)m, blk, inv, piv))
-        return fail(ctx, AGGMG_ERR_SINGULAR,
-                    "aggmg_blockdiag_setup: singular block " + std::to_string(k + 1) + " (SingularException)");
-      std::copy(inv.begin(), inv.end(), mats.begin() + k * m * m);
-    } else {
-      std::copy(blk.begin(), blk.end(), mats.begin() + k * m * m);
-    }
-  }
-  CHECK(dev_upload(ctx, mats, &sm->binv));
   CHECK(dev_upload(ctx, inds, &sm->inds));
+  const size_t bytes = (size_t)std::max<int64_t>(nb * m * m, 1) * sizeof(double);
+  HIPCHK(hipMalloc((void**)&sm->binv, bytes));
+  if (factorize) {
+    double* raw = nullptr;  // the column-major blocks as given; inverted on the device (K6)
+    HIPCHK(hipMalloc((void**)&raw, bytes));
+    if (nb) HIPCHK(hipMemcpyAsync(raw, blocks, (size_t)nb * m * m * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    int64_t sing = -1;
+    const int st = setup_invert_blocks(ctx, nb, (int)m, raw, 1, sm->binv, &sing);
+    (void)hipFree(raw);
+    CHECK(st);
+    if (sing >= 0)
+      return fail(ctx, AGGMG_ERR_SINGULAR, "aggmg_blockdiag_setup: singular block " + std::to_string(sing + 1) + " (SingularException)");
+  } else {
+    std::vector<double> mats((size_t)nb * m * m);
+    for (int64_t k = 0; k < nb; ++k)
+      for (int64_t i = 0; i < m; ++i)
+        for (int64_t j = 0; j < m; ++j) mats[k * m * m + i * m + j] = blocks[k * m * m + j * m + i];  // column- to row-major
+    if (nb) HIPCHK(hipMemcpyAsync(sm->binv, mats.data(), mats.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+  }
   *out = sm.release();
   return AGGMG_OK;
 }
@@ -641,15 +296,12 @@ extern "C" int aggmg_jacobi_setup(aggmg_ctx* ctx, aggmg_op* A, aggmg_smoother** 
   if (!ctx || !A || !out) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_jacobi_setup: NULL argument");
   *out = nullptr;
   if (A->m != A->n) return fail(ctx, AGGMG_ERR_DIMENSION, "aggmg_jacobi_setup: operator is not square");
-  if (!A->host_valid) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_jacobi_setup: host copy of the operator was released");
   HIPCHK(hipSetDevice(ctx->device));
   auto sm = std::make_unique<aggmg_smoother>();
   sm->kind = 0;
   sm->A = A;
   sm->N = A->m;
-  std::vector<double> d(A->m);
-  for (int64_t i = 0; i < A->m; ++i) d[i] = host_entry(A->host, i, i);  // A[i,i], 0.0 when not stored
-  CHECK(dev_upload(ctx, d, &sm->diag));
+  CHECK(setup_jacobi_diag(ctx, A, &sm->diag));  // A[i,i], 0.0 when not stored
   *out = sm.release();
   return AGGMG_OK;
 }
@@ -886,6 +538,7 @@ static int generic_sweep(aggmg_ctx* ctx, aggmg_op* A, aggmg_smoother* sm, const 
   const int64_t N = A->m;
   if (sm->kind == 0) {
     ProfScope ps(ctx, AGGMG_KIND_JACOBI, level);
+    CHECK(op_ensure_csr(ctx, A));
     return launch_csr<kJacobi>(ctx, A->csr, u_in, rhs, sm->diag, alpha, u_out);
   }
   double *r = nullptr, *y = nullptr;
@@ -893,6 +546,7 @@ static int generic_sweep(aggmg_ctx* ctx, aggmg_op* A, aggmg_smoother* sm, const 
   CHECK(scratch(ctx, 2, N, &y));
   {
     ProfScope ps(ctx, AGGMG_KIND_RESIDUAL, level);
+    CHECK(op_ensure_csr(ctx, A));
     CHECK(launch_csr<kResidual>(ctx, A->csr, u_in, rhs, nullptr, 0.0, r));
   }
   ProfScope ps(ctx, AGGMG_KIND_BLOCK_APPLY, level);
@@ -991,20 +645,23 @@ extern "C" int aggmg_residual_dev(aggmg_ctx* ctx, aggmg_op* A, const double* u, 
     a.r_out = r_out;
     return launch_btd(ctx, *A->btd, a, 1);
   }
+  CHECK(op_ensure_csr(ctx, A));
   return launch_csr<kResidual>(ctx, A->csr, u, b, nullptr, 0.0, r_out);
 }
 
 extern "C" int aggmg_restrict_dev(aggmg_ctx* ctx, aggmg_op* L, const double* r, double* rc_out) {
   if (!ctx) return AGGMG_ERR_ARGUMENT;
   if (!L || !r || !rc_out) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_restrict: NULL argument");
-  if (!L->csrT.rowptr) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_restrict: operator was not uploaded as a transfer");
+  if (L->kind != AGGMG_OP_TRANSFER) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_restrict: operator was not uploaded as a transfer");
+  CHECK(op_ensure_csc_blocks(ctx, L));
   ProfScope ps(ctx, AGGMG_KIND_RESTRICT, 0);
-  return launch_csr<kSpmvSet>(ctx, L->csrT, r, nullptr, nullptr, 0.0, rc_out);
+  return launch_csr<kSpmvSet>(ctx, L->csc, r, nullptr, nullptr, 0.0, rc_out);
 }
 
 extern "C" int aggmg_prolong_add_dev(aggmg_ctx* ctx, aggmg_op* L, const double* uc, double* u_inout) {
   if (!ctx) return AGGMG_ERR_ARGUMENT;
   if (!L || !uc || !u_inout) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_prolong_add: NULL argument");
+  CHECK(op_ensure_csr(ctx, L));
   ProfScope ps(ctx, AGGMG_KIND_PROLONG, 0);
   return launch_csr<kSpmvAdd>(ctx, L->csr, uc, nullptr, nullptr, 0.0, u_inout);
 }
@@ -1202,309 +859,9 @@ static void banded_solve(const BandedLU& f, double* b) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// coarsest-level direct solve on the device: block cyclic reduction (factor once, solve per cycle)
+// coarsest-level direct solve on the device: block cyclic reduction (factored once on the device,
+// setup_cr in setup.hip; solved per cycle here)
 // ---------------------------------------------------------------------------------------------
-static double norm1(int m, const double* A) {
-  double best = 0.0;
-  for (int j = 0; j < m; ++j) {
-    double s = 0.0;
-    for (int i = 0; i < m; ++i) s += std::fabs(A[i * m + j]);
-    best = std::max(best, s);
-  }
-  return best;
-}
-
-// LU with partial pivoting of an m x m row-major block, stored as the factors of the
-// row-permuted matrix (perm[k] = original row that ends up in position k).  false if singular.
-static bool lu_perm(int m, const double* b, double* lu, int32_t* perm) {
-  std::copy(b, b + m * m, lu);
-  for (int k = 0; k < m; ++k) perm[k] = k;
-  for (int k = 0; k < m; ++k) {
-    int p = k;
-    double best = std::fabs(lu[k * m + k]);
-    for (int i = k + 1; i < m; ++i)
-      if (std::fabs(lu[i * m + k]) > best) {
-        best = std::fabs(lu[i * m + k]);
-        p = i;
-      }
-    if (lu[p * m + k] == 0.0) return false;
-    if (p != k) {
-      for (int j = 0; j < m; ++j) std::swap(lu[k * m + j], lu[p * m + j]);
-      std::swap(perm[k], perm[p]);
-    }
-    const double rp = 1.0 / lu[k * m + k];
-    for (int i = k + 1; i < m; ++i) lu[i * m + k] *= rp;
-    for (int i = k + 1; i < m; ++i) {
-      const double l = lu[i * m + k];
-      for (int j = k + 1; j < m; ++j) lu[i * m + j] -= l * lu[k * m + j];
-    }
-  }
-  return true;
-}
-
-// X = b \ R for an m x ncols row-major right-hand side (host mirror of cr_lu_solve)
-static void lu_perm_solve(int m, const double* lu, const int32_t* perm, const double* R, int ncols, double* X) {
-  std::vector<double> y(m);
-  for (int c = 0; c < ncols; ++c) {
-    for (int k = 0; k < m; ++k) y[k] = R[perm[k] * ncols + c];
-    for (int i = 1; i < m; ++i) {
-      double s = y[i];
-      for (int j = 0; j < i; ++j) s -= lu[i * m + j] * y[j];
-      y[i] = s;
-    }
-    for (int i = m - 1; i >= 0; --i) {
-      double s = y[i];
-      for (int j = i + 1; j < m; ++j) s -= lu[i * m + j] * y[j];
-      y[i] = s / lu[i * m + i];
-    }
-    for (int k = 0; k < m; ++k) X[k * ncols + c] = y[k];
-  }
-}
-
-static void free_cr(CrDev* c) {
-  for (void* p : c->owned)
-    if (p) (void)hipFree(p);
-  *c = CrDev();  // (clears `owned`: the hierarchy's destructor will not free these again)
-}
-
-// Returns AGGMG_OK and sets cr->valid when the operator is block-tridiagonal for some block size
-// m <= 8 and every pivot block is comfortably invertible; leaves cr->valid == false otherwise
-// (the caller then keeps the host banded solver).
-static int cr_setup(aggmg_ctx* ctx, const HostCsr& h, int64_t N, int hint_m, CrDev* cr) {
-  cr->valid = false;
-  if (N == 0) return AGGMG_OK;
-  int kl = 0, ku = 0;
-  for (int64_t i = 0; i < N; ++i)
-    for (int32_t p = h.rowptr[i]; p < h.rowptr[i + 1]; ++p) {
-      kl = std::max<int64_t>(kl, i - h.colind[p]);
-      ku = std::max<int64_t>(ku, h.colind[p] - i);
-    }
-  int m = 0;
-  auto fits = [&](int mm_) {
-    for (int64_t i = 0; i < N; ++i) {
-      const int64_t e = i / mm_;
-      for (int32_t p = h.rowptr[i]; p < h.rowptr[i + 1]; ++p) {
-        const int64_t ce = h.colind[p] / mm_;
-        if (ce < e - 1 || ce > e + 1) return false;
-      }
-    }
-    return true;
-  };
-  if (hint_m >= 1 && hint_m <= 8 && fits(hint_m)) m = hint_m;
-  // otherwise the smallest block size for which the operator is block-tridiagonal (bandwidth <= m
-  // always works), so that a coarsest operator is eliminated in the same order however it arrives
-  for (int cand = 1; !m && cand <= 8; ++cand)
-    if (std::max(kl, ku) <= 2 * cand - 1 && fits(cand)) m = cand;
-  if (!m) return AGGMG_OK;
-  const int mm2 = m * m;
-  int64_t n = (N + m - 1) / m;
-  std::vector<double> a((size_t)n * mm2, 0.0), b((size_t)n * mm2, 0.0), c((size_t)n * mm2, 0.0);
-  for (int64_t i = 0; i < N; ++i) {
-    const int64_t e = i / m;
-    const int li = (int)(i - e * m);
-    for (int32_t p = h.rowptr[i]; p < h.rowptr[i + 1]; ++p) {
-      const int64_t cj = h.colind[p];
-      const int64_t ce = cj / m;
-      const int lj = (int)(cj - ce * m);
-      double* dst = ce == e ? b.data() : (ce == e - 1 ? a.data() : c.data());
-      dst[e * mm2 + li * m + lj] = h.vals[p];
-    }
-  }
-  for (int64_t i = N; i < n * m; ++i) b[(i / m) * mm2 + (i % m) * m + (i % m)] = 1.0;  // identity padding
-  cr->m = m;
-  cr->n0 = n;
-  cr->N = N;
-  std::vector<double> blk(mm2), inv, za(mm2), zc(mm2);
-  std::vector<int> piv;
-  double cond = 0.0;
-  auto upd = [&](const std::vector<double>& v, const double** out) -> int {
-    double* d = nullptr;
-    CHECK(dev_upload(ctx, v, &d));
-    cr->owned.push_back(d);
-    *out = d;
-    return AGGMG_OK;
-  };
-  auto upi = [&](const std::vector<int32_t>& v, const int32_t** out) -> int {
-    int32_t* d = nullptr;
-    CHECK(dev_upload(ctx, v, &d));
-    cr->owned.push_back(d);
-    *out = d;
-    return AGGMG_OK;
-  };
-  auto pivot_cond = [&](const double* bb) -> bool {  // monitor only
-    std::copy(bb, bb + mm2, blk.begin());
-    const double nb = norm1(m, blk.data());
-    if (!invert_block(m, blk, inv, piv)) return false;
-    cond = std::max(cond, nb * norm1(m, inv.data()));
-    return true;
-  };
-  while (n > 1) {
-    const int64_t ne = (n + 1) / 2, no = n / 2;
-    std::vector<double> lu((size_t)no * mm2);
-    std::vector<int32_t> perm((size_t)no * m);
-    std::vector<double> Za((size_t)no * mm2), Zc((size_t)no * mm2);  // b_odd \ a_odd, b_odd \ c_odd
-    std::vector<double> a2((size_t)ne * mm2, 0.0), b2((size_t)ne * mm2, 0.0), c2((size_t)ne * mm2, 0.0);
-    std::atomic<int> bad{0};
-    std::vector<double> conds((size_t)setup_threads() + 1, 0.0);
-    std::atomic<int> slot{0};
-    parallel_for(no, [&](int64_t jb, int64_t je) {
-      std::vector<double> tb(mm2), tinv;
-      std::vector<int> tp;
-      double lc = 0.0;
-      for (int64_t j = jb; j < je; ++j) {
-        const int64_t i = 2 * j + 1;
-        std::copy(&b[i * mm2], &b[i * mm2] + mm2, tb.begin());  // condition monitor (explicit inverse)
-        const double nb1 = norm1(m, tb.data());
-        if (!invert_block(m, tb, tinv, tp) || !lu_perm(m, &b[i * mm2], &lu[j * mm2], &perm[j * m])) {
-          bad.store(1);
-          return;
-        }
-        lc = std::max(lc, nb1 * norm1(m, tinv.data()));
-        lu_perm_solve(m, &lu[j * mm2], &perm[j * m], &a[i * mm2], m, &Za[j * mm2]);
-        lu_perm_solve(m, &lu[j * mm2], &perm[j * m], &c[i * mm2], m, &Zc[j * mm2]);
-      }
-      conds[slot.fetch_add(1) % conds.size()] = lc;  // one slot per worker chunk
-    });
-    if (bad.load()) {
-      free_cr(cr);
-      return AGGMG_OK;
-    }
-    for (double v : conds) cond = std::max(cond, v);
-    parallel_for(ne, [&](int64_t jb, int64_t je) {
-      for (int64_t j = jb; j < je; ++j) {
-        const int64_t i = 2 * j;
-        double* B2 = &b2[j * mm2];
-        std::copy(b.begin() + i * mm2, b.begin() + (i + 1) * mm2, B2);
-        if (j > 0) {  // eliminate x_{i-1}: -a_i (b_{i-1} \ [a_{i-1} | c_{i-1}])
-          const double* A = &a[i * mm2];
-          const double* ZA = &Za[(j - 1) * mm2];
-          const double* ZC = &Zc[(j - 1) * mm2];
-          for (int r = 0; r < m; ++r)
-            for (int q = 0; q < m; ++q) {
-              double s1 = 0.0, s2 = 0.0;
-              for (int k = 0; k < m; ++k) {
-                s1 += A[r * m + k] * ZA[k * m + q];
-                s2 += A[r * m + k] * ZC[k * m + q];
-              }
-              a2[j * mm2 + r * m + q] = -s1;
-              B2[r * m + q] -= s2;
-            }
-        }
-        if (i + 1 < n) {  // eliminate x_{i+1}: -c_i (b_{i+1} \ [a_{i+1} | c_{i+1}])
-          const double* C = &c[i * mm2];
-          const double* ZA = &Za[j * mm2];
-          const double* ZC = &Zc[j * mm2];
-          for (int r = 0; r < m; ++r)
-            for (int q = 0; q < m; ++q) {
-              double s1 = 0.0, s2 = 0.0;
-              for (int k = 0; k < m; ++k) {
-                s1 += C[r * m + k] * ZA[k * m + q];
-                s2 += C[r * m + k] * ZC[k * m + q];
-              }
-              B2[r * m + q] -= s1;
-              c2[j * mm2 + r * m + q] = -s2;
-            }
-        }
-      }
-    });
-    CrLevel L;
-    L.n = n;
-    L.n_even = ne;
-    L.n_odd = no;
-    int st = upd(a, &L.a);
-    if (st == AGGMG_OK) st = upd(c, &L.c);
-    if (st == AGGMG_OK) st = upd(lu, &L.lu);
-    if (st == AGGMG_OK) st = upi(perm, &L.perm);
-    if (st != AGGMG_OK) {
-      free_cr(cr);
-      return st;
-    }
-    cr->lv.push_back(L);
-    a.swap(a2);
-    b.swap(b2);
-    c.swap(c2);
-    n = ne;
-    if ((int)cr->lv.size() > kCrMaxLevels) {
-      free_cr(cr);
-      return AGGMG_OK;
-    }
-  }
-  {
-    std::vector<double> lu(mm2);
-    std::vector<int32_t> perm(m);
-    if (!pivot_cond(&b[0]) || !lu_perm(m, &b[0], lu.data(), perm.data())) {
-      free_cr(cr);
-      return AGGMG_OK;
-    }
-    const double* p = nullptr;
-    const int32_t* q = nullptr;
-    int st = upd(lu, &p);
-    if (st == AGGMG_OK) st = upi(perm, &q);
-    if (st != AGGMG_OK) {
-      free_cr(cr);
-      return st;
-    }
-    cr->lu_last = p;
-    cr->perm_last = q;
-  }
-  cr->cond_est = cond;
-  if (!(cond < 1e13)) {  // a pivot block is close to singular: elimination without pivoting across
-    free_cr(cr);         // blocks is not trustworthy here, keep the pivoted banded LU
-    return AGGMG_OK;
-  }
-  // plan: [g per-level launches, only if a chunk would not fit in LDS] -> q chunk levels (one
-  // forward and one backward launch, every workgroup reducing 2^q + 1 blocks in LDS) -> the tail
-  // (all remaining levels, <= kCrTailRows rows, one workgroup)
-  const int nl = (int)cr->lv.size();
-  auto level_n = [&](int l) -> int64_t { return l < nl ? cr->lv[l].n : 1; };
-  int g = 0, q = 0;
-  for (;; ++g) {
-    q = 0;
-    while (g + q < nl && level_n(g + q) * m > kCrTailRows) ++q;
-    const size_t lds = ((size_t)(2 << q) + q + 2) * m * sizeof(double);
-    if (q <= kCrMaxChunkLevels && lds <= 48 * 1024) break;
-    if (g >= nl) break;
-  }
-  if (nl - (g + q) > 16) {
-    free_cr(cr);
-    return AGGMG_OK;
-  }
-  cr->nglobal = g;
-  cr->q = q;
-  {
-    size_t o = 0;
-    for (int l = 0; l <= q; ++l) o += ((size_t)(1 << (q - l)) + 1) * m;
-    cr->chunk_lds = o * sizeof(double);
-  }
-  int64_t rows = 0;
-  for (int l = g + q; l < nl; ++l) rows += cr->lv[l].n * m;
-  cr->tail_lds = (size_t)(rows + m) * sizeof(double);
-  auto dalloc = [&](int64_t len, double** out) -> int {
-    HIPCHK(hipMalloc((void**)out, (size_t)std::max<int64_t>(len, 1) * sizeof(double)));
-    HIPCHK(hipMemsetAsync(*out, 0, (size_t)std::max<int64_t>(len, 1) * sizeof(double), ctx->stream));
-    cr->owned.push_back(*out);
-    return AGGMG_OK;
-  };
-  for (int l = 0; l <= g; ++l) {
-    double *dd = nullptr, *xx = nullptr;
-    CHECK(dalloc(level_n(l) * m, &dd));
-    CHECK(dalloc(level_n(l) * m, &xx));
-    cr->d.push_back(dd);
-    cr->x.push_back(xx);
-  }
-  if (q > 0) {
-    const int64_t nq = level_n(g + q) * m;
-    CHECK(dalloc(nq, &cr->partR));
-    CHECK(dalloc(nq, &cr->partL));  // partL[0] is never written: stays zero
-    CHECK(dalloc(nq, &cr->xq));
-    cr->stack_stride = (int)(cr->chunk_lds / sizeof(double));
-    CHECK(dalloc((level_n(g + q) + 1) * (int64_t)cr->stack_stride, &cr->stack));
-  }
-  HIPCHK(hipStreamSynchronize(ctx->stream));
-  cr->valid = true;
-  return AGGMG_OK;
-}
-
 template <int M>
 static int cr_solve_t(aggmg_ctx* ctx, CrDev& cr, const double* rhs, double* out) {
   const int nl = (int)cr.lv.size();
@@ -1634,64 +991,6 @@ static int cr_solve(aggmg_ctx* ctx, CrDev& cr, const double* rhs, double* out, i
 // ---------------------------------------------------------------------------------------------
 // hierarchy + V-cycle
 // ---------------------------------------------------------------------------------------------
-// structured transfer: every fine row's stored columns lie in the mc modes of coarse element
-// J = (fine element) / rho
-static int build_transfer(aggmg_ctx* ctx, const aggmg_op* L, const aggmg_op* A, int mf, int64_t nef, int hint_mc,
-                          TransferBtd* out, bool* ok) {
-  *ok = false;
-  if (!L->host_valid) return AGGMG_OK;
-  const HostCsr& h = L->host;
-  const int64_t Nf = L->m, Nc = L->n;
-  if (Nf != nef * mf) return AGGMG_OK;
-  for (int mc = 1; mc <= 16; ++mc) {
-    if (hint_mc > 0 && mc != hint_mc) continue;
-    if (Nc % mc) continue;
-    const int64_t nec = Nc / mc;
-    if (nec == 0 || nef % nec) continue;
-    const int64_t rho = nef / nec;
-    if (rho > 64) continue;
-    bool fits = true;
-    for (int64_t r = 0; r < Nf && fits; ++r) {
-      const int64_t J = (r / mf) / rho;
-      for (int32_t p = h.rowptr[r]; p < h.rowptr[r + 1]; ++p)
-        if (h.colind[p] < J * mc || h.colind[p] >= (J + 1) * mc) {
-          fits = false;
-          break;
-        }
-    }
-    if (!fits) continue;
-    std::vector<double> lf((size_t)Nf * mc, 0.0);
-    for (int64_t r = 0; r < Nf; ++r) {
-      const int64_t J = (r / mf) / rho;
-      for (int32_t p = h.rowptr[r]; p < h.rowptr[r + 1]; ++p) lf[r * mc + (h.colind[p] - J * mc)] = h.vals[p];
-    }
-    CHECK(dev_upload(ctx, lf, &out->lf));
-    if (A && A->host_valid) {
-      // ld[(e,j)][c] = sum_i L[(e,i)][c] * D_e[i][j]  so that  L' r = sum_rows ld * (B^{-1} r)
-      std::vector<double> ld((size_t)Nf * mc, 0.0);
-      parallel_for(nef, [&](int64_t eb, int64_t ee) {
-        std::vector<double> D((size_t)mf * mf);
-        for (int64_t e = eb; e < ee; ++e) {
-          for (int i = 0; i < mf; ++i)
-            for (int j = 0; j < mf; ++j) D[i * mf + j] = host_entry(A->host, e * mf + i, e * mf + j);
-          for (int j = 0; j < mf; ++j)
-            for (int c = 0; c < mc; ++c) {
-              double acc = 0.0;
-              for (int i = 0; i < mf; ++i) acc += lf[(e * mf + i) * mc + c] * D[i * mf + j];
-              ld[(e * mf + j) * mc + c] = acc;
-            }
-        }
-      });
-      CHECK(dev_upload(ctx, ld, &out->ld));
-    }
-    out->mc = mc;
-    out->rho = (int)rho;
-    *ok = true;
-    return AGGMG_OK;
-  }
-  return AGGMG_OK;
-}
-
 extern "C" int aggmg_hier_free(aggmg_ctx* ctx, aggmg_hier* h) {
   if (!ctx) return AGGMG_ERR_ARGUMENT;
   if (!h) return AGGMG_OK;
@@ -1731,7 +1030,7 @@ extern "C" int aggmg_hier_create(aggmg_ctx* ctx, int nlevels, aggmg_op* const* s
       if (l.S->N != l.N) return fail(ctx, AGGMG_ERR_DIMENSION, "aggmg_hier_create: smoother size mismatch at level " + std::to_string(k + 1));
       if (l.L->m != l.N || l.L->n != stiffness[k + 1]->m)
         return fail(ctx, AGGMG_ERR_DIMENSION, "aggmg_hier_create: interpolation size mismatch at level " + std::to_string(k + 1));
-      if (!l.L->csrT.rowptr) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_hier_create: interpolation must be uploaded with AGGMG_OP_TRANSFER");
+      if (l.L->kind != AGGMG_OP_TRANSFER) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_hier_create: interpolation must be uploaded with AGGMG_OP_TRANSFER");
       if (l.S->cgt && l.S->A == l.A) l.Nalloc = std::max(l.N, l.S->cgt->ne * l.S->cgt->m);  // block order incl. padding
     }
     for (double** p : {&l.u[0], &l.u[1], &l.rhs, &l.tmp}) {
@@ -1747,7 +1046,8 @@ extern "C" int aggmg_hier_create(aggmg_ctx* ctx, int nlevels, aggmg_op* const* s
     if (k + 2 < nlevels && h->lv[k + 1].S && h->lv[k + 1].S->btd) hint = h->lv[k + 1].S->btd->m;
     auto tb = std::make_unique<TransferBtd>();
     bool ok = false;
-    CHECK(build_transfer(ctx, l.L, l.A, l.S->btd->m, l.S->btd->ne, hint, tb.get(), &ok));
+    // every fine row's stored columns must lie in the mc modes of coarse element (fine element) / rho
+    CHECK(setup_transfer_btd(ctx, l.L, l.S->btd.get(), l.S->btd->m, l.S->btd->ne, hint, tb.get(), &ok));
     if (ok) l.tb = std::move(tb);
   }
   // CG chain levels: structured transfer to the next level; a level is fused when it has both
@@ -1771,19 +1071,20 @@ extern "C" int aggmg_hier_create(aggmg_ctx* ctx, int nlevels, aggmg_op* const* s
     if (h->lv[k].cgt_fused && h->lv[k].tc->type == kTrChain && h->lv[k + 1].cgt_fused) h->lv[k + 1].native_io = true;
   // coarsest level: factor once (unless the caller solves it elsewhere)
   if (coarse_mode != AGGMG_COARSE_EXTERNAL) {
-    const aggmg_op* Ac = h->lv[nlevels - 1].A;
-    if (!Ac->host_valid) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_hier_create: host copy of the coarsest operator was released");
+    aggmg_op* Ac = h->lv[nlevels - 1].A;
     if (coarse_mode != AGGMG_COARSE_HOST_BANDED) {
       int hint = 0;
       if (nlevels >= 2 && h->lv[nlevels - 2].tb) hint = h->lv[nlevels - 2].tb->mc;
-      CHECK(cr_setup(ctx, Ac->host, Ac->m, hint, &h->cr));
+      CHECK(setup_cr(ctx, Ac, hint, &h->cr));
       if (!h->cr.valid && coarse_mode == AGGMG_COARSE_DEVICE_CR)
         return fail(ctx, AGGMG_ERR_UNSUPPORTED,
                     "aggmg_hier_create: coarsest operator is not block-tridiagonal with well-conditioned pivot "
                     "blocks; device cyclic reduction not applicable");
     }
-    if (!h->cr.valid) {
-      CHECK(banded_factor(ctx, Ac->host, Ac->m, &h->coarse));
+    if (!h->cr.valid) {  // host banded LU with partial pivoting: the one set-up path that reads the operator back
+      HostCsr hc;
+      CHECK(op_host_csr(ctx, Ac, &hc));
+      CHECK(banded_factor(ctx, hc, Ac->m, &h->coarse));
       h->h_coarse.assign(Ac->m, 0.0);
     }
   }
@@ -1865,10 +1166,12 @@ static int vcycle_down(aggmg_ctx* ctx, aggmg_hier* h, const double* x0, const do
       }
       {
         ProfScope ps(ctx, AGGMG_KIND_RESIDUAL, k);
+        CHECK(op_ensure_csr(ctx, l.A));
         CHECK(launch_csr<kResidual>(ctx, l.A->csr, l.u[0], rhs, nullptr, 0.0, l.tmp));
       }
       ProfScope ps(ctx, AGGMG_KIND_RESTRICT, k);
-      CHECK(launch_csr<kSpmvSet>(ctx, l.L->csrT, l.tmp, nullptr, nullptr, 0.0, c.rhs));
+      CHECK(op_ensure_csc_blocks(ctx, l.L));
+      CHECK(launch_csr<kSpmvSet>(ctx, l.L->csc, l.tmp, nullptr, nullptr, 0.0, c.rhs));
     }
   }
   return AGGMG_OK;
@@ -1912,6 +1215,7 @@ static int vcycle_up(aggmg_ctx* ctx, aggmg_hier* h, const double* b, int nPost, 
         return fail(ctx, AGGMG_ERR_UNSUPPORTED, "split ascent needs the fused block-tridiagonal fine level");
       {
         ProfScope ps(ctx, AGGMG_KIND_PROLONG, k);
+        CHECK(op_ensure_csr(ctx, l.L));
         CHECK(launch_csr<kSpmvAdd>(ctx, l.L->csr, uc, nullptr, nullptr, 0.0, l.u[0]));
       }
       if (structured) {

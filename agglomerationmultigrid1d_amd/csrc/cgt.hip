@@ -21,7 +21,7 @@ struct CgtTile {
   static constexpr int TE = EPS * NS;
 };
 
-static int cgt_tile_blocks(int m) {
+int cgt_tile_blocks(int m) {
   switch (m) {
     case 1: return CgtTile<1>::TE;
     case 2: return CgtTile<2>::TE;
@@ -95,223 +95,7 @@ static CgtXfer cgt_xfer(const TransferCgt& t, bool coarse_native) {
   return x;
 }
 
-// ---------------------------------------------------------------------------------------------
-// set-up: element chain -> permutation -> packed operator
-// ---------------------------------------------------------------------------------------------
-int cgt_build(aggmg_ctx* ctx, aggmg_smoother* sm, const int64_t* elems, int64_t m1, int64_t nel, int one_based) {
-  aggmg_op* A = sm->A;
-  const int64_t N = A->m;
-  const int64_t p = m1 - 1;
-  if (p < 1 || p > 8 || nel < 1) return AGGMG_OK;  // generic path
-  if (N != nel * p + 1) return AGGMG_OK;
-  const int64_t base = one_based ? 1 : 0;
-  const int m = (int)p;
-  const int64_t ne = nel + 1, Np = ne * m;
-  if (Np >= ((int64_t)1 << 31)) return AGGMG_OK;
-  auto el = [&](int64_t e, int j) -> int64_t { return elems[e * m1 + j] - base; };
-  auto g = std::make_shared<CgtDev>();
-  g->m = m;
-  g->ne = ne;
-  g->N = N;
-  g->h_perm.assign(Np, -1);
-  g->h_inv.assign(N, -1);
-  // block e = [first node of element e, its nodes 3..p+1]; node 2 must open the next element
-  for (int64_t e = 0; e < nel; ++e) {
-    for (int j = 0; j <= m; ++j) {
-      const int64_t v = el(e, j);
-      if (v < 0 || v >= N) return fail(ctx, AGGMG_ERR_DIMENSION, "aggmg_jacobi_setup_elements: node index out of range");
-    }
-    if (e + 1 < nel && el(e, 1) != el(e + 1, 0)) return AGGMG_OK;  // not a chain: generic path
-    g->h_perm[e * m] = (int32_t)el(e, 0);
-    for (int j = 1; j < m; ++j) g->h_perm[e * m + j] = (int32_t)el(e, j + 1);
-  }
-  g->h_perm[nel * m] = (int32_t)el(nel - 1, 1);
-  for (int64_t q = 0; q < Np; ++q) {
-    const int32_t o = g->h_perm[q];
-    if (o < 0) continue;
-    if (g->h_inv[o] >= 0) return AGGMG_OK;  // a node listed twice: not a chain
-    g->h_inv[o] = (int32_t)q;
-  }
-  for (int64_t o = 0; o < N; ++o)
-    if (g->h_inv[o] < 0) return AGGMG_OK;
-  // pack: every stored entry must fall into the diagonal block, the sub-diagonal row or the
-  // super-diagonal column of its block row
-  const HostCsr& h = A->host;
-  std::vector<double> dblk((size_t)Np * m, 0.0), subrow((size_t)Np, 0.0), supcol((size_t)Np, 0.0);
-  std::atomic<int> bad{0};
-  const std::vector<int32_t>& inv = g->h_inv;
-  parallel_for(N, [&](int64_t rb, int64_t re) {
-    for (int64_t r = rb; r < re && !bad.load(std::memory_order_relaxed); ++r) {
-      const int64_t q = inv[r];
-      const int64_t e = q / m;
-      const int i = (int)(q - e * m);
-      for (int32_t pp = h.rowptr[r]; pp < h.rowptr[r + 1]; ++pp) {
-        const int64_t qc = inv[h.colind[pp]];
-        const int64_t ce = qc / m;
-        const int cj = (int)(qc - ce * m);
-        const double v = h.vals[pp];
-        if (ce == e) {
-          dblk[q * m + cj] = v;
-        } else if (ce == e - 1 && i == 0) {
-          subrow[e * m + cj] = v;
-        } else if (ce == e + 1 && cj == 0) {
-          supcol[q] = v;
-        } else if (v != 0.0) {
-          bad.store(1);
-          break;
-        }
-      }
-    }
-  });
-  if (bad.load()) return AGGMG_OK;  // couplings beyond the chain pattern: generic path
-  for (int64_t q = 0; q < Np; ++q)
-    if (g->h_perm[q] < 0) dblk[q * m + (q % m)] = 1.0;  // padding rows: identity
-  CHECK(dev_upload(ctx, dblk, &g->dblk));
-  CHECK(dev_upload(ctx, subrow, &g->subrow));
-  CHECK(dev_upload(ctx, supcol, &g->supcol));
-  CHECK(dev_upload(ctx, g->h_perm, &g->perm));
-  sm->cgt = g;
-  A->cgt = g;
-  return AGGMG_OK;
-}
-
-// ---------------------------------------------------------------------------------------------
-// set-up: structured transfers of a chain level
-// ---------------------------------------------------------------------------------------------
-int cgt_build_transfer(aggmg_ctx* ctx, const aggmg_op* L, const CgtDev& f, const CgtDev* coarse, int hint_mc,
-                       TransferCgt* out, bool* ok) {
-  *ok = false;
-  if (!L->host_valid) return AGGMG_OK;
-  const HostCsr& h = L->host;
-  const int64_t Nf = L->m, Nc = L->n;
-  if (Nf != f.N) return AGGMG_OK;
-  const int M = f.m;
-  const int64_t nel = f.ne - 1, Np = f.ne * M;
-  const int tile = cgt_tile_blocks(M);
-
-  // ---- chain: the coarse level is a CG level on the same elements ------------------------------
-  if (nel > 0 && Nc > 1 && (Nc - 1) % nel == 0 && (Nc - 1) / nel <= 8 && M >= 2) {
-    const int mc = (int)((Nc - 1) / nel);
-    std::vector<int32_t> cperm, cinv;
-    bool have = false;
-    if (coarse && coarse->N == Nc && coarse->m == mc && coarse->ne == f.ne) {
-      cperm = coarse->h_perm;
-      cinv = coarse->h_inv;
-      have = true;
-    } else if (!coarse) {
-      // the coarse level carries no element lists (the coarsest level has no smoother): read its
-      // chain off L -- a fine vertex row has ONE entry (its coarse vertex), the first interior row of
-      // element e lists every coarse node of element e
-      cperm.assign((size_t)f.ne * mc, -1);
-      cinv.assign(Nc, -1);
-      have = true;
-      for (int64_t e = 0; e <= nel && have; ++e) {
-        const int64_t r = f.h_perm[e * M];
-        if (h.rowptr[r + 1] - h.rowptr[r] != 1) have = false;
-        else cperm[e * mc] = h.colind[h.rowptr[r]];
-      }
-      for (int64_t e = 0; e < nel && have && mc > 1; ++e) {
-        const int64_t r = f.h_perm[e * M + 1];
-        int j = 1;
-        for (int32_t pp = h.rowptr[r]; pp < h.rowptr[r + 1]; ++pp) {
-          const int32_t c = h.colind[pp];
-          if (c == cperm[e * mc] || c == cperm[(e + 1) * mc]) continue;
-          if (j >= mc) {
-            have = false;
-            break;
-          }
-          cperm[e * mc + j++] = c;
-        }
-        if (j != mc) have = false;
-      }
-      for (int64_t q = 0; q < (int64_t)cperm.size() && have; ++q) {
-        const int32_t o = cperm[q];
-        if (o < 0) continue;
-        if (o >= Nc || cinv[o] >= 0) have = false;
-        else cinv[o] = (int32_t)q;
-      }
-      for (int64_t o = 0; o < Nc && have; ++o)
-        if (cinv[o] < 0) have = false;
-    }
-    if (have) {
-      const int w = mc + 1;
-      std::vector<double> l((size_t)Np * w, 0.0);
-      std::atomic<int> bad{0};
-      parallel_for(Nf, [&](int64_t rb, int64_t re) {
-        for (int64_t r = rb; r < re && !bad.load(std::memory_order_relaxed); ++r) {
-          const int64_t q = f.h_inv[r];
-          const int64_t e = q / M;
-          for (int32_t pp = h.rowptr[r]; pp < h.rowptr[r + 1]; ++pp) {
-            const int64_t qc = cinv[h.colind[pp]];
-            const int64_t ce = qc / mc;
-            const int cj = (int)(qc - ce * mc);
-            if (ce == e)
-              l[q * w + cj] = h.vals[pp];
-            else if (ce == e + 1 && cj == 0)
-              l[q * w + mc] = h.vals[pp];
-            else if (h.vals[pp] != 0.0) {
-              bad.store(1);
-              break;
-            }
-          }
-        }
-      });
-      if (!bad.load()) {
-        CHECK(dev_upload(ctx, l, &out->l));
-        CHECK(dev_upload(ctx, cperm, &out->cperm));
-        out->type = kTrChain;
-        out->mc = mc;
-        out->rho = 1;
-        out->nec = f.ne;
-        *ok = true;
-        return AGGMG_OK;
-      }
-    }
-  }
-
-  // ---- agglomerating: the coarse level has contiguous blocks of mc DoFs per rho fine elements ---
-  for (int mc = 1; mc <= 16; ++mc) {
-    if (hint_mc > 0 && mc != hint_mc) continue;
-    if (Nc % mc) continue;
-    const int64_t nec = Nc / mc;
-    if (nec == 0 || nel % nec) continue;
-    const int64_t rho = nel / nec;
-    if (rho > 64 || rho * 4 > tile) continue;
-    std::vector<double> l((size_t)Np * mc, 0.0), lp((size_t)f.ne * mc, 0.0);
-    std::atomic<int> bad{0};
-    parallel_for(Nf, [&](int64_t rb, int64_t re) {
-      for (int64_t r = rb; r < re && !bad.load(std::memory_order_relaxed); ++r) {
-        const int64_t q = f.h_inv[r];
-        const int64_t e = q / M;
-        const int i = (int)(q - e * M);
-        const int64_t J = e / rho;
-        for (int32_t pp = h.rowptr[r]; pp < h.rowptr[r + 1]; ++pp) {
-          const int64_t c = h.colind[pp];
-          const int64_t Jc = c / mc;
-          const int cj = (int)(c - Jc * mc);
-          if (Jc == J)
-            l[q * mc + cj] = h.vals[pp];
-          else if (i == 0 && Jc == J - 1 && e == J * rho)
-            lp[e * mc + cj] = h.vals[pp];
-          else if (h.vals[pp] != 0.0) {
-            bad.store(1);
-            break;
-          }
-        }
-      }
-    });
-    if (bad.load()) continue;
-    CHECK(dev_upload(ctx, l, &out->l));
-    CHECK(dev_upload(ctx, lp, &out->lp));
-    out->type = kTrAgg;
-    out->mc = mc;
-    out->rho = (int)rho;
-    out->nec = nec;
-    *ok = true;
-    return AGGMG_OK;
-  }
-  return AGGMG_OK;
-}
+// (set-up of the chain form and of its transfers: setup.hip, on the device)
 
 // ---------------------------------------------------------------------------------------------
 // launches

@@ -1,0 +1,533 @@
+// Element-partitioned V-cycle inside the library (BASELINE config 4): one rank's share
+// of multigrid_v_cycle (src/solvers.jl:19-50) on its local hierarchy (owned elements + ghost layers),
+// with the interface exchanges issued from C++ on the context's stream -- no host language in the
+// per-cycle path.  The reference is single-process; there is nothing to mirror here but the cycle.
+//
+// Schedule (the one agglomerationmultigrid1d_amd/distributed.py documents and the gloo tests pin
+// bitwise against the single-GPU cycle): ghost layers deep enough that one V(nPre, nPost) cycle needs
+//   1. an all-gather of the interface elements of x0 (W_0 elements per side and rank),
+//   2. the coarsest solve across ranks: every rank eliminates the chunks of its own block range of
+//      the cyclic reduction, the ranks all-gather their slices of the chunk-boundary system, each
+//      solves it and back-substitutes its own chunks, then the coarse ghost blocks are all-gathered
+//      (small coarsest levels: all-gather of the owned right-hand side + replicated solve),
+// and nothing else: block-Jacobi sweeps are recomputed in the ghost layers.
+// Collectives: RCCL (ncclAllGather, loaded with dlopen so that libaggmg_hip.so carries no link-time
+// dependency on it and shares the copy torch has already loaded), or a caller-supplied function
+// (tests drive the same C++ schedule over gloo), or a device-local loop-back (rehearsals).
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include "internal.hpp"
+
+namespace {
+
+struct RcclApi {
+  void* lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+RcclApi* rccl_api(std::string* err) {
+  static RcclApi api;
+  static bool tried = false;
+  static std::string why;
+  if (!tried) {
+    tried = true;
+    // the copy already in the process (torch's) if there is one, the ROCm one otherwise
+    for (const char* name : {"librccl.so.1", "librccl.so"}) {
+      api.lib = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
+      if (!api.lib) api.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (api.lib) break;
+    }
+    if (!api.lib) {
+      why = std::string("RCCL not loadable: ") + (dlerror() ? dlerror() : "librccl.so.1 not found");
+    } else {
+      auto sym = [&](const char* n) -> void* {
+        void* p = dlsym(api.lib, n);
+        if (!p && why.empty()) why = std::string("RCCL symbol missing: ") + n;
+        return p;
+      };
+      api.GetUniqueId = (decltype(api.GetUniqueId))sym("ncclGetUniqueId");
+      api.CommInitRank = (decltype(api.CommInitRank))sym("ncclCommInitRank");
+      api.CommDestroy = (decltype(api.CommDestroy))sym("ncclCommDestroy");
+      api.CommCount = (decltype(api.CommCount))sym("ncclCommCount");
+      api.AllGather = (decltype(api.AllGather))sym("ncclAllGather");
+      api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
+    }
+  }
+  if (!why.empty()) {
+    if (err) *err = why;
+    return nullptr;
+  }
+  return &api;
+}
+
+// out[r * count + i] = in[i] for every rank slot r (loop-back "all-gather" of rehearsals)
+__global__ __launch_bounds__(kThreads) void loopback_kernel(const double* __restrict__ in, double* __restrict__ out,
+                                                            int64_t count, int world) {
+  const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (i >= count) return;
+  const double v = in[i];
+  for (int r = 0; r < world; ++r) out[(int64_t)r * count + i] = v;
+}
+
+}  // namespace
+
+struct DevBuf {
+  double* p = nullptr;
+  int64_t n = 0;
+  ~DevBuf() {
+    if (p) (void)hipFree(p);
+  }
+  int alloc(aggmg_ctx* ctx, int64_t len) {
+    n = len;
+    HIPCHK(hipMalloc((void**)&p, (size_t)std::max<int64_t>(len, 1) * sizeof(double)));
+    HIPCHK(hipMemsetAsync(p, 0, (size_t)std::max<int64_t>(len, 1) * sizeof(double), ctx->stream));
+    return AGGMG_OK;
+  }
+};
+
+struct aggmg_dist {
+  aggmg_hier* H = nullptr;   // local hierarchy, AGGMG_COARSE_EXTERNAL
+  aggmg_hier* Hc = nullptr;  // one-level hierarchy of the GLOBAL coarsest operator (replicated)
+  int world = 1, rank = 0, nl = 0;
+  std::vector<int64_t> own_lo, own_hi, loc_lo, loc_hi, ne;
+  std::vector<int> m, W;
+  DevBuf send[2], recv[2];  // [0]: finest level, [1]: coarsest level ghosts
+  DevBuf rhs_g, sol_g, zero_g;
+  bool chunked = false;
+  int q = 0;
+  int64_t nq = 0, cnt = 0;
+  DevBuf send2, recv2, partR, partL, xq;
+  // collectives
+  int backend = 0;  // 0 none, 1 callback, 2 RCCL, 3 loop-back
+  aggmg_allgather_fn fn = nullptr;
+  void* user = nullptr;
+  ncclComm_t comm = nullptr;
+  // interface exchange of the next cycle's x0 under the fine-level ascent
+  hipStream_t side = nullptr;
+  hipEvent_t ev_main = nullptr, ev_ends = nullptr, ev_side = nullptr;
+  const double* pending = nullptr;
+  int64_t exchanges = 0;
+  // hipGraph replay of whole cycles, keyed by the argument tuple (AGGMG_DIST_GRAPH)
+  struct GraphKey {
+    const double *x0, *b;
+    double* x_out;
+    int nPre, nPost, flags;
+    double alpha;
+    bool operator==(const GraphKey& o) const {
+      return x0 == o.x0 && b == o.b && x_out == o.x_out && nPre == o.nPre && nPost == o.nPost && flags == o.flags && alpha == o.alpha;
+    }
+  };
+  struct GraphEntry {
+    GraphKey key;
+    int seen = 0;               // eager runs with this key so far (the first one warms every lazy allocation)
+    hipGraphExec_t exec = nullptr;
+    int64_t exchanges = 0;      // all-gathers one replay stands for
+  };
+  std::vector<GraphEntry> graphs;
+  bool graph_broken = false;    // a capture failed once (e.g. the collective backend cannot be captured): stay eager
+  int64_t graph_replays = 0;
+  ~aggmg_dist() {
+    if (comm) {
+      if (RcclApi* a = rccl_api(nullptr)) (void)a->CommDestroy(comm);
+    }
+    for (auto& g : graphs)
+      if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    for (hipEvent_t e : {ev_main, ev_ends, ev_side})
+      if (e) (void)hipEventDestroy(e);
+    if (side) (void)hipStreamDestroy(side);
+  }
+};
+
+static int dist_allgather(aggmg_ctx* ctx, aggmg_dist* d, const double* send, double* recv, int64_t count) {
+  d->exchanges += 1;
+  if (d->world == 1 && d->backend != 2) {
+    HIPCHK(hipMemcpyAsync(recv, send, count * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    return AGGMG_OK;
+  }
+  switch (d->backend) {
+    case 1: {
+      const int st = d->fn(d->user, send, recv, count, (void*)ctx->stream);
+      if (st != 0) return fail(ctx, AGGMG_ERR_HIP, "aggmg_dist: the all-gather callback reported failure " + std::to_string(st));
+      return AGGMG_OK;
+    }
+    case 2: {
+      RcclApi* a = rccl_api(nullptr);
+      const ncclResult_t r = a->AllGather(send, recv, (size_t)count, ncclDouble, d->comm, ctx->stream);
+      if (r != ncclSuccess) return fail(ctx, AGGMG_ERR_HIP, std::string("ncclAllGather: ") + a->GetErrorString(r));
+      return AGGMG_OK;
+    }
+    case 3: {
+      const unsigned nb = (unsigned)((count + kThreads - 1) / kThreads);
+      if (nb) hipLaunchKernelGGL(loopback_kernel, dim3(nb), dim3(kThreads), 0, ctx->stream, send, recv, count, d->world);
+      HIPCHK(hipGetLastError());
+      return AGGMG_OK;
+    }
+  }
+  return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_dist: no collective backend set (aggmg_dist_init_rccl / aggmg_dist_set_allgather)");
+}
+
+static int copy2(aggmg_ctx* ctx, int nseg, const double* const* src, double* const* dst, const int64_t* rows,
+                 const int64_t* cols, const int64_t* sld, const int64_t* dld) {
+  return aggmg_copy_segments_dev(ctx, nseg, src, dst, rows, cols, sld, dld);
+}
+
+// pack the first and last W owned elements of a local level vector
+static int pack_interface(aggmg_ctx* ctx, aggmg_dist* d, const double* x, int level, double* send) {
+  const int64_t m = d->m[level], wm = (int64_t)d->W[level] * m;
+  const int64_t o0 = (d->own_lo[level] - d->loc_lo[level]) * m;
+  const int64_t o1 = o0 + (d->own_hi[level] - d->own_lo[level]) * m;
+  const double* src[2] = {x + o0, x + o1 - wm};
+  double* dst[2] = {send, send + wm};
+  const int64_t rows[2] = {1, 1}, cols[2] = {wm, wm}, ld[2] = {wm, wm};
+  return copy2(ctx, 2, src, dst, rows, cols, ld, ld);
+}
+
+// neighbours' interface elements -> ghost entries
+static int unpack_ghosts(aggmg_ctx* ctx, aggmg_dist* d, double* x, int level, const double* recv) {
+  const int64_t m = d->m[level], wm = (int64_t)d->W[level] * m;
+  const int64_t gl = d->own_lo[level] - d->loc_lo[level], gr = d->loc_hi[level] - d->own_hi[level];
+  const int64_t o0 = gl * m;
+  const int64_t o1 = o0 + (d->own_hi[level] - d->own_lo[level]) * m;
+  const double* src[2];
+  double* dst[2];
+  int64_t rows[2], cols[2], ld[2];
+  int n = 0;
+  const int r = d->rank;
+  if (gl) {  // the left neighbour's last W elements
+    src[n] = recv + (int64_t)(r - 1) * 2 * wm + wm;
+    dst[n] = x;
+    rows[n] = 1, cols[n] = gl * m, ld[n] = gl * m;
+    ++n;
+  }
+  if (gr) {
+    src[n] = recv + (int64_t)(r + 1) * 2 * wm;
+    dst[n] = x + o1;
+    rows[n] = 1, cols[n] = gr * m, ld[n] = gr * m;
+    ++n;
+  }
+  return n ? copy2(ctx, n, src, dst, rows, cols, ld, ld) : AGGMG_OK;
+}
+
+static int exchange_ghosts(aggmg_ctx* ctx, aggmg_dist* d, double* x, int level) {
+  if (d->world == 1 || d->W[level] == 0) return AGGMG_OK;
+  const int slot = level == 0 ? 0 : 1;
+  const int64_t wm = (int64_t)d->W[level] * d->m[level];
+  CHECK(pack_interface(ctx, d, x, level, d->send[slot].p));
+  CHECK(dist_allgather(ctx, d, d->send[slot].p, d->recv[slot].p, 2 * wm));
+  return unpack_ghosts(ctx, d, x, level, d->recv[slot].p);
+}
+
+extern "C" int aggmg_dist_create(aggmg_ctx* ctx, aggmg_hier* local, aggmg_hier* coarse_global, int world, int rank,
+                                 int nlevels, const int64_t* own_lo, const int64_t* own_hi, const int64_t* loc_lo,
+                                 const int64_t* loc_hi, const int64_t* ne, const int32_t* m, const int32_t* W,
+                                 aggmg_dist** out) {
+  if (!ctx || !out) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_dist_create: NULL argument");
+  *out = nullptr;
+  if (!local || !coarse_global || !own_lo || !own_hi || !loc_lo || !loc_hi || !ne || !m || !W)
+    return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_dist_create: NULL argument");
+  if (world < 1 || rank < 0 || rank >= world) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_dist_create: bad rank / world");
+  if (nlevels != (int)local->lv.size() || nlevels < 2)
+    return fail(ctx, AGGMG_ERR_DIMENSION, "aggmg_dist_create: nlevels does not match the local hierarchy (>= 2 levels)");
+  if (local->coarse_mode != AGGMG_COARSE_EXTERNAL)
+    return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_dist_create: the local hierarchy must be created with AGGMG_COARSE_EXTERNAL");
+  if (coarse_global->lv.size() != 1) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_dist_create: the coarse hierarchy must have one level");
+  HIPCHK(hipSetDevice(ctx->device));
+  std::unique_ptr<aggmg_dist> d(new aggmg_dist());
+  d->H = local;
+  d->Hc = coarse_global;
+  d->world = world;
+  d->rank = rank;
+  d->nl = nlevels;
+  for (int k = 0; k < nlevels; ++k) {
+    if (m[k] < 1 || W[k] < 0 || !(0 <= loc_lo[k] && loc_lo[k] <= own_lo[k] && own_lo[k] <= own_hi[k] &&
+                                   own_hi[k] <= loc_hi[k] && loc_hi[k] <= ne[k]))
+      return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_dist_create: inconsistent element ranges at level " + std::to_string(k + 1));
+    if ((loc_hi[k] - loc_lo[k]) * m[k] != local->lv[k].N)
+      return fail(ctx, AGGMG_ERR_DIMENSION, "aggmg_dist_create: local level size does not match the layout at level " + std::to_string(k + 1));
+    const int64_t gl = own_lo[k] - loc_lo[k], gr = loc_hi[k] - own_hi[k];
+    if ((gl && gl != W[k]) || (gr && gr != W[k]) || (world > 1 && own_hi[k] - own_lo[k] < W[k]))
+      return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_dist_create: ghost layers must be W elements wide (or absent at a domain end)");
+    d->own_lo.push_back(own_lo[k]), d->own_hi.push_back(own_hi[k]);
+    d->loc_lo.push_back(loc_lo[k]), d->loc_hi.push_back(loc_hi[k]);
+    d->ne.push_back(ne[k]), d->m.push_back(m[k]), d->W.push_back(W[k]);
+  }
+  const int nc = nlevels - 1;
+  if (ne[nc] * m[nc] != coarse_global->lv[0].N)
+    return fail(ctx, AGGMG_ERR_DIMENSION, "aggmg_dist_create: global coarsest operator size does not match the layout");
+  for (int s = 0; s < 2; ++s) {
+    const int lev = s == 0 ? 0 : nc;
+    const int64_t wm = (int64_t)W[lev] * m[lev];
+    CHECK(d->send[s].alloc(ctx, 2 * wm));
+    CHECK(d->recv[s].alloc(ctx, 2 * wm * world));
+  }
+  const int64_t Ng = ne[nc] * m[nc];
+  CHECK(d->rhs_g.alloc(ctx, Ng));
+  CHECK(d->sol_g.alloc(ctx, Ng));
+  CHECK(d->zero_g.alloc(ctx, Ng));
+  // chunked coarsest solve when the replicated solver has a chunk plan that the partition respects
+  if (world > 1) {
+    int q = -1, mblk = 0;
+    int64_t nq = 0, nblk = 0;
+    CHECK(aggmg_coarse_plan(ctx, coarse_global, &q, &nq, &mblk, &nblk));
+    const int64_t own_blk = own_hi[nc] - own_lo[nc];
+    // every rank must own the same number of whole chunks (the all-gather has equal counts)
+    if (q > 0 && mblk == m[nc] && nblk == ne[nc] && own_blk % ((int64_t)1 << q) == 0 && own_blk >= ((int64_t)1 << q) &&
+        own_blk * world == ne[nc]) {
+      d->chunked = true;
+      d->q = q;
+      d->nq = nq;
+      d->cnt = (own_blk >> q) * mblk;
+      CHECK(d->send2.alloc(ctx, 2 * d->cnt));
+      CHECK(d->recv2.alloc(ctx, 2 * d->cnt * world));
+      CHECK(d->partR.alloc(ctx, (nq + 1) * mblk));
+      CHECK(d->partL.alloc(ctx, (nq + 1) * mblk));
+      CHECK(d->xq.alloc(ctx, (nq + 1) * mblk));
+    }
+  }
+  HIPCHK(hipStreamCreateWithFlags(&d->side, hipStreamNonBlocking));
+  for (hipEvent_t* e : {&d->ev_main, &d->ev_ends, &d->ev_side}) HIPCHK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  *out = d.release();
+  return AGGMG_OK;
+}
+
+extern "C" int aggmg_dist_free(aggmg_ctx* ctx, aggmg_dist* d) {
+  if (!ctx) return AGGMG_ERR_ARGUMENT;
+  if (!d) return AGGMG_OK;
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (d->side) HIPCHK(hipStreamSynchronize(d->side));
+  delete d;
+  return AGGMG_OK;
+}
+
+extern "C" int aggmg_dist_set_allgather(aggmg_ctx* ctx, aggmg_dist* d, aggmg_allgather_fn fn, void* user) {
+  if (!ctx || !d) return AGGMG_ERR_ARGUMENT;
+  d->fn = fn;
+  d->user = user;
+  d->backend = fn ? 1 : 0;
+  return AGGMG_OK;
+}
+
+extern "C" int aggmg_dist_set_loopback(aggmg_ctx* ctx, aggmg_dist* d) {
+  if (!ctx || !d) return AGGMG_ERR_ARGUMENT;
+  d->backend = 3;
+  return AGGMG_OK;
+}
+
+extern "C" int aggmg_rccl_unique_id(aggmg_ctx* ctx, void* id_out, int nbytes) {
+  if (!ctx || !id_out) return AGGMG_ERR_ARGUMENT;
+  if (nbytes < (int)sizeof(ncclUniqueId)) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_rccl_unique_id: buffer smaller than AGGMG_RCCL_ID_BYTES");
+  std::string why;
+  RcclApi* a = rccl_api(&why);
+  if (!a) return fail(ctx, AGGMG_ERR_UNSUPPORTED, why);
+  ncclUniqueId id;
+  const ncclResult_t r = a->GetUniqueId(&id);
+  if (r != ncclSuccess) return fail(ctx, AGGMG_ERR_HIP, std::string("ncclGetUniqueId: ") + a->GetErrorString(r));
+  std::memcpy(id_out, &id, sizeof(id));
+  return AGGMG_OK;
+}
+
+extern "C" int aggmg_dist_init_rccl(aggmg_ctx* ctx, aggmg_dist* d, const void* id, int nbytes, int* nranks_out) {
+  if (!ctx || !d || !id) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_dist_init_rccl: NULL argument");
+  if (nbytes < (int)sizeof(ncclUniqueId)) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_dist_init_rccl: id smaller than AGGMG_RCCL_ID_BYTES");
+  std::string why;
+  RcclApi* a = rccl_api(&why);
+  if (!a) return fail(ctx, AGGMG_ERR_UNSUPPORTED, why);
+  HIPCHK(hipSetDevice(ctx->device));
+  ncclUniqueId uid;
+  std::memcpy(&uid, id, sizeof(uid));
+  ncclComm_t comm = nullptr;
+  ncclResult_t r = a->CommInitRank(&comm, d->world, uid, d->rank);
+  if (r != ncclSuccess) return fail(ctx, AGGMG_ERR_HIP, std::string("ncclCommInitRank: ") + a->GetErrorString(r));
+  int cnt = 0;
+  r = a->CommCount(comm, &cnt);
+  if (r != ncclSuccess || cnt != d->world) {
+    (void)a->CommDestroy(comm);
+    return fail(ctx, AGGMG_ERR_HIP, "aggmg_dist_init_rccl: communicator reports " + std::to_string(cnt) + " ranks, expected " +
+                                        std::to_string(d->world));
+  }
+  if (d->comm) (void)a->CommDestroy(d->comm);
+  d->comm = comm;
+  d->backend = 2;
+  if (nranks_out) *nranks_out = cnt;
+  return AGGMG_OK;
+}
+
+extern "C" int aggmg_dist_allgather_dev(aggmg_ctx* ctx, aggmg_dist* d, const double* send, double* recv, int64_t count) {
+  if (!ctx || !d || !send || !recv || count < 0) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_dist_allgather_dev: bad argument");
+  return dist_allgather(ctx, d, send, recv, count);
+}
+
+extern "C" int aggmg_dist_exchange_ghosts_dev(aggmg_ctx* ctx, aggmg_dist* d, double* x_local, int level) {
+  if (!ctx || !d || !x_local) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_dist_exchange_ghosts_dev: NULL argument");
+  if (level != 0 && level != d->nl - 1)
+    return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_dist_exchange_ghosts_dev: only the finest and the coarsest level exchange ghosts");
+  return exchange_ghosts(ctx, d, x_local, level);
+}
+
+extern "C" int aggmg_dist_info(aggmg_ctx* ctx, const aggmg_dist* d, int64_t* exchanges, int* chunked, int* backend) {
+  if (!ctx || !d) return AGGMG_ERR_ARGUMENT;
+  if (exchanges) *exchanges = d->exchanges;
+  if (chunked) *chunked = d->chunked ? 1 : 0;
+  if (backend) *backend = d->backend;
+  return AGGMG_OK;
+}
+
+// one cycle, issued launch by launch on ctx->stream (and the side stream for the overlapped exchange,
+// which is joined back before returning: the cycle is self-contained, hence capturable)
+static int dist_vcycle_eager(aggmg_ctx* ctx, aggmg_dist* d, double* x0, const double* b, double* x_out, int nPre,
+                             int nPost, double alpha, int flags) {
+  aggmg_hier* H = d->H;
+  const int nc = d->nl - 1;
+  const int mc = d->m[nc];
+  bool ghosts_valid = (flags & AGGMG_DIST_X0_GHOSTS_VALID) != 0;
+  hipStream_t main = ctx->stream;
+  if (d->pending) {
+    // the exchange issued under the previous cycle's ascent (already joined to the main stream): use
+    // it if it was for this x0
+    if (d->pending == x0) {
+      CHECK(unpack_ghosts(ctx, d, x0, 0, d->recv[0].p));
+      ghosts_valid = true;
+    }
+    d->pending = nullptr;
+  }
+  if (!ghosts_valid) CHECK(exchange_ghosts(ctx, d, x0, 0));
+  CHECK(aggmg_vcycle_down_dev(ctx, H, x0, b, nPre, alpha));
+  double* rhs_c = H->lv[nc].rhs;
+  double* sol_c = H->lv[nc].u[0];
+  const int64_t gl = d->own_lo[nc] - d->loc_lo[nc];
+  const int64_t own_c = (d->own_hi[nc] - d->own_lo[nc]) * mc;
+  const double* own = rhs_c + gl * mc;
+  if (d->chunked) {
+    const int64_t blo = d->own_lo[nc], bhi = d->own_hi[nc];
+    const int64_t clo = blo >> d->q;
+    const int64_t cnt = d->cnt;
+    const int P = d->world;
+    // the chunk kernels write their boundary rows at GLOBAL positions partR[c*mc ..], partL[(c+1)*mc ..]:
+    // shifted base pointers make this rank's slices land in the send buffer directly (no pack launch)
+    CHECK(aggmg_coarse_chunk_forward_dev(ctx, d->Hc, own, blo, bhi, d->send2.p - clo * mc, d->send2.p + cnt - (clo + 1) * mc));
+    CHECK(dist_allgather(ctx, d, d->send2.p, d->recv2.p, 2 * cnt));
+    {  // rank r's slices go to their global positions: partR[r*cnt ..], partL[mc + r*cnt ..]
+      const double* src[2] = {d->recv2.p, d->recv2.p + cnt};
+      double* dst[2] = {d->partR.p, d->partL.p + mc};
+      const int64_t rows[2] = {P, P}, cols[2] = {cnt, cnt}, sld[2] = {2 * cnt, 2 * cnt}, dld[2] = {cnt, cnt};
+      CHECK(copy2(ctx, 2, src, dst, rows, cols, sld, dld));
+    }
+    CHECK(aggmg_coarse_boundary_solve_dev(ctx, d->Hc, d->partR.p, d->partL.p, d->xq.p));
+    CHECK(aggmg_coarse_chunk_backward_dev(ctx, d->Hc, own, blo, bhi, d->xq.p, sol_c + gl * mc));
+    CHECK(exchange_ghosts(ctx, d, sol_c, nc));
+  } else {
+    CHECK(dist_allgather(ctx, d, own, d->rhs_g.p, own_c));
+    // a one-level hierarchy's V-cycle IS the coarsest direct solve (src/solvers.jl:39)
+    CHECK(aggmg_vcycle_dev(ctx, d->Hc, d->zero_g.p, d->rhs_g.p, 0, 0, 1.0, d->sol_g.p));
+    HIPCHK(hipMemcpyAsync(sol_c, d->sol_g.p + d->loc_lo[nc] * mc, (size_t)(d->loc_hi[nc] - d->loc_lo[nc]) * mc * sizeof(double),
+                          hipMemcpyDeviceToDevice, ctx->stream));
+  }
+  const bool overlap = (flags & AGGMG_DIST_OVERLAP_NEXT) && d->world > 1 && d->W[0] > 0;
+  if (overlap) {
+    const int64_t gl0 = d->own_lo[0] - d->loc_lo[0];
+    const int64_t head = gl0 + d->W[0];                                      // local elements [0, head)
+    const int64_t tail = gl0 + (d->own_hi[0] - d->own_lo[0]) - d->W[0];      // [tail, end)
+    int st = aggmg_vcycle_up_split_dev(ctx, H, b, nPost, alpha, x_out, head, tail, 0);  // the coarser levels
+    if (st == AGGMG_OK) {
+      // side stream: the tiles holding the interface elements, then their pack + all-gather
+      HIPCHK(hipEventRecord(d->ev_main, main));
+      HIPCHK(hipStreamWaitEvent(d->side, d->ev_main, 0));
+      ctx->stream = d->side;
+      st = aggmg_vcycle_up_split_dev(ctx, H, b, nPost, alpha, x_out, head, tail, 1);
+      if (st == AGGMG_OK) {
+        (void)hipEventRecord(d->ev_ends, d->side);
+        st = pack_interface(ctx, d, x_out, 0, d->send[0].p);
+      }
+      if (st == AGGMG_OK) st = dist_allgather(ctx, d, d->send[0].p, d->recv[0].p, 2 * (int64_t)d->W[0] * d->m[0]);
+      (void)hipEventRecord(d->ev_side, d->side);
+      ctx->stream = main;
+      CHECK(st);
+      d->pending = x_out;
+      CHECK(aggmg_vcycle_up_split_dev(ctx, H, b, nPost, alpha, x_out, head, tail, 2));  // the middle, main stream
+      HIPCHK(hipStreamWaitEvent(main, d->ev_side, 0));  // join: x_out whole and the gathered interface ready
+      return AGGMG_OK;
+    }
+    if (st != AGGMG_ERR_UNSUPPORTED) return st;  // (not a fused block-tridiagonal fine level: plain ascent)
+  }
+  return aggmg_vcycle_up_dev(ctx, H, b, nPost, alpha, x_out);
+}
+
+extern "C" int aggmg_dist_vcycle_dev(aggmg_ctx* ctx, aggmg_dist* d, double* x0, const double* b, double* x_out, int nPre,
+                                     int nPost, double alpha, int flags) {
+  if (!ctx || !d || !x0 || !b || !x_out) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_dist_vcycle_dev: NULL argument");
+  if (nPre < 0 || nPost < 0) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_dist_vcycle_dev: negative sweep count");
+  if (x_out == x0 || x_out == b) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_dist_vcycle_dev: x_out must not alias x0 or b");
+  // hipGraph replay: a cycle with the same arguments was issued eagerly once (lazy allocations done)
+  // and captured on its second call; host callbacks, the host coarsest solver and the event profiler
+  // cannot be captured
+  const bool graphable = (flags & AGGMG_DIST_GRAPH) && !d->graph_broken && ctx->profiling == 0 && d->backend != 1 &&
+                         d->Hc->cr.valid;
+  if (!graphable) return dist_vcycle_eager(ctx, d, x0, b, x_out, nPre, nPost, alpha, flags);
+  // whether this call consumes a prefetched exchange is part of what the graph does
+  const int eff = flags | (d->pending == x0 && d->pending ? 0x100 : 0);
+  const aggmg_dist::GraphKey key{x0, b, x_out, nPre, nPost, eff, alpha};
+  aggmg_dist::GraphEntry* g = nullptr;
+  for (auto& e : d->graphs)
+    if (e.key == key) g = &e;
+  if (!g) {
+    if (d->graphs.size() >= 8) return dist_vcycle_eager(ctx, d, x0, b, x_out, nPre, nPost, alpha, flags);
+    d->graphs.push_back(aggmg_dist::GraphEntry{key});
+    g = &d->graphs.back();
+  }
+  if (g->exec) {
+    HIPCHK(hipGraphLaunch(g->exec, ctx->stream));
+    d->exchanges += g->exchanges;
+    d->graph_replays += 1;
+    d->pending = (flags & AGGMG_DIST_OVERLAP_NEXT) && d->world > 1 && d->W[0] > 0 ? x_out : nullptr;
+    return AGGMG_OK;
+  }
+  if (g->seen++ == 0) return dist_vcycle_eager(ctx, d, x0, b, x_out, nPre, nPost, alpha, flags);
+  // second call with this key: capture it
+  const int64_t ex0 = d->exchanges;
+  const double* pending0 = d->pending;
+  // (the legacy default stream cannot be captured: run the library on its own stream, aggmg_reset_stream)
+  hipError_t e = ctx->stream ? hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) : hipErrorStreamCaptureUnsupported;
+  if (e != hipSuccess) {
+    (void)hipGetLastError();  // the refusal must not surface at the next launch check
+    d->graph_broken = true;
+    return dist_vcycle_eager(ctx, d, x0, b, x_out, nPre, nPost, alpha, flags);
+  }
+  const int st = dist_vcycle_eager(ctx, d, x0, b, x_out, nPre, nPost, alpha, flags);
+  hipGraph_t graph = nullptr;
+  e = hipStreamEndCapture(ctx->stream, &graph);
+  hipGraphExec_t exec = nullptr;
+  if (st == AGGMG_OK && e == hipSuccess && graph) e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+  if (graph) (void)hipGraphDestroy(graph);
+  if (st != AGGMG_OK || e != hipSuccess || !exec) {
+    // nothing has run: fall back to issuing this cycle eagerly, and stay eager from now on
+    (void)hipGetLastError();
+    d->graph_broken = true;
+    d->exchanges = ex0;
+    d->pending = pending0;
+    return dist_vcycle_eager(ctx, d, x0, b, x_out, nPre, nPost, alpha, flags);
+  }
+  g->exec = exec;
+  g->exchanges = d->exchanges - ex0;
+  HIPCHK(hipGraphLaunch(exec, ctx->stream));
+  d->graph_replays += 1;
+  return AGGMG_OK;
+}
+
+extern "C" int aggmg_dist_graph_info(aggmg_ctx* ctx, const aggmg_dist* d, int64_t* replays, int* captured, int* broken) {
+  if (!ctx || !d) return AGGMG_ERR_ARGUMENT;
+  if (replays) *replays = d->graph_replays;
+  if (captured) {
+    int n = 0;
+    for (auto& g : d->graphs) n += g.exec ? 1 : 0;
+    *captured = n;
+  }
+  if (broken) *broken = d->graph_broken ? 1 : 0;
+  return AGGMG_OK;
+}

@@ -92,10 +92,10 @@ struct CgtDev {
   int64_t ne = 0;   // blocks = elements + 1 (the trailing one holds the last vertex, identity-padded)
   int64_t N = 0;    // DoFs of the operator; the block-ordered vectors have ne * m entries
   double *dblk = nullptr, *subrow = nullptr, *supcol = nullptr;
-  int32_t* perm = nullptr;            // [ne*m] block order -> reference numbering, -1 = padding
-  std::vector<int32_t> h_perm, h_inv; // host copies: block order -> reference, reference -> block order
+  int32_t* perm = nullptr;  // [ne*m] block order -> reference numbering, -1 = padding
+  int32_t* inv = nullptr;   // [N]    reference numbering -> block order
   ~CgtDev() {
-    for (void* p : {(void*)dblk, (void*)subrow, (void*)supcol, (void*)perm})
+    for (void* p : {(void*)dblk, (void*)subrow, (void*)supcol, (void*)perm, (void*)inv})
       if (p) (void)hipFree(p);
   }
 };
@@ -103,12 +103,15 @@ struct CgtDev {
 struct aggmg_op {
   int64_t m = 0, n = 0, nnz = 0;
   int kind = AGGMG_OP_STIFFNESS;
-  CsrDev csr;   // row-gather form of the matrix
-  CsrDev csrT;  // row-gather form of its transpose (transfers only)
-  HostCsr host; // host CSR kept for smoother / structure set-up until released
-  bool host_valid = false;
+  CsrDev csc;  // the uploaded CSC arrays (int32, 0-based) == row-gather CSR of the TRANSPOSE; always present
+  CsrDev csr;  // row-gather CSR of the matrix: transposed on the device on first use (generic kernels only)
   std::shared_ptr<BtdDev> btd;  // set when a block-Jacobi smoother recognised the structure
   std::shared_ptr<CgtDev> cgt;  // set when a point-Jacobi smoother was given the CG element chain
+  ~aggmg_op() {
+    for (CsrDev* d : {&csc, &csr})
+      for (void* p : {(void*)d->rowptr, (void*)d->colind, (void*)d->vals, (void*)d->rowblk})
+        if (p) (void)hipFree(p);
+  }
 };
 
 struct aggmg_smoother {
@@ -344,6 +347,7 @@ struct ProfScope {
 // ---------------------------------------------------------------------------------------------
 // CG chain path (cgt.hip)
 // ---------------------------------------------------------------------------------------------
+int cgt_tile_blocks(int m);
 int cgt_build(aggmg_ctx* ctx, aggmg_smoother* sm, const int64_t* elems, int64_t m1, int64_t nel, int one_based);
 int cgt_build_transfer(aggmg_ctx* ctx, const aggmg_op* L, const CgtDev& fine, const CgtDev* coarse, int hint_mc,
                        TransferCgt* out, bool* ok);
@@ -353,3 +357,19 @@ int cgt_smooth_ext(aggmg_ctx* ctx, const CgtDev& g, const double* u_in, const do
 int cgt_residual_ext(aggmg_ctx* ctx, const CgtDev& g, const double* u, const double* b, double* r_out);
 int cgt_down(aggmg_ctx* ctx, aggmg_hier* h, int k, const double* uin, const double* rhs, int nPre, double alpha);
 int cgt_up(aggmg_ctx* ctx, aggmg_hier* h, int k, const double* rhs, int nPost, double alpha, double* dst);
+
+// ---------------------------------------------------------------------------------------------
+// device-side set-up (setup.hip)
+// ---------------------------------------------------------------------------------------------
+int setup_csc_upload(aggmg_ctx* ctx, int64_t m, int64_t n, const int64_t* colptr, const int64_t* rowval,
+                     const double* nzval, int one_based, CsrDev* out);
+int op_ensure_csr(aggmg_ctx* ctx, aggmg_op* op);         // row-gather CSR + its CSR-stream row blocks
+int op_ensure_csc_blocks(aggmg_ctx* ctx, aggmg_op* op);  // CSR-stream row blocks of the transposed orientation
+int op_host_csr(aggmg_ctx* ctx, aggmg_op* op, HostCsr* h);
+int setup_jacobi_diag(aggmg_ctx* ctx, const aggmg_op* A, double** diag);
+int setup_invert_blocks(aggmg_ctx* ctx, int64_t nb, int m, const double* blocks_dev, int colmajor, double* inv_dev,
+                        int64_t* first_singular);
+int setup_block_smoother(aggmg_ctx* ctx, aggmg_smoother* sm, const int64_t* blockinds, int one_based, int want_btd);
+int setup_transfer_btd(aggmg_ctx* ctx, const aggmg_op* L, const BtdDev* Abtd, int mf, int64_t nef, int hint_mc,
+                       TransferBtd* out, bool* ok);
+int setup_cr(aggmg_ctx* ctx, const aggmg_op* Ac, int hint_m, CrDev* cr);

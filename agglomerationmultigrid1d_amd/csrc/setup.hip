@@ -1,0 +1,731 @@
+// Device-side set-up of libaggmg_hip: host code here only allocates, launches the
+// kernels of setup_kernels.hpp and reads back a handful of flags -- no O(n) host loop touches an
+// operator any more.  Compiled with -ffp-contract=off (see setup_kernels.hpp).
+#include <hipcub/hipcub.hpp>
+
+#include "internal.hpp"
+#include "setup_kernels.hpp"
+
+namespace {
+
+inline unsigned grid_for(int64_t n) { return (unsigned)((n + kSetupThreads - 1) / kSetupThreads); }
+
+// device scratch that frees itself
+struct Tmp {
+  void* p = nullptr;
+  ~Tmp() {
+    if (p) (void)hipFree(p);
+  }
+  template <typename T>
+  T* as() const {
+    return static_cast<T*>(p);
+  }
+};
+
+int tmp_alloc(aggmg_ctx* ctx, Tmp* t, size_t bytes, bool zero) {
+  HIPCHK(hipMalloc(&t->p, std::max<size_t>(bytes, 8)));
+  if (zero) HIPCHK(hipMemsetAsync(t->p, 0, std::max<size_t>(bytes, 8), ctx->stream));
+  return AGGMG_OK;
+}
+
+template <typename T>
+int dalloc(aggmg_ctx* ctx, T** out, int64_t count, bool zero) {
+  *out = nullptr;
+  const size_t bytes = (size_t)std::max<int64_t>(count, 1) * sizeof(T);
+  HIPCHK(hipMalloc((void**)out, bytes));
+  if (zero) HIPCHK(hipMemsetAsync(*out, 0, bytes, ctx->stream));
+  return AGGMG_OK;
+}
+
+// a few ints of flags on the device, read back synchronously
+struct Flags {
+  int* d = nullptr;
+  int n = 0;
+  ~Flags() {
+    if (d) (void)hipFree(d);
+  }
+  int init(aggmg_ctx* ctx, int count) {
+    n = count;
+    HIPCHK(hipMalloc((void**)&d, count * sizeof(int)));
+    HIPCHK(hipMemsetAsync(d, 0, count * sizeof(int), ctx->stream));
+    return AGGMG_OK;
+  }
+  int read(aggmg_ctx* ctx, int* host) {
+    HIPCHK(hipMemcpyAsync(host, d, n * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return AGGMG_OK;
+  }
+  int clear(aggmg_ctx* ctx) {
+    HIPCHK(hipMemsetAsync(d, 0, n * sizeof(int), ctx->stream));
+    return AGGMG_OK;
+  }
+};
+
+#define LAUNCH(kern, n, ...)                                                                      \
+  do {                                                                                            \
+    if ((n) > 0) hipLaunchKernelGGL(kern, dim3(grid_for(n)), dim3(kSetupThreads), 0, ctx->stream, __VA_ARGS__); \
+    HIPCHK(hipGetLastError());                                                                    \
+  } while (0)
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// upload
+// ---------------------------------------------------------------------------------------------
+int setup_csc_upload(aggmg_ctx* ctx, int64_t m, int64_t n, const int64_t* colptr, const int64_t* rowval,
+                     const double* nzval, int one_based, CsrDev* out) {
+  const int64_t base = one_based ? 1 : 0;
+  const int64_t nnz = colptr[n] - base;
+  out->nrows = n;  // rows of the transposed orientation = columns of the matrix
+  out->ncols = m;
+  out->nnz = nnz;
+  CHECK(dalloc(ctx, &out->rowptr, n + 1, false));
+  CHECK(dalloc(ctx, &out->colind, nnz, false));
+  CHECK(dalloc(ctx, &out->vals, nnz, false));
+  Tmp cp64, rv64;
+  CHECK(tmp_alloc(ctx, &cp64, (size_t)(n + 1) * 8, false));
+  CHECK(tmp_alloc(ctx, &rv64, (size_t)std::max<int64_t>(nnz, 1) * 8, false));
+  HIPCHK(hipMemcpyAsync(cp64.p, colptr, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+  if (nnz) {
+    HIPCHK(hipMemcpyAsync(rv64.p, rowval, (size_t)nnz * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(out->vals, nzval, (size_t)nnz * 8, hipMemcpyHostToDevice, ctx->stream));
+  }
+  Flags f;
+  CHECK(f.init(ctx, 4));
+  LAUNCH(csc_convert_colptr_kernel, n + 1, n, cp64.as<int64_t>(), base, nnz, out->rowptr, f.d);
+  int h[4];
+  CHECK(f.read(ctx, h));  // the row pass below walks colptr: it must be sane first
+  if (h[0]) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_csc_upload: colptr not monotone");
+  LAUNCH(csc_convert_rows_kernel, n, n, m, (const int32_t*)out->rowptr, rv64.as<int64_t>(), base, out->colind, f.d);
+  CHECK(f.read(ctx, h));
+  if (h[1]) return fail(ctx, AGGMG_ERR_DIMENSION, "aggmg_csc_upload: row index out of range");
+  if (h[2]) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_csc_upload: row indices not strictly ascending in a column");
+  return AGGMG_OK;
+}
+
+// CSR-stream row blocks of a device CSR (rows cut into runs of <= kStreamNnz entries and <= 4 * kThreads
+// rows); only the generic kernels need them
+int setup_stream_blocks(aggmg_ctx* ctx, CsrDev* d) {
+  if (d->rowblk || d->nrows == 0) return AGGMG_OK;
+  d->lpr = 1;
+  {
+    const double avg = (double)d->nnz / (double)d->nrows;
+    while (d->lpr < 64 && (double)d->lpr * 1.5 < avg) d->lpr *= 2;
+  }
+  if ((double)d->nnz / (double)d->nrows > 48.0) return AGGMG_OK;  // long rows: lanes-per-row kernel
+  std::vector<int32_t> rowptr(d->nrows + 1);
+  HIPCHK(hipMemcpyAsync(rowptr.data(), d->rowptr, rowptr.size() * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  std::vector<int32_t> blk;
+  blk.push_back(0);
+  int64_t r = 0;
+  const int64_t nrows = d->nrows;
+  while (r < nrows) {
+    int64_t e = r + 1;  // a block always takes at least one row (a long row stands alone)
+    const int64_t b0 = rowptr[r];
+    while (e < nrows && e - r < 4 * kThreads && rowptr[e + 1] - b0 <= kStreamNnz) ++e;
+    if (rowptr[r + 1] - b0 > kStreamNnz) e = r + 1;
+    blk.push_back((int32_t)e);
+    r = e;
+  }
+  d->nblk = (int64_t)blk.size() - 1;
+  CHECK(dev_upload(ctx, blk, &d->rowblk));
+  return AGGMG_OK;
+}
+
+// row-gather CSR of the matrix from its CSC arrays: stable radix sort of the entries by row
+int setup_transpose(aggmg_ctx* ctx, const CsrDev& csc, int64_t m, CsrDev* out) {
+  const int64_t n = csc.nrows, nnz = csc.nnz;
+  out->nrows = m;
+  out->ncols = n;
+  out->nnz = nnz;
+  CHECK(dalloc(ctx, &out->rowptr, m + 1, true));
+  CHECK(dalloc(ctx, &out->colind, nnz, false));
+  CHECK(dalloc(ctx, &out->vals, nnz, false));
+  if (nnz == 0) return AGGMG_OK;
+  // rowptr: histogram of the row indices, exclusive scan
+  Tmp counts;
+  CHECK(tmp_alloc(ctx, &counts, (size_t)(m + 1) * 4, true));
+  LAUNCH(row_count_kernel, nnz, nnz, (const int32_t*)csc.colind, counts.as<int32_t>());
+  size_t sbytes = 0;
+  HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, sbytes, counts.as<int32_t>(), out->rowptr, (int)(m + 1), ctx->stream));
+  Tmp stmp;
+  CHECK(tmp_alloc(ctx, &stmp, sbytes, false));
+  HIPCHK(hipcub::DeviceScan::ExclusiveSum(stmp.p, sbytes, counts.as<int32_t>(), out->rowptr, (int)(m + 1), ctx->stream));
+  // entries sorted by row; the sort is stable, so columns stay ascending inside a row
+  Tmp ecol, iota, perm, keys;
+  CHECK(tmp_alloc(ctx, &ecol, (size_t)nnz * 4, false));
+  CHECK(tmp_alloc(ctx, &iota, (size_t)nnz * 4, false));
+  CHECK(tmp_alloc(ctx, &perm, (size_t)nnz * 4, false));
+  CHECK(tmp_alloc(ctx, &keys, (size_t)nnz * 4, false));
+  LAUNCH(csc_entry_cols_kernel, n, n, (const int32_t*)csc.rowptr, ecol.as<int32_t>());
+  LAUNCH(iota_kernel, nnz, nnz, iota.as<uint32_t>());
+  int bits = 1;
+  while (bits < 32 && ((int64_t)1 << bits) < m) ++bits;
+  size_t rbytes = 0;
+  HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, rbytes, (const uint32_t*)csc.colind, keys.as<uint32_t>(), iota.as<uint32_t>(),
+                                            perm.as<uint32_t>(), (int)nnz, 0, bits, ctx->stream));
+  Tmp rtmp;
+  CHECK(tmp_alloc(ctx, &rtmp, rbytes, false));
+  HIPCHK(hipcub::DeviceRadixSort::SortPairs(rtmp.p, rbytes, (const uint32_t*)csc.colind, keys.as<uint32_t>(), iota.as<uint32_t>(),
+                                            perm.as<uint32_t>(), (int)nnz, 0, bits, ctx->stream));
+  LAUNCH(csr_gather_kernel, nnz, nnz, (const uint32_t*)perm.as<uint32_t>(), (const int32_t*)ecol.as<int32_t>(),
+         (const double*)csc.vals, out->colind, out->vals);
+  HIPCHK(hipStreamSynchronize(ctx->stream));  // the temporaries go out of scope
+  return AGGMG_OK;
+}
+
+int op_ensure_csr(aggmg_ctx* ctx, aggmg_op* op) {
+  if (!op->csr.rowptr) CHECK(setup_transpose(ctx, op->csc, op->m, &op->csr));
+  return setup_stream_blocks(ctx, &op->csr);
+}
+
+int op_ensure_csc_blocks(aggmg_ctx* ctx, aggmg_op* op) { return setup_stream_blocks(ctx, &op->csc); }
+
+// host copy of the row-gather CSR (the host banded LU fallback of the coarsest solve wants one)
+int op_host_csr(aggmg_ctx* ctx, aggmg_op* op, HostCsr* h) {
+  CHECK(op_ensure_csr(ctx, op));
+  h->rowptr.resize(op->m + 1);
+  h->colind.resize(op->nnz);
+  h->vals.resize(op->nnz);
+  HIPCHK(hipMemcpyAsync(h->rowptr.data(), op->csr.rowptr, (op->m + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+  if (op->nnz) {
+    HIPCHK(hipMemcpyAsync(h->colind.data(), op->csr.colind, op->nnz * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(h->vals.data(), op->csr.vals, op->nnz * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  }
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return AGGMG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// smoothers
+// ---------------------------------------------------------------------------------------------
+int setup_jacobi_diag(aggmg_ctx* ctx, const aggmg_op* A, double** diag) {
+  CHECK(dalloc(ctx, diag, A->m, false));
+  LAUNCH(diag_extract_kernel, A->m, A->m, (const int32_t*)A->csc.rowptr, (const int32_t*)A->csc.colind,
+         (const double*)A->csc.vals, *diag);
+  return AGGMG_OK;
+}
+
+// blocks [nb][m][m] (row-major, or one column-major Julia Matrix per block) -> inverses on the device;
+// *first_singular = index of the first singular block or -1
+int setup_invert_blocks(aggmg_ctx* ctx, int64_t nb, int m, const double* blocks_dev, int colmajor, double* inv_dev,
+                        int64_t* first_singular) {
+  unsigned long long* sing = nullptr;
+  HIPCHK(hipMalloc((void**)&sing, sizeof(unsigned long long)));
+  Tmp sing_owner;
+  sing_owner.p = sing;
+  const unsigned long long none = (unsigned long long)nb;
+  HIPCHK(hipMemcpyAsync(sing, &none, sizeof(none), hipMemcpyHostToDevice, ctx->stream));
+  Tmp work;
+  switch (m) {
+#define CASE(MM)                                                                              \
+  case MM:                                                                                    \
+    LAUNCH((block_invert_kernel<MM>), nb, nb, blocks_dev, colmajor, inv_dev, sing);           \
+    break;
+    CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
+#undef CASE
+    default:
+      CHECK(tmp_alloc(ctx, &work, (size_t)nb * ((size_t)m * m + 2 * m) * sizeof(double), false));
+      LAUNCH(block_invert_any_kernel, nb, nb, m, blocks_dev, colmajor, work.as<double>(), inv_dev, sing);
+  }
+  unsigned long long got = none;
+  HIPCHK(hipMemcpyAsync(&got, sing, sizeof(got), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  *first_singular = got >= none ? -1 : (int64_t)got;
+  return AGGMG_OK;
+}
+
+static bool btd_supported(int m, bool cmp) {
+  if (cmp) return m >= 2 && m <= 9;
+  return m >= 1 && m <= 5;
+}
+
+// dg_smoother(mesh, A, :blockJac) / cg_smoother(..., :addSchwarz | :hybridSchwarz) on the device: index lists
+// -> dense blocks A[inds, inds] -> pivoted LU -> inverses; contiguous aligned lists on a block-tridiagonal
+// operator additionally get the index-free fused form (patterns and symmetry detected on the device)
+int setup_block_smoother(aggmg_ctx* ctx, aggmg_smoother* sm, const int64_t* blockinds, int one_based, int want_btd) {
+  aggmg_op* A = sm->A;
+  const int64_t N = sm->N, nb = sm->nb;
+  const int m = (int)sm->m;
+  const int64_t total = nb * m;
+  const int64_t base = one_based ? 1 : 0;
+  Tmp inds64;
+  CHECK(tmp_alloc(ctx, &inds64, (size_t)std::max<int64_t>(total, 1) * 8, false));
+  if (total) HIPCHK(hipMemcpyAsync(inds64.p, blockinds, (size_t)total * 8, hipMemcpyHostToDevice, ctx->stream));
+  CHECK(dalloc(ctx, &sm->inds, total, false));
+  CHECK(dalloc(ctx, &sm->counts, N, true));
+  Flags f;
+  CHECK(f.init(ctx, 4));
+  LAUNCH(inds_convert_kernel, total, total, N, inds64.as<int64_t>(), base, sm->inds, sm->counts, f.d);
+  int h[4];
+  CHECK(f.read(ctx, h));
+  if (h[0]) return fail(ctx, AGGMG_ERR_DIMENSION, "aggmg_blockjacobi_setup: block index out of range");
+  sm->contiguous = (total == N) && !h[1];
+  sm->overlapping = h[2] != 0;
+  CHECK(dalloc(ctx, &sm->binv, total * m, false));
+  int64_t sing = -1;
+  auto b = std::make_shared<BtdDev>();
+  bool btd_ok = false;
+  if (sm->contiguous && !sm->overlapping && m <= 9) {
+    // scatter the entries into the three block diagonals: the diagonal blocks ARE A[inds, inds]
+    b->m = m;
+    b->ne = nb;
+    CHECK(dalloc(ctx, &b->dblk, N * m, true));
+    CHECK(dalloc(ctx, &b->sub, N * m, true));
+    CHECK(dalloc(ctx, &b->sup, N * m, true));
+    Flags f2;
+    CHECK(f2.init(ctx, 4));
+    unsigned* masks = reinterpret_cast<unsigned*>(f2.d + 2);
+    LAUNCH(btd_scatter_kernel, N, N, m, (const int32_t*)A->csc.rowptr, (const int32_t*)A->csc.colind,
+           (const double*)A->csc.vals, b->dblk, b->sub, b->sup, f2.d, masks);
+    int g[4];
+    CHECK(f2.read(ctx, g));
+    btd_ok = !g[0];
+    CHECK(setup_invert_blocks(ctx, nb, m, b->dblk, 0, sm->binv, &sing));
+    if (btd_ok && want_btd && sing < 0) {
+      const unsigned submask = (unsigned)g[2], supmask = (unsigned)g[3];
+      bool cmp = m >= 2 && __builtin_popcount(submask) <= 1 && __builtin_popcount(supmask) <= 1;
+      int c_sub = submask ? __builtin_ctz(submask) : 0, r_sup = supmask ? __builtin_ctz(supmask) : 0;
+      if (cmp && !btd_supported(m, true)) cmp = false;
+      if (!cmp) c_sub = r_sup = 0;
+      if (cmp || btd_supported(m, false)) {
+        b->cmp = cmp;
+        b->c_sub = c_sub;
+        b->r_sup = r_sup;
+        // the fused kernel's copy of the inverses
+        CHECK(dalloc(ctx, &b->binv, N * m, false));
+        HIPCHK(hipMemcpyAsync(b->binv, sm->binv, (size_t)N * m * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+        Flags asym;
+        CHECK(asym.init(ctx, 1));
+        const bool grp = cmp ? (m == 2 || m == 4 || m == 8) : (m == 2 || m == 4);
+        const bool try_sym = grp && ctx->sym_packing && (!cmp || c_sub == r_sup);
+        if (cmp) {
+          CHECK(dalloc(ctx, &b->scol, N, false));
+          CHECK(dalloc(ctx, &b->pcol, N, false));
+          CHECK(dalloc(ctx, &b->qrow, N, false));
+          LAUNCH(btd_cmp_finish_kernel, nb, nb, m, c_sub, r_sup, (const double*)b->binv, (const double*)b->sub,
+                 (const double*)b->sup, b->scol, b->pcol, b->qrow);
+        } else {
+          CHECK(dalloc(ctx, &b->P, N * m, false));
+          CHECK(dalloc(ctx, &b->Q, N * m, false));
+          LAUNCH(btd_dense_finish_kernel, N, nb, m, (const double*)b->binv, (const double*)b->sub, (const double*)b->sup,
+                 b->P, b->Q);
+        }
+        if (try_sym) {
+          LAUNCH(btd_sym_check_kernel, nb, nb, m, cmp ? 1 : 0, c_sub, r_sup, 1e-13, (const double*)b->binv,
+                 (const double*)b->sub, (const double*)b->sup, asym.d);
+          int a1 = 0;
+          CHECK(asym.read(ctx, &a1));
+          if (!a1) {
+            CHECK(dalloc(ctx, &b->bsym, nb * (int64_t)(m * (m + 1) / 2), false));
+            LAUNCH(btd_sym_pack_kernel, nb, nb, m, (const double*)b->binv, b->bsym);
+          }
+        }
+        if (cmp) {  // the dense off-diagonal blocks are not read by the compressed kernels
+          (void)hipStreamSynchronize(ctx->stream);
+          (void)hipFree(b->sub);
+          (void)hipFree(b->sup);
+          b->sub = b->sup = nullptr;
+        }
+        sm->btd = b;
+        A->btd = b;
+      }
+    }
+  } else {
+    Tmp blocks;
+    CHECK(tmp_alloc(ctx, &blocks, (size_t)std::max<int64_t>(total * m, 1) * sizeof(double), false));
+    LAUNCH(block_extract_generic_kernel, total * m, nb, m, (const int32_t*)sm->inds, (const int32_t*)A->csc.rowptr,
+           (const int32_t*)A->csc.colind, (const double*)A->csc.vals, blocks.as<double>());
+    CHECK(setup_invert_blocks(ctx, nb, m, blocks.as<double>(), 0, sm->binv, &sing));
+  }
+  if (sing >= 0)
+    return fail(ctx, AGGMG_ERR_SINGULAR,
+                "aggmg_blockjacobi_setup: singular block " + std::to_string(sing + 1) + " (SingularException)");
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return AGGMG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// structured transfer of a block-tridiagonal level
+// ---------------------------------------------------------------------------------------------
+int setup_transfer_btd(aggmg_ctx* ctx, const aggmg_op* L, const BtdDev* Abtd, int mf, int64_t nef, int hint_mc,
+                       TransferBtd* out, bool* ok) {
+  *ok = false;
+  const int64_t Nf = L->m, Nc = L->n;
+  if (Nf != nef * mf) return AGGMG_OK;
+  Flags bad;
+  CHECK(bad.init(ctx, 1));
+  for (int mc = 1; mc <= 16; ++mc) {
+    if (hint_mc > 0 && mc != hint_mc) continue;
+    if (Nc % mc) continue;
+    const int64_t nec = Nc / mc;
+    if (nec == 0 || nef % nec) continue;
+    const int64_t rho = nef / nec;
+    if (rho > 64) continue;
+    double* lf = nullptr;
+    CHECK(dalloc(ctx, &lf, Nf * mc, true));
+    CHECK(bad.clear(ctx));
+    LAUNCH(transfer_scatter_kernel, Nc, Nc, mf, mc, rho, (const int32_t*)L->csc.rowptr, (const int32_t*)L->csc.colind,
+           (const double*)L->csc.vals, lf, bad.d);
+    int b1 = 0;
+    CHECK(bad.read(ctx, &b1));
+    if (b1) {
+      (void)hipFree(lf);
+      continue;
+    }
+    out->lf = lf;
+    if (Abtd && Abtd->dblk) {
+      CHECK(dalloc(ctx, &out->ld, Nf * mc, false));
+      LAUNCH(transfer_ld_kernel, Nf, nef, mf, mc, (const double*)lf, (const double*)Abtd->dblk, out->ld);
+    }
+    out->mc = mc;
+    out->rho = (int)rho;
+    *ok = true;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return AGGMG_OK;
+  }
+  return AGGMG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// cyclic-reduction factorisation of the coarsest operator
+// ---------------------------------------------------------------------------------------------
+template <int M>
+static int cr_levels_t(aggmg_ctx* ctx, CrDev* cr, double* a, double* b, double* c, int64_t n, double* cond_dev, int* bad_dev) {
+  const int mm2 = M * M;
+  auto own = [&](void* p) { cr->owned.push_back(p); };
+  while (n > 1) {
+    const int64_t ne = (n + 1) / 2, no = n / 2;
+    double *lu = nullptr, *Za = nullptr, *Zc = nullptr, *a2 = nullptr, *b2 = nullptr, *c2 = nullptr;
+    int32_t* perm = nullptr;
+    CHECK(dalloc(ctx, &lu, no * mm2, false));
+    own(lu);
+    CHECK(dalloc(ctx, &perm, no * M, false));
+    own(perm);
+    Tmp tza, tzc;
+    CHECK(tmp_alloc(ctx, &tza, (size_t)std::max<int64_t>(no, 1) * mm2 * sizeof(double), false));
+    CHECK(tmp_alloc(ctx, &tzc, (size_t)std::max<int64_t>(no, 1) * mm2 * sizeof(double), false));
+    Za = tza.as<double>();
+    Zc = tzc.as<double>();
+    CHECK(dalloc(ctx, &a2, ne * mm2, false));
+    CHECK(dalloc(ctx, &b2, ne * mm2, false));
+    CHECK(dalloc(ctx, &c2, ne * mm2, false));
+    LAUNCH((cr_factor_odd_kernel<M>), no, no, (const double*)a, (const double*)b, (const double*)c, lu, perm, Za, Zc, cond_dev,
+           bad_dev);
+    LAUNCH((cr_schur_even_kernel<M>), ne, n, ne, (const double*)a, (const double*)b, (const double*)c, (const double*)Za,
+           (const double*)Zc, a2, b2, c2);
+    HIPCHK(hipStreamSynchronize(ctx->stream));  // Za / Zc leave scope
+    CrLevel L;
+    L.n = n;
+    L.n_even = ne;
+    L.n_odd = no;
+    L.a = a;
+    L.c = c;
+    L.lu = lu;
+    L.perm = perm;
+    own(a);
+    own(c);
+    (void)hipFree(b);  // the diagonal blocks of this level live on in the odd factors and the next level
+    cr->lv.push_back(L);
+    a = a2;
+    b = b2;
+    c = c2;
+    n = ne;
+    if ((int)cr->lv.size() > kCrMaxLevels) {
+      (void)hipFree(a), (void)hipFree(b), (void)hipFree(c);
+      return AGGMG_ERR_UNSUPPORTED;
+    }
+  }
+  double* lu = nullptr;
+  int32_t* perm = nullptr;
+  CHECK(dalloc(ctx, &lu, mm2, false));
+  own(lu);
+  CHECK(dalloc(ctx, &perm, M, false));
+  own(perm);
+  hipLaunchKernelGGL((cr_factor_last_kernel<M>), dim3(1), dim3(64), 0, ctx->stream, (const double*)b, lu, perm, cond_dev, bad_dev);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  (void)hipFree(a), (void)hipFree(b), (void)hipFree(c);
+  cr->lu_last = lu;
+  cr->perm_last = perm;
+  return AGGMG_OK;
+}
+
+static void cr_release(CrDev* c) {
+  for (void* p : c->owned)
+    if (p) (void)hipFree(p);
+  *c = CrDev();
+}
+
+// Sets cr->valid when the operator is block-tridiagonal for some block size m <= 8 and every pivot block is
+// comfortably invertible; leaves it false otherwise (the caller then keeps the host banded solver).
+int setup_cr(aggmg_ctx* ctx, const aggmg_op* Ac, int hint_m, CrDev* cr) {
+  cr->valid = false;
+  const int64_t N = Ac->m;
+  if (N == 0) return AGGMG_OK;
+  const int32_t* cp = Ac->csc.rowptr;
+  const int32_t* rv = Ac->csc.colind;
+  const double* vv = Ac->csc.vals;
+  Flags f;
+  CHECK(f.init(ctx, 4));
+  LAUNCH(band_kernel, N, N, cp, rv, f.d);
+  int band[4];
+  CHECK(f.read(ctx, band));
+  const int kl = band[0], ku = band[1];
+  Flags bad;
+  CHECK(bad.init(ctx, 1));
+  auto fits = [&](int mm_, bool* out) -> int {
+    CHECK(bad.clear(ctx));
+    LAUNCH(block_fit_kernel, N, N, mm_, cp, rv, bad.d);
+    int b1 = 0;
+    CHECK(bad.read(ctx, &b1));
+    *out = !b1;
+    return AGGMG_OK;
+  };
+  int m = 0;
+  bool okm = false;
+  if (hint_m >= 1 && hint_m <= 8) {
+    CHECK(fits(hint_m, &okm));
+    if (okm) m = hint_m;
+  }
+  // otherwise the smallest block size for which the operator is block-tridiagonal
+  for (int cand = 1; !m && cand <= 8; ++cand)
+    if (std::max(kl, ku) <= 2 * cand - 1) {
+      CHECK(fits(cand, &okm));
+      if (okm) m = cand;
+    }
+  if (!m) return AGGMG_OK;
+  const int mm2 = m * m;
+  const int64_t n = (N + m - 1) / m;
+  cr->m = m;
+  cr->n0 = n;
+  cr->N = N;
+  double *a = nullptr, *b = nullptr, *c = nullptr;
+  CHECK(dalloc(ctx, &a, n * mm2, true));
+  CHECK(dalloc(ctx, &b, n * mm2, true));
+  CHECK(dalloc(ctx, &c, n * mm2, true));
+  LAUNCH(cr_pack_kernel, n * m, N, m, cp, rv, vv, a, b, c);
+  Tmp condt;
+  CHECK(tmp_alloc(ctx, &condt, sizeof(double), true));
+  CHECK(bad.clear(ctx));
+  int st = AGGMG_OK;
+  switch (m) {
+#define CASE(MM) \
+  case MM:       \
+    st = cr_levels_t<MM>(ctx, cr, a, b, c, n, condt.as<double>(), bad.d); \
+    break;
+    CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
+#undef CASE
+  }
+  if (st == AGGMG_ERR_UNSUPPORTED) {  // too many levels
+    cr_release(cr);
+    return AGGMG_OK;
+  }
+  if (st != AGGMG_OK) {
+    cr_release(cr);
+    return st;
+  }
+  int b1 = 0;
+  CHECK(bad.read(ctx, &b1));
+  double cond = 0.0;
+  HIPCHK(hipMemcpyAsync(&cond, condt.p, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  cr->cond_est = cond;
+  if (b1 || !(cond < 1e13)) {  // a pivot block is singular or close to it: keep the pivoted banded LU
+    cr_release(cr);
+    return AGGMG_OK;
+  }
+  // plan: [g per-level launches, only if a chunk would not fit in LDS] -> q chunk levels -> the tail
+  const int nl = (int)cr->lv.size();
+  auto level_n = [&](int l) -> int64_t { return l < nl ? cr->lv[l].n : 1; };
+  int g = 0, q = 0;
+  for (;; ++g) {
+    q = 0;
+    while (g + q < nl && level_n(g + q) * m > kCrTailRows) ++q;
+    const size_t lds = ((size_t)(2 << q) + q + 2) * m * sizeof(double);
+    if (q <= kCrMaxChunkLevels && lds <= 48 * 1024) break;
+    if (g >= nl) break;
+  }
+  if (nl - (g + q) > 16) {
+    cr_release(cr);
+    return AGGMG_OK;
+  }
+  cr->nglobal = g;
+  cr->q = q;
+  {
+    size_t o = 0;
+    for (int l = 0; l <= q; ++l) o += ((size_t)(1 << (q - l)) + 1) * m;
+    cr->chunk_lds = o * sizeof(double);
+  }
+  int64_t rows = 0;
+  for (int l = g + q; l < nl; ++l) rows += cr->lv[l].n * m;
+  cr->tail_lds = (size_t)(rows + m) * sizeof(double);
+  auto dz = [&](int64_t len, double** out) -> int {
+    CHECK(dalloc(ctx, out, len, true));
+    cr->owned.push_back(*out);
+    return AGGMG_OK;
+  };
+  for (int l = 0; l <= g; ++l) {
+    double *dd = nullptr, *xx = nullptr;
+    CHECK(dz(level_n(l) * m, &dd));
+    CHECK(dz(level_n(l) * m, &xx));
+    cr->d.push_back(dd);
+    cr->x.push_back(xx);
+  }
+  if (q > 0) {
+    const int64_t nq = level_n(g + q) * m;
+    CHECK(dz(nq, &cr->partR));
+    CHECK(dz(nq, &cr->partL));  // partL[0] is never written: stays zero
+    CHECK(dz(nq, &cr->xq));
+    cr->stack_stride = (int)(cr->chunk_lds / sizeof(double));
+    CHECK(dz((level_n(g + q) + 1) * (int64_t)cr->stack_stride, &cr->stack));
+  }
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  cr->valid = true;
+  return AGGMG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// CG chain form
+// ---------------------------------------------------------------------------------------------
+int cgt_build(aggmg_ctx* ctx, aggmg_smoother* sm, const int64_t* elems, int64_t m1, int64_t nel, int one_based) {
+  aggmg_op* A = sm->A;
+  const int64_t N = A->m;
+  const int64_t p = m1 - 1;
+  if (p < 1 || p > 8 || nel < 1) return AGGMG_OK;  // generic path
+  if (N != nel * p + 1) return AGGMG_OK;
+  const int64_t base = one_based ? 1 : 0;
+  const int m = (int)p;
+  const int64_t ne = nel + 1, Np = ne * m;
+  if (Np >= ((int64_t)1 << 31)) return AGGMG_OK;
+  auto g = std::make_shared<CgtDev>();
+  g->m = m;
+  g->ne = ne;
+  g->N = N;
+  Tmp el64;
+  CHECK(tmp_alloc(ctx, &el64, (size_t)nel * m1 * 8, false));
+  HIPCHK(hipMemcpyAsync(el64.p, elems, (size_t)nel * m1 * 8, hipMemcpyHostToDevice, ctx->stream));
+  CHECK(dalloc(ctx, &g->perm, Np, false));
+  CHECK(dalloc(ctx, &g->inv, N, false));
+  HIPCHK(hipMemsetAsync(g->perm, 0xFF, (size_t)Np * 4, ctx->stream));
+  HIPCHK(hipMemsetAsync(g->inv, 0xFF, (size_t)N * 4, ctx->stream));
+  Flags f;
+  CHECK(f.init(ctx, 4));
+  LAUNCH(chain_perm_kernel, nel, nel, m, N, el64.as<int64_t>(), base, g->perm, f.d);
+  LAUNCH(perm_invert_kernel, Np, Np, (const int32_t*)g->perm, g->inv, f.d);
+  LAUNCH(perm_cover_kernel, N, N, (const int32_t*)g->inv, f.d);
+  int h[4];
+  CHECK(f.read(ctx, h));
+  if (h[0]) return fail(ctx, AGGMG_ERR_DIMENSION, "aggmg_jacobi_setup_elements: node index out of range");
+  if (h[1]) return AGGMG_OK;  // not a chain: generic path
+  CHECK(dalloc(ctx, &g->dblk, Np * m, true));
+  CHECK(dalloc(ctx, &g->subrow, Np, true));
+  CHECK(dalloc(ctx, &g->supcol, Np, true));
+  LAUNCH(chain_scatter_kernel, N, N, m, (const int32_t*)g->inv, (const int32_t*)A->csc.rowptr, (const int32_t*)A->csc.colind,
+         (const double*)A->csc.vals, g->dblk, g->subrow, g->supcol, f.d);
+  LAUNCH(chain_pad_kernel, Np, Np, m, (const int32_t*)g->perm, g->dblk);
+  CHECK(f.read(ctx, h));
+  if (h[2]) return AGGMG_OK;  // couplings beyond the chain pattern: generic path
+  sm->cgt = g;
+  A->cgt = g;
+  return AGGMG_OK;
+}
+
+int cgt_build_transfer(aggmg_ctx* ctx, const aggmg_op* L, const CgtDev& f, const CgtDev* coarse, int hint_mc,
+                       TransferCgt* out, bool* ok) {
+  const int tile_blocks = cgt_tile_blocks(f.m);
+  *ok = false;
+  const int64_t Nf = L->m, Nc = L->n;
+  if (Nf != f.N) return AGGMG_OK;
+  const int M = f.m;
+  const int64_t nel = f.ne - 1, Np = f.ne * M;
+  const int32_t* cp = L->csc.rowptr;
+  const int32_t* rv = L->csc.colind;
+  const double* vv = L->csc.vals;
+  Flags fl;
+  CHECK(fl.init(ctx, 4));
+  int h[4];
+
+  // ---- chain: the coarse level is a CG level on the same elements ------------------------------
+  if (nel > 0 && Nc > 1 && (Nc - 1) % nel == 0 && (Nc - 1) / nel <= 8 && M >= 2) {
+    const int mc = (int)((Nc - 1) / nel);
+    int32_t *cperm = nullptr, *cinv = nullptr;
+    Tmp own_perm, own_inv;
+    bool have = false;
+    if (coarse && coarse->N == Nc && coarse->m == mc && coarse->ne == f.ne) {
+      cperm = coarse->perm;
+      cinv = coarse->inv;
+      have = true;
+    } else if (!coarse) {
+      // the coarse level carries no element lists (the coarsest level has no smoother): read its chain
+      // off L -- a coarse column holding a fine vertex row is that block's vertex, the others are the
+      // interior nodes of the one element whose fine rows they touch, in ascending order
+      CHECK(tmp_alloc(ctx, &own_perm, (size_t)f.ne * mc * 4, false));
+      CHECK(tmp_alloc(ctx, &own_inv, (size_t)Nc * 4, false));
+      cperm = own_perm.as<int32_t>();
+      cinv = own_inv.as<int32_t>();
+      HIPCHK(hipMemsetAsync(cperm, 0xFF, (size_t)f.ne * mc * 4, ctx->stream));
+      HIPCHK(hipMemsetAsync(cinv, 0xFF, (size_t)Nc * 4, ctx->stream));
+      Tmp slots;
+      CHECK(tmp_alloc(ctx, &slots, (size_t)f.ne * 4, true));
+      LAUNCH(chain_coarse_vertices_kernel, Nc, Nc, M, mc, (const int32_t*)f.inv, cp, rv, cperm, cinv, fl.d);
+      LAUNCH(chain_coarse_interiors_kernel, Nc, Nc, M, mc, (const int32_t*)f.inv, cp, rv, cperm, cinv, slots.as<int32_t>(), fl.d);
+      LAUNCH(chain_coarse_sort_kernel, f.ne, f.ne, mc, cperm, cinv, (const int32_t*)slots.as<int32_t>(), nel, fl.d);
+      CHECK(fl.read(ctx, h));
+      have = !h[1];
+      CHECK(fl.clear(ctx));
+    }
+    if (have) {
+      const int w = mc + 1;
+      double* l = nullptr;
+      CHECK(dalloc(ctx, &l, Np * w, true));
+      LAUNCH(chain_transfer_scatter_kernel, Nc, Nc, M, mc, (const int32_t*)f.inv, (const int32_t*)cinv, cp, rv, vv, l, fl.d);
+      CHECK(fl.read(ctx, h));
+      if (!h[0]) {
+        out->l = l;
+        CHECK(dalloc(ctx, &out->cperm, f.ne * mc, false));
+        HIPCHK(hipMemcpyAsync(out->cperm, cperm, (size_t)f.ne * mc * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        out->type = kTrChain;
+        out->mc = mc;
+        out->rho = 1;
+        out->nec = f.ne;
+        *ok = true;
+        return AGGMG_OK;
+      }
+      (void)hipFree(l);
+      CHECK(fl.clear(ctx));
+    }
+  }
+
+  // ---- agglomerating: the coarse level has contiguous blocks of mc DoFs per rho fine elements ---
+  for (int mc = 1; mc <= 16; ++mc) {
+    if (hint_mc > 0 && mc != hint_mc) continue;
+    if (Nc % mc) continue;
+    const int64_t nec = Nc / mc;
+    if (nec == 0 || nel % nec) continue;
+    const int64_t rho = nel / nec;
+    if (rho > 64 || rho * 4 > tile_blocks) continue;
+    double *l = nullptr, *lp = nullptr;
+    CHECK(dalloc(ctx, &l, Np * mc, true));
+    CHECK(dalloc(ctx, &lp, f.ne * mc, true));
+    CHECK(fl.clear(ctx));
+    LAUNCH(agg_transfer_scatter_kernel, Nc, Nc, M, mc, rho, (const int32_t*)f.inv, cp, rv, vv, l, lp, fl.d);
+    CHECK(fl.read(ctx, h));
+    if (h[0]) {
+      (void)hipFree(l);
+      (void)hipFree(lp);
+      continue;
+    }
+    out->l = l;
+    out->lp = lp;
+    out->type = kTrAgg;
+    out->mc = mc;
+    out->rho = (int)rho;
+    out->nec = nec;
+    *ok = true;
+    return AGGMG_OK;
+  }
+  return AGGMG_OK;
+}

@@ -325,6 +325,142 @@ class DistributedVCycle:
 
 
 # ------------------------------------------------------------------------------------------
+# the same schedule inside the library (C ABI aggmg_dist_*): no Python between the launches of a cycle
+# ------------------------------------------------------------------------------------------
+class NativeDistributedVCycle:
+    """DistributedVCycle's schedule executed by libaggmg_hip.so (csrc/dist.hip): one C call per cycle,
+    collectives issued from C++ on the library's stream.
+
+    collectives = 'rccl'      RCCL inside the library (ncclAllGather); the unique id is broadcast once
+                              through the torch.distributed group that is already up
+                  'torch'     a callback into torch.distributed (gloo: host-staged, tests on one GPU;
+                              nccl: device tensors on the library's stream)
+                  'loopback'  device-local copies (rehearsal of one rank's share, measurement only)"""
+
+    def __init__(self, engine, layout, comm, collectives="rccl"):
+        from . import _lib
+        self.e, self.L, self.c = engine, layout, comm
+        ctx = engine.ctx
+        self.ctx = ctx
+        L = layout
+        nl = len(L.m)
+        i64 = lambda v: (ctypes.c_int64 * nl)(*[int(x) for x in v])
+        i32 = lambda v: (ctypes.c_int32 * nl)(*[int(x) for x in v])
+        h = ctypes.c_void_p()
+        ctx.check(ctx.lib.aggmg_dist_create(
+            ctx.handle, engine.H.handle, engine.Hc.handle, L.world, L.rank, nl,
+            i64([o[0] for o in L.own]), i64([o[1] for o in L.own]), i64([o[0] for o in L.loc]), i64([o[1] for o in L.loc]),
+            i64(L.ne), i32(L.m), i32(L.W), ctypes.byref(h)))
+        self.handle = h
+        self.collectives = collectives
+        self.rccl_ranks = None
+        if collectives in ("rccl", "loopback"):
+            # nothing of the cycle goes through torch any more: run on the library's own (capturable,
+            # non-blocking) stream instead of torch's current one; torch-side initialisation of the
+            # vectors is complete after this synchronisation
+            engine.torch.cuda.synchronize()
+            ctx.reset_stream()
+        if collectives == "rccl":
+            self._init_rccl()
+        elif collectives == "torch":
+            self._cb = _lib.ALLGATHER_FN(self._torch_allgather)     # keep the callback object alive
+            ctx.check(ctx.lib.aggmg_dist_set_allgather(ctx.handle, h, ctypes.cast(self._cb, ctypes.c_void_p), None))
+        elif collectives == "loopback":
+            ctx.check(ctx.lib.aggmg_dist_set_loopback(ctx.handle, h))
+        else:
+            raise ValueError("collectives: 'rccl', 'torch' or 'loopback'")
+
+    def _init_rccl(self):
+        """rank 0 creates the RCCL unique id, the existing process group broadcasts its 128 bytes"""
+        import torch
+        from . import _lib
+        ctx, c = self.ctx, self.c
+        buf = (ctypes.c_ubyte * _lib.RCCL_ID_BYTES)()
+        if c.rank == 0:
+            ctx.check(ctx.lib.aggmg_rccl_unique_id(ctx.handle, buf, _lib.RCCL_ID_BYTES))
+        if c.world > 1:
+            t = torch.tensor(list(buf), dtype=torch.uint8)
+            on_dev = (not c.staged) and c.dist.get_backend() == "nccl"
+            if on_dev:
+                t = t.to(self.e.dev)
+            c.dist.broadcast(t, src=0)
+            buf = (ctypes.c_ubyte * _lib.RCCL_ID_BYTES)(*t.cpu().tolist())
+        n = ctypes.c_int(0)
+        ctx.check(ctx.lib.aggmg_dist_init_rccl(ctx.handle, self.handle, buf, _lib.RCCL_ID_BYTES, ctypes.byref(n)))
+        self.rccl_ranks = n.value
+
+    def _torch_allgather(self, user, send, recv, count, stream):
+        """aggmg_allgather_fn: recv[r * count + i] = rank r's send[i], ordered on `stream`"""
+        try:
+            import torch
+            c = self.c
+            if c.staged or c.dist.get_backend() != "nccl":
+                ctx = self.ctx
+                s = np.empty(int(count))
+                ctx.check(ctx.lib.aggmg_memcpy_d2h(ctx.handle, s.ctypes.data, ctypes.c_void_p(send), int(count) * 8))   # syncs the stream
+                o = torch.empty(int(count) * c.world, dtype=torch.float64)
+                c.dist.all_gather_into_tensor(o, torch.from_numpy(s))
+                o = o.numpy()
+                ctx.check(ctx.lib.aggmg_memcpy_h2d(ctx.handle, ctypes.c_void_p(recv), o.ctypes.data, o.size * 8))
+            else:
+                ext = torch.cuda.ExternalStream(int(stream or 0), device=self.e.dev)
+                with torch.cuda.stream(ext):
+                    si = torch.as_tensor(_DevView(send, int(count)), device=self.e.dev)
+                    ro = torch.as_tensor(_DevView(recv, int(count) * c.world), device=self.e.dev)
+                    c.dist.all_gather_into_tensor(ro, si)
+            return 0
+        except Exception:       # an exception must not unwind through the C frames
+            import traceback
+            traceback.print_exc()
+            return 1
+
+    def info(self):
+        ex, ch, be = ctypes.c_int64(0), ctypes.c_int(0), ctypes.c_int(0)
+        self.ctx.check(self.ctx.lib.aggmg_dist_info(self.ctx.handle, self.handle, ctypes.byref(ex), ctypes.byref(ch), ctypes.byref(be)))
+        return dict(exchanges=ex.value, chunked=bool(ch.value), backend=["none", "callback", "rccl", "loopback"][be.value])
+
+    @property
+    def exchanges(self):
+        return self.info()["exchanges"]
+
+    @property
+    def chunked(self):
+        return self.info()["chunked"]
+
+    def exchange_ghosts(self, x, level=0):
+        self.ctx.check(self.ctx.lib.aggmg_dist_exchange_ghosts_dev(self.ctx.handle, self.handle, _p(x), int(level)))
+
+    def allgather(self, out, inp):
+        self.ctx.check(self.ctx.lib.aggmg_dist_allgather_dev(self.ctx.handle, self.handle, _p(inp), _p(out), inp.numel()))
+
+    def graph_info(self):
+        r, c, b = ctypes.c_int64(0), ctypes.c_int(0), ctypes.c_int(0)
+        self.ctx.check(self.ctx.lib.aggmg_dist_graph_info(self.ctx.handle, self.handle, ctypes.byref(r), ctypes.byref(c), ctypes.byref(b)))
+        return dict(replays=r.value, captured=c.value, broken=bool(b.value))
+
+    def vcycle(self, x0, b, x_out, nPre=3, nPost=3, alpha=2.0 / 3.0, x0_ghosts_valid=False, overlap_next=False,
+               graph=False):
+        from . import _lib
+        if nPre > self.L.nPre or nPost > self.L.nPost:
+            raise ValueError("halo widths were sized for fewer sweeps")
+        flags = ((_lib.DIST_X0_GHOSTS_VALID if x0_ghosts_valid else 0) | (_lib.DIST_OVERLAP_NEXT if overlap_next else 0) |
+                 (_lib.DIST_GRAPH if graph else 0))
+        self.ctx.check(self.ctx.lib.aggmg_dist_vcycle_dev(self.ctx.handle, self.handle, _p(x0), _p(b), _p(x_out), int(nPre),
+                                                           int(nPost), float(alpha), flags))
+
+    def free(self):
+        if getattr(self, "handle", None) and self.ctx.handle:
+            self.ctx.lib.aggmg_dist_free(self.ctx.handle, self.handle)
+        self.handle = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+# ------------------------------------------------------------------------------------------
 # HIP engine
 # ------------------------------------------------------------------------------------------
 def main_stream_handle(eng):
@@ -549,7 +685,21 @@ def bench_main(args, rank, world, local_rank, nPre, nPost, alpha):
     t_setup = time.perf_counter()
     layout = RankLayout(n, ratios, [args.p + 1, 2, 2, 2], world, rank, nPre, nPost)
     engine, U = build_local_uniform(n, args.p, 1, ratios, layout, ctx, comm)
-    dv = DistributedVCycle(engine, layout, comm)
+    # the cycle runs inside the library (csrc/dist.hip).  Collectives: RCCL from C++ when the process
+    # group is nccl; AGGMG_DIST_COLLECTIVES=torch routes them through torch.distributed instead (the
+    # gloo rehearsal on a box with fewer GPUs than ranks needs that), =python keeps the Python schedule
+    mode = os.environ.get("AGGMG_DIST_COLLECTIVES", "rccl" if backend == "nccl" else "torch")
+    rccl_note = None
+    if mode == "python":
+        dv = DistributedVCycle(engine, layout, comm)
+    else:
+        try:
+            dv = NativeDistributedVCycle(engine, layout, comm, collectives=mode)
+        except Exception as exc:         # RCCL not loadable / communicator failed: same schedule over torch.distributed
+            if mode != "rccl":
+                raise
+            rccl_note = f"in-library RCCL unavailable ({exc!r}); collectives through torch.distributed"
+            dv = NativeDistributedVCycle(engine, layout, comm, collectives="torch")
     b = torch.from_numpy(U.rhs()).to(engine.dev)        # generated on the whole local domain
     xa = engine.new(layout.local_dofs(0))
     xb = engine.new(layout.local_dofs(0))
@@ -560,22 +710,39 @@ def bench_main(args, rank, world, local_rank, nPre, nPost, alpha):
 
     src, dst = xa, xb
     # every cycle's output is the next cycle's x0 (the loop of multigrid, src/solvers.jl:124-126):
-    # its interface exchange is issued under the fine-level ascent (AGGMG_DIST_OVERLAP=0: in line)
+    # its interface exchange is issued under the fine-level ascent.  AGGMG_DIST_GRAPH=1 lets the library
+    # replay the cycle as a hipGraph (built in untimed pre-warm cycles: first call eager, second captured,
+    # per buffer order); off by default: on one rank's share of an 8-rank 2^24 job the replayed cycle
+    # measured 0.452 ms against 0.430 ms launch by launch (the cycle is GPU-bound, issue time 0.07 ms)
+    use_graph = isinstance(dv, NativeDistributedVCycle) and os.environ.get("AGGMG_DIST_GRAPH", "0") == "1"
+    kw = dict(overlap_next=True)
+    if use_graph:
+        kw["graph"] = True
+        for _ in range(8):
+            dv.vcycle(src, b, dst, nPre, nPost, alpha, **kw)
+            src, dst = dst, src
     for _ in range(args.warmup):
-        dv.vcycle(src, b, dst, nPre, nPost, alpha, overlap_next=True)
+        dv.vcycle(src, b, dst, nPre, nPost, alpha, **kw)
         src, dst = dst, src
     torch.cuda.synchronize()
     comm.barrier()
     torch.cuda.synchronize()
-    ctx.profile_enable(2)   # events around the dominant kernel only (an event pair costs ~7 us of stream time)
+    ex0 = dv.exchanges
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        dv.vcycle(src, b, dst, nPre, nPost, alpha, overlap_next=True)
+        dv.vcycle(src, b, dst, nPre, nPost, alpha, **kw)
         src, dst = dst, src
     torch.cuda.synchronize()
     comm.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    ex_per_cycle = (dv.exchanges - ex0) // max(args.steps, 1)
+    # per-kernel times: an untimed pass with events around the dominant kernel (events cannot ride in a graph)
+    ctx.profile_enable(2)
+    for _ in range(args.steps):
+        dv.vcycle(src, b, dst, nPre, nPost, alpha, overlap_next=True)
+        src, dst = dst, src
+    torch.cuda.synchronize()
     ctx.profile_enable(False)
     prof = ctx.profile_collect()
     dt = comm.max(dt)
@@ -596,8 +763,12 @@ def bench_main(args, rank, world, local_rank, nPre, nPost, alpha):
                                    f"2:1 -> 2:1, V(3,3)) partitioned by contiguous element range over {world} GPUs",
                        "fine_dofs": N, "nPre": nPre, "nPost": nPost,
                        "backend": backend,
+                       "collectives": (getattr(dv, "collectives", "python schedule") if rccl_note is None else rccl_note),
+                       "rccl_ranks": getattr(dv, "rccl_ranks", None),
+                       "hipgraph": (dv.graph_info() if use_graph else None),
                        "parallelism": f"element-range x{world}, deep halos W={layout.W}, "
-                                      f"{dv.exchanges // (args.steps + args.warmup)} RCCL all-gathers per cycle, "
+                                      f"{ex_per_cycle} all-gathers per cycle "
+                                      f"(x0 interface exchange issued under the fine-level ascent), "
                                       + ("coarsest solve: chunk elimination on each rank's own blocks, boundary system replicated"
                                          if dv.chunked else "coarsest solve gathered and replicated")},
             "roofline": {"bound": "hbm", "kernel": f"btd_fused_kernel<{args.p + 1},cmp> {dkind} level {dlevel + 1} (rank 0)",

@@ -256,6 +256,64 @@ int aggmg_copy_segments_dev(aggmg_ctx* ctx, int nseg, const double* const* src, 
                             const int64_t* rows, const int64_t* cols, const int64_t* src_ld,
                             const int64_t* dst_ld);
 
+/* ---- element-partitioned V-cycle inside the library (BASELINE config 4) -----------
+ * The reference is single-process; this is one rank's share of multigrid_v_cycle (src/solvers.jl:19-50)
+ * on a LOCAL hierarchy (owned elements + W_k ghost elements per side and level, created with
+ * AGGMG_COARSE_EXTERNAL) plus a one-level hierarchy holding the GLOBAL coarsest operator, with the
+ * interface exchanges issued by the library on the context's stream: per cycle one all-gather of the
+ * interface elements of x0, and the coarsest solve across ranks (chunk elimination on the rank's own
+ * block range, all-gather of the chunk-boundary system, replicated boundary solve, back substitution,
+ * all-gather of the coarse ghost blocks; small coarsest levels: all-gather of the owned right-hand
+ * side + replicated solve).  Layout arrays have nlevels entries (level 0 finest): owned element range
+ * [own_lo, own_hi), local range [loc_lo, loc_hi) (owned + ghosts, clipped to the domain), global
+ * element counts ne, DoFs per element m, ghost widths W.  Vectors are LOCAL (loc range) device vectors.
+ * Owned results are bitwise those of the single-GPU cycle (tests/test_distributed_gpu.py). */
+typedef struct aggmg_dist aggmg_dist;
+int aggmg_dist_create(aggmg_ctx* ctx, aggmg_hier* local, aggmg_hier* coarse_global, int world, int rank, int nlevels,
+                      const int64_t* own_lo, const int64_t* own_hi, const int64_t* loc_lo, const int64_t* loc_hi,
+                      const int64_t* ne, const int32_t* m, const int32_t* W, aggmg_dist** out);
+int aggmg_dist_free(aggmg_ctx* ctx, aggmg_dist* d);
+/* Collectives, one of:
+ *  - RCCL inside the library: rank 0 calls aggmg_rccl_unique_id, the AGGMG_RCCL_ID_BYTES bytes travel to
+ *    every rank by any means (they are not secret and small), every rank calls aggmg_dist_init_rccl
+ *    (ncclCommInitRank; collective).  librccl.so.1 is loaded with dlopen on first use -- the copy already
+ *    in the process if there is one.  nranks_out receives what the communicator reports.
+ *  - a caller-supplied all-gather: recv_dev[r * count + i] = rank r's send_dev[i], ordered on hip_stream
+ *    after everything enqueued there so far; returns 0 on success.
+ *  - a device-local loop-back (every slot receives the caller's own data): rehearsals of one rank's
+ *    share on a single GPU, measurement only. */
+#define AGGMG_RCCL_ID_BYTES 128
+typedef int (*aggmg_allgather_fn)(void* user, const double* send_dev, double* recv_dev, int64_t count, void* hip_stream);
+int aggmg_rccl_unique_id(aggmg_ctx* ctx, void* id_out, int nbytes);
+int aggmg_dist_init_rccl(aggmg_ctx* ctx, aggmg_dist* d, const void* id, int nbytes, int* nranks_out);
+int aggmg_dist_set_allgather(aggmg_ctx* ctx, aggmg_dist* d, aggmg_allgather_fn fn, void* user);
+int aggmg_dist_set_loopback(aggmg_ctx* ctx, aggmg_dist* d);
+/* One all-gather through the configured backend (count doubles per rank); also the smoke test of it. */
+int aggmg_dist_allgather_dev(aggmg_ctx* ctx, aggmg_dist* d, const double* send_dev, double* recv_dev, int64_t count);
+/* Fill the ghost entries of a local finest- or coarsest-level vector from the neighbours' owned
+ * interface elements (needed once for the right-hand side; the cycle does it for x0 itself). */
+int aggmg_dist_exchange_ghosts_dev(aggmg_ctx* ctx, aggmg_dist* d, double* x_local, int level);
+/* One V-cycle.  x0's ghost entries are overwritten with the neighbours' values unless
+ * AGGMG_DIST_X0_GHOSTS_VALID; b must be valid on the whole local range; on return the owned part of
+ * x_out is the result (its ghosts are not).  AGGMG_DIST_OVERLAP_NEXT: the caller will pass x_out as the
+ * next cycle's x0 (the loop of multigrid, src/solvers.jl:124-126) -- the fine-level ascent then produces
+ * the interface elements first and their all-gather runs on a second stream under the rest of that
+ * launch; the next call only waits for it.  Same arithmetic either way. */
+#define AGGMG_DIST_X0_GHOSTS_VALID 1
+#define AGGMG_DIST_OVERLAP_NEXT 2
+/* AGGMG_DIST_GRAPH: replay the cycle as a hipGraph.  The first call with a given argument tuple is
+ * issued launch by launch, the second is captured (both streams, the collective included) and every
+ * later one is a single hipGraphLaunch.  Falls back to launch-by-launch issue for good when the capture
+ * fails (a collective backend that cannot be captured), with caller-supplied collectives, the host
+ * coarsest solver, or while the event profiler is on.  aggmg_dist_graph_info reports what happened. */
+#define AGGMG_DIST_GRAPH 4
+int aggmg_dist_vcycle_dev(aggmg_ctx* ctx, aggmg_dist* d, double* x0, const double* b, double* x_out, int nPre,
+                          int nPost, double alpha, int flags);
+/* exchanges: all-gathers issued so far; chunked: 1 when the coarsest solve follows the partition;
+ * backend: 0 none, 1 caller-supplied, 2 RCCL, 3 loop-back */
+int aggmg_dist_info(aggmg_ctx* ctx, const aggmg_dist* d, int64_t* exchanges, int* chunked, int* backend);
+int aggmg_dist_graph_info(aggmg_ctx* ctx, const aggmg_dist* d, int64_t* replays, int* captured, int* broken);
+
 /* ---- outer solver loops, device-resident -------------------------------------- */
 /* x . y and ||x||_2 of device vectors (fixed reduction tree: reproducible run to run). */
 int aggmg_dot_dev(aggmg_ctx* ctx, const double* x, const double* y, int64_t n, double* out);

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, n, q, overlap=False):
+def _worker(rank, world, port, n, q, overlap=False, native=False):
     sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle")]
     import torch
     import torch.distributed as dist
@@ -33,7 +33,10 @@ def _worker(rank, world, port, n, q, overlap=False):
         layout = D.RankLayout(n, ratios, [p + 1, 2, 2, 2], world, rank)
         engine, U = D.build_local_uniform(n, p, 1, ratios, layout, ctx, comm)
         assert all(engine.H.structured_levels()) and engine.Hc.coarse_info()['on_device']
-        dv = D.DistributedVCycle(engine, layout, comm)
+        if native:    # the schedule inside libaggmg_hip.so; its all-gathers call back into torch.distributed (gloo)
+            dv = D.NativeDistributedVCycle(engine, layout, comm, collectives="torch")
+        else:
+            dv = D.DistributedVCycle(engine, layout, comm)
         b = torch.from_numpy(U.rhs()).to(engine.dev)
         x = engine.new(layout.local_dofs(0))
         y = engine.new(layout.local_dofs(0))
@@ -133,6 +136,96 @@ def test_four_ranks_overlapped_interface_exchange():
         # cycle 1: x0 + boundary system + coarse ghosts + prefetch; cycles 2, 3: three each
         assert chunked and nex == 10
         assert err == 0.0, (rank, err, scale)
+
+
+@pytest.mark.parametrize("world,n,overlap,nex", [(2, 2048, False, 6), (2, 2**16, False, 9), (4, 2**16, False, 9),
+                                                 (4, 2**16, True, 10)])
+def test_native_schedule_matches_single_gpu(world, n, overlap, nex):
+    """aggmg_dist_vcycle_dev (the schedule in C++, csrc/dist.hip) with its collectives routed through gloo:
+    2 / 4 ranks on the one GPU, replicated and chunked coarsest solve, with and without the overlapped
+    interface exchange -- owned values bitwise those of the single-GPU cycle, same number of all-gathers
+    as the Python schedule"""
+    import torch.multiprocessing as mp
+    from test_distributed_cpu import free_port
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, q, overlap, True)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    for pr in procs:
+        pr.join(900)
+    assert all(pr.exitcode == 0 for pr in procs), [pr.exitcode for pr in procs]
+    for rank, err, scale, got_nex, chunked in sorted(q.get() for _ in range(world)):
+        assert err == 0.0, (rank, err, scale)
+        assert chunked == (n >= 2**16) and got_nex == nex, (chunked, got_nex)
+
+
+def _rccl_in_library_worker(port, q):
+    sys.path[:0] = [ROOT]
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        import agglomerationmultigrid1d_amd as mg
+        from agglomerationmultigrid1d_amd import distributed as D
+        n, ratios, p = 4096, (4, 2, 2), 3
+        ctx = mg.Context(0)
+        comm = D.Comm(1, 0)
+        layout = D.RankLayout(n, ratios, [p + 1, 2, 2, 2], 1, 0)
+        engine, U = D.build_local_uniform(n, p, 1, ratios, layout, ctx, comm)
+        dv = D.NativeDistributedVCycle(engine, layout, comm, collectives="rccl")
+        inp = torch.arange(640, dtype=torch.float64, device="cuda") * 0.25
+        out = torch.zeros(640, dtype=torch.float64, device="cuda")
+        dv.allgather(out, inp)                       # ncclAllGather issued by the library on its stream
+        b = torch.from_numpy(U.rhs()).to(engine.dev)
+        x, y = engine.new(layout.local_dofs(0)), engine.new(layout.local_dofs(0))
+        for _ in range(2):
+            dv.vcycle(x, b, y, overlap_next=True)
+            x, y = y, x
+        torch.cuda.synchronize()
+        # the same two cycles replayed as hipGraphs (ncclAllGather captured): 2 eager + 2 captures + 4 replays
+        x2, y2 = engine.new(layout.local_dofs(0)), engine.new(layout.local_dofs(0))
+        for rep in range(4):
+            x2.zero_(), y2.zero_()
+            torch.cuda.synchronize()     # torch's stream and the library's own stream are not ordered otherwise
+            dv.vcycle(x2, b, y2, overlap_next=True, graph=True)
+            dv.vcycle(y2, b, x2, overlap_next=True, graph=True)
+            torch.cuda.synchronize()
+        ginfo = dv.graph_info()
+        gerr = float(torch.max(torch.abs(x2 - x)).item())
+        from agglomerationmultigrid1d_amd.uniform import UniformDgAggHierarchy, build_device_hierarchy
+        Hg = build_device_hierarchy(UniformDgAggHierarchy(n, p=p, pAgg=1, ratios=ratios), ctx)
+        xa, xb, bg = ctx.to_device(np.zeros(4 * n)), ctx.alloc(4 * n), ctx.to_device(U.rhs())
+        for _ in range(2):
+            Hg.vcycle_dev(xa, bg, xb)
+            xa, xb = xb, xa
+        q.put((bool(torch.equal(out, inp)), dv.rccl_ranks, dv.info()["backend"],
+               float(np.max(np.abs(x.cpu().numpy() - xa.download()))), ginfo, gerr))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_inside_the_library_single_rank():
+    """aggmg_rccl_unique_id / aggmg_dist_init_rccl / ncclAllGather from C++ (librccl loaded with dlopen, the copy
+    torch already holds) on the one rank a single-GPU box allows, and the native cycle on top of it"""
+    import torch.multiprocessing as mp
+    from test_distributed_cpu import free_port
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    pr = ctx.Process(target=_rccl_in_library_worker, args=(free_port(), q))
+    pr.start()
+    pr.join(600)
+    assert pr.exitcode == 0
+    same, ranks, backend, err, ginfo, gerr = q.get()
+    assert same and ranks == 1 and backend == "rccl" and err == 0.0
+    # graph replay gives the same bits; if RCCL could not be captured the library stays eager and says so
+    assert gerr == 0.0
+    assert (ginfo["captured"] == 2 and ginfo["replays"] >= 4) or ginfo["broken"], ginfo
 
 
 def _nccl_worker(port, q):

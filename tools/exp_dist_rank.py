@@ -47,6 +47,9 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--profile", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="AGGMG_DIST_GRAPH: replay the cycle as a hipGraph")
+    ap.add_argument("--python-schedule", action="store_true",
+                    help="the Python schedule (one ctypes / torch call per launch) instead of aggmg_dist_vcycle_dev")
     args = ap.parse_args()
     import torch
     from agglomerationmultigrid1d_amd import _lib
@@ -88,28 +91,38 @@ def main():
     Ac = mg.DeviceOperator(_csc(colptr, rowval, nzval, (N, N)), _lib.OP_STIFFNESS, ctx)
     Hc = mg.MeshHierarchy(None, [Ac], [], [], ctx=ctx, keep_host=False, coarse_mode=_lib.COARSE_AUTO)
     engine = D.HipEngine(H, Hc, ctx)
-    dv = D.DistributedVCycle(engine, layout, comm)
+    if args.python_schedule:
+        dv = D.DistributedVCycle(engine, layout, comm)
+    else:   # the schedule inside the library with its device-local loop-back "all-gather"
+        dv = D.NativeDistributedVCycle(engine, layout, comm, collectives="loopback")
     b = torch.from_numpy(U.rhs()).to(engine.dev)
     xa = engine.new(layout.local_dofs(0))
     xb = engine.new(layout.local_dofs(0))
     src, dst = xa, xb
+    kw = dict(overlap_next=True)
+    if args.graph:
+        kw["graph"] = True
+        args.warmup = max(args.warmup, 8)      # eager, capture, then replays
     for _ in range(args.warmup):
-        dv.vcycle(src, b, dst, nPre, nPost, alpha, overlap_next=True)
+        dv.vcycle(src, b, dst, nPre, nPost, alpha, **kw)
         src, dst = dst, src
     torch.cuda.synchronize()
     if args.profile:
         ctx.profile_enable(1)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        dv.vcycle(src, b, dst, nPre, nPost, alpha, overlap_next=True)
+        dv.vcycle(src, b, dst, nPre, nPost, alpha, **kw)
         src, dst = dst, src
     t_issue = time.perf_counter() - t0
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     out = {"world": args.world, "rank": args.rank, "log2_elems": args.log2_elems, "chunked": dv.chunked,
            "W": layout.W, "ms_per_cycle": 1e3 * dt / args.steps, "ms_issue_per_cycle": 1e3 * t_issue / args.steps,
-           "collectives_per_cycle": comm.calls // (args.steps + args.warmup),
+           "schedule": "python" if args.python_schedule else "library (aggmg_dist_vcycle_dev)",
+           "collectives_per_cycle": (comm.calls if args.python_schedule else dv.exchanges) // (args.steps + args.warmup),
            "projected_value_if_all_ranks_alike": n * (p + 1) * (nPre + nPost) * args.steps / dt}
+    if args.graph:
+        out["graph"] = dv.graph_info()
     if args.profile:
         ctx.profile_enable(0)
         prof = ctx.profile_collect()
