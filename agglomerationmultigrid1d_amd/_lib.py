@@ -85,6 +85,12 @@ SYMBOLS = {
     "aggmg_op_shape": (c_int, [_P, _P, POINTER(c_int64), POINTER(c_int64), POINTER(c_int64)]),
     "aggmg_op_download": (c_int, [_P, _P, c_int, POINTER(c_int32), POINTER(c_int32), _PD]),
     "aggmg_op_release_host": (c_int, [_P, _P]),
+    "aggmg_bd_sp_apply": (c_int, [_P, _P, _P, c_int, POINTER(_P)]),
+    "aggmg_sp_matmul": (c_int, [_P, _P, _P, c_int, POINTER(_P)]),
+    "aggmg_sp_sub": (c_int, [_P, _P, _P, c_int, POINTER(_P)]),
+    "aggmg_op_transpose": (c_int, [_P, _P, c_int, POINTER(_P)]),
+    "aggmg_op_download_csc": (c_int, [_P, _P, POINTER(c_int32), POINTER(c_int32), _PD]),
+    "aggmg_smoother_download_blocks": (c_int, [_P, _P, _PD]),
     "aggmg_blockjacobi_setup": (c_int, [_P, _P, c_int64, c_int64, POINTER(c_int64), c_int, c_int,
                                         POINTER(_P)]),
     "aggmg_blockdiag_setup": (c_int, [_P, c_int64, c_int64, _PD, c_int, POINTER(_P)]),

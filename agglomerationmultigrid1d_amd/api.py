@@ -201,6 +201,47 @@ class DeviceOperator:
         self.nnz = int(nzval.size)
         self.kind = kind
 
+    @classmethod
+    def _from_handle(cls, ctx, handle, kind):
+        """wrap an operator the library produced (aggmg_sp_matmul, aggmg_bd_sp_apply, ...)"""
+        self = cls.__new__(cls)
+        self.ctx, self.handle, self.kind = ctx, handle, kind
+        m, n, nnz = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int64(0)
+        ctx.check(ctx.lib.aggmg_op_shape(ctx.handle, handle, ctypes.byref(m), ctypes.byref(n), ctypes.byref(nnz)))
+        self.shape, self.nnz = (m.value, n.value), nnz.value
+        return self
+
+    def to_scipy(self):
+        """the operator as a SciPy CSC matrix (C ABI aggmg_op_download_csc): stored entries, zeros included"""
+        cp = np.empty(self.shape[1] + 1, dtype=np.int32)
+        rv = np.empty(self.nnz, dtype=np.int32)
+        nz = np.empty(self.nnz)
+        self.ctx.check(self.ctx.lib.aggmg_op_download_csc(
+            self.ctx.handle, self.handle, cp.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
+            rv.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), _pd(nz)))
+        return sp.csc_matrix((nz, rv, cp), shape=self.shape)
+
+    def _binary(self, fn, other, kind):
+        other = _as_op(other, kind, self.ctx)
+        h = ctypes.c_void_p()
+        self.ctx.check(fn(self.ctx.handle, self.handle, other.handle, int(kind), ctypes.byref(h)))
+        return DeviceOperator._from_handle(self.ctx, h, kind)
+
+    def matmul(self, B, kind=_lib.OP_STIFFNESS):
+        """`A * B` for two sparse matrices on the device (C ABI aggmg_sp_matmul): the products of
+        `L'*X*L` and `D*(M_LU\\G)`, src/mesh_heirarchy.jl:71-72,79-84"""
+        return self._binary(self.ctx.lib.aggmg_sp_matmul, B, kind)
+
+    def sub(self, B, kind=_lib.OP_STIFFNESS):
+        """`A - B`, numerically-zero results dropped as SparseArrays does (C ABI aggmg_sp_sub)"""
+        return self._binary(self.ctx.lib.aggmg_sp_sub, B, kind)
+
+    def transpose(self, kind=_lib.OP_STIFFNESS):
+        """the adjoint as an operator of its own (C ABI aggmg_op_transpose)"""
+        h = ctypes.c_void_p()
+        self.ctx.check(self.ctx.lib.aggmg_op_transpose(self.ctx.handle, self.handle, int(kind), ctypes.byref(h)))
+        return DeviceOperator._from_handle(self.ctx, h, kind)
+
     def download(self, transposed=False):
         """Device index maps and values: (rowptr, colind, vals), 0-based int32 CSR of the matrix
         (or of its transpose)."""
@@ -304,6 +345,18 @@ class _BlockSmoother(AbstractSmoother):
                                               ctypes.byref(h)))
         self.handle = h
 
+    def inverse_blocks(self):
+        """the explicit inverses of the pivoted block LUs, (nb, m, m): what the device factorisation (K6)
+        produced from A[inds, inds] (C ABI aggmg_smoother_download_blocks)"""
+        m, nb = self.mBlockInds.shape
+        return _download_blocks(self.A.ctx, self.handle, nb, m)
+
+
+def _download_blocks(ctx, handle, nb, m):
+    out = np.empty((nb, m, m))
+    ctx.check(ctx.lib.aggmg_smoother_download_blocks(ctx.handle, handle, _pd(out)))
+    return out
+
 
 class BlockJacobi(_BlockSmoother):
     """BlockJacobi{mBlocks::Vector{LU}, mBlockInds} src/smoother.jl:64-81.  Blocks are
@@ -339,6 +392,14 @@ class _BlockObject(AbstractSmoother):
         if getattr(self, "handle", None) and self._ctx.handle:
             self._ctx.lib.aggmg_smoother_free(self._ctx.handle, self.handle)
         self.handle = None
+
+    def _apply_sparse(self, S, kind):
+        """block object times a sparse matrix -> DeviceOperator (C ABI aggmg_bd_sp_apply)"""
+        S = _as_op(S, kind, self._ctx)
+        h = ctypes.c_void_p()
+        c = self._ctx
+        c.check(c.lib.aggmg_bd_sp_apply(c.handle, self.handle, S.handle, int(kind), ctypes.byref(h)))
+        return DeviceOperator._from_handle(c, h, kind)
 
     def _apply(self, B):
         B = np.asarray(B, dtype=np.float64)
@@ -387,8 +448,12 @@ class BlockDiagonal:
         return _BlockObject(c, h, self.shape[0])
 
     def __matmul__(self, B):
+        """`A * x`, `A * B` (dense: mul!, :166-176) and `A * S` for a sparse S (SciPy sparse or DeviceOperator:
+        bd_sp_matmul, :195-264 -> DeviceOperator)"""
         if self._dev is None:
             self._dev = self._setup(False)
+        if sp.issparse(B) or isinstance(B, DeviceOperator):
+            return self._dev._apply_sparse(B, _lib.OP_STIFFNESS)
         return self._dev._apply(B)
 
     mul = __matmul__
@@ -417,7 +482,11 @@ class BlockDiagonalLU:
     def shape(self):
         return (self._dev.N, self._dev.N)
 
-    def solve(self, B):
+    def solve(self, B, kind=_lib.OP_STIFFNESS):
+        """`A \\ x`, `A \\ B` (dense: ldiv!, :299-309) and `A \\ S` for a sparse S (bd_sp_solve, :314-383
+        -> DeviceOperator)"""
+        if sp.issparse(B) or isinstance(B, DeviceOperator):
+            return self._dev._apply_sparse(B, kind)
         return self._dev._apply(B)
 
     ldiv = solve
@@ -552,6 +621,46 @@ class MeshHierarchy:
                    getattr(H, "mBdConds", None), getattr(H, "mGradient", None),
                    getattr(H, "mDivergence", None), getattr(H, "mC", None), ctx=ctx,
                    coarse_mode=coarse_mode)
+
+    @classmethod
+    def from_dg_operators(cls, mMeshes, A, G, D, C, mInterpolation, mMassMatrices, ctx=None, keep_host=True,
+                          coarse_mode=_lib.COARSE_AUTO):
+        """MeshHierarchy(mMeshes, mBdConds, A, G, D, C; nDG, nAgg) (src/mesh_heirarchy.jl:140-181, with the
+        agglomerated levels of SURVEY D4) given the interpolation matrices L_k and the mass matrices
+        (BlockDiagonal) of the coarser levels: the recurrences of :79-84 / :98-103 run on the device --
+
+            G_{k+1} = L' * G_k * L,  D_{k+1} = L' * D_k * L,  C_{k+1} = L' * C_k * L
+            A_{k+1} = C_{k+1} - D_{k+1} * (M_LU \\ G_{k+1})
+            mSmoothers[k] = dg_smoother(mMeshes[k], A_k, :blockJac)
+
+        (aggmg_op_transpose, aggmg_sp_matmul, aggmg_bd_sp_apply, aggmg_sp_sub, aggmg_blockjacobi_setup).
+        mMeshes[k] need `mBlockInds` (or `mElements` / `mP`); mMassMatrices[k] is the BlockDiagonal of
+        level k + 1.  The Galerkin operators stay in HBM; H.mGradient / mDivergence / mC / mStiffness hold
+        DeviceOperators (`.to_scipy()` reads one back)."""
+        ctx = ctx or default_context()
+        n = len(mMeshes)
+        if n < 1:
+            raise ArgumentError("At least one DG mesh required.")
+        if len(mInterpolation) != n - 1 or len(mMassMatrices) != n - 1:
+            raise ArgumentError("Length of vector of meshes does not match inputed number of DG and "
+                                "agglomerated meshes.")
+        St = [_as_op(A, _lib.OP_STIFFNESS, ctx)]
+        Gs, Ds, Cs = [_as_op(G, _lib.OP_STIFFNESS, ctx)], [_as_op(D, _lib.OP_STIFFNESS, ctx)], [_as_op(C, _lib.OP_STIFFNESS, ctx)]
+        Ls = [_as_op(L, _lib.OP_TRANSFER, ctx) for L in mInterpolation]
+        for k in range(n - 1):
+            L = Ls[k]
+            Lt = L.transpose()
+            Gs.append(Lt.matmul(Gs[k]).matmul(L))         # (L' * G) * L, left to right as Julia evaluates it
+            Ds.append(Lt.matmul(Ds[k]).matmul(L))
+            Cs.append(Lt.matmul(Cs[k]).matmul(L))
+            M = mMassMatrices[k]
+            Mlu = M if isinstance(M, BlockDiagonalLU) else M.lu()
+            St.append(Cs[k + 1].sub(Ds[k + 1].matmul(Mlu.solve(Gs[k + 1]))))
+            Lt.free()
+        sms = [BlockJacobi(St[k], _mesh_block_inds(mMeshes[k]), ctx) for k in range(n - 1)]
+        H = cls(mMeshes, St, sms, Ls, mGradient=Gs, mDivergence=Ds, mC=Cs, ctx=ctx, keep_host=keep_host,
+                coarse_mode=coarse_mode)
+        return H
 
     @property
     def nlevels(self):
@@ -738,7 +847,8 @@ def multigrid(H, x0, b, maxiter, tol, exact=True, check_every=1):
         dx, ncyc, res = multigrid_dev(H, c.to_device(x0), c.to_device(b), maxiter, tol, check_every)
         return dx.download(), (ncyc if check_every > 1 else len(res)), res, []
     x = np.zeros(len(x0))
-    u_exact = spla.spsolve(sp.csc_matrix(H.mStiffness[0]), b)
+    A0 = H.mStiffness[0]
+    u_exact = spla.spsolve(sp.csc_matrix(A0.to_scipy() if isinstance(A0, DeviceOperator) else A0), b)
     err, res = [], []
     nb = np.linalg.norm(b, 2)
     if check_every <= 1:

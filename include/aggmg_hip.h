@@ -84,7 +84,7 @@ int aggmg_op_shape(aggmg_ctx* ctx, const aggmg_op* op, int64_t* m, int64_t* n, i
  * transposed != 0: CSR of its transpose (rowptr[n+1], ...), transfers only.  0-based int32. */
 int aggmg_op_download(aggmg_ctx* ctx, const aggmg_op* op, int transposed, int32_t* rowptr,
                       int32_t* colind, double* vals);
-/* Free the host-side copy kept for smoother set-up once all smoothers on this op exist. */
+/* No-op, kept for ABI compatibility: the library keeps no host copy of an operator (set-up runs on the device). */
 int aggmg_op_release_host(aggmg_ctx* ctx, aggmg_op* op);
 
 /* ---- smoothers: src/smoother.jl ------------------------------------------------------------- */
@@ -133,6 +133,30 @@ int aggmg_smoother_apply(aggmg_ctx* ctx, aggmg_smoother* sm, const double* B, in
 /* 1 when the (operator, smoother) pair was recognised as block-tridiagonal with contiguous
  * aligned element blocks and runs the LDS-tiled fused kernels; 0 = generic CSR path. */
 int aggmg_smoother_is_structured(aggmg_ctx* ctx, const aggmg_smoother* sm, int* out);
+
+/* ---- sparse set-up operations on the device ---------------------------
+ * The products the reference's hierarchy constructors are made of, on operators that are already in
+ * HBM; every result is an ordinary operator (aggmg_op) in CSC form.
+ * aggmg_bd_sp_apply: `A * S` for A::BlockDiagonal (bd_sp_matmul / bd_sp_colmul, src/block_diagonal.jl:195-264)
+ * or `A \ S` for A::BlockDiagonalLU (bd_sp_solve / bd_sp_colsolve, :314-383) with a sparse S: bd is the block
+ * object of aggmg_blockdiag_setup (factorize = 0 / 1).  As in the reference, every column of the result
+ * holds ALL m rows of each block its column of S touches (zeros included).  The solve applies the explicit
+ * inverse of the pivoted LU (the reference runs getrs per block: equal up to round-off).
+ * aggmg_sp_matmul: A * B; aggmg_sp_sub: A - B with numerically-zero results dropped (SparseArrays' `-`,
+ * SURVEY.md 9.4); aggmg_op_transpose: the adjoint as an operator of its own.  With them
+ *     G_c = L' * G * L,   A_c = C_c - D_c * (M_LU \ G_c)          src/mesh_heirarchy.jl:71-72,79-84,98-103
+ * run on the device (agglomerationmultigrid1d_amd.api.MeshHierarchy.from_dg_operators).  One thread
+ * per result column, accumulation in SparseArrays' order; columns longer than 128 rows are refused
+ * (AGGMG_ERR_UNSUPPORTED).  kind: AGGMG_OP_STIFFNESS or AGGMG_OP_TRANSFER for the result. */
+int aggmg_bd_sp_apply(aggmg_ctx* ctx, aggmg_smoother* bd, aggmg_op* S, int kind, aggmg_op** out);
+int aggmg_sp_matmul(aggmg_ctx* ctx, aggmg_op* A, aggmg_op* B, int kind, aggmg_op** out);
+int aggmg_sp_sub(aggmg_ctx* ctx, aggmg_op* A, aggmg_op* B, int kind, aggmg_op** out);
+int aggmg_op_transpose(aggmg_ctx* ctx, aggmg_op* A, int kind, aggmg_op** out);
+/* The CSC arrays of an operator (colptr[n+1], rowval[nnz], nzval[nnz], 0-based int32) and the dense blocks
+ * of a block smoother / block object ([nb][m][m] row-major: the inverses, or the matrices of a
+ * factorize = 0 object): read-back for the parity tests of the set-up products. */
+int aggmg_op_download_csc(aggmg_ctx* ctx, const aggmg_op* op, int32_t* colptr, int32_t* rowval, double* nzval);
+int aggmg_smoother_download_blocks(aggmg_ctx* ctx, const aggmg_smoother* sm, double* out);
 
 /* ---- fused hot-path operations -------------------------------------------------------------- */
 /* nsweeps x  `u += apply_smoother(S, b - A*u; alpha)`   src/solvers.jl:32-35,43-46, :199 */
