@@ -1,10 +1,10 @@
 // libaggmg_hip.so -- host side of the C ABI declared in include/aggmg_hip.h.
 //
-// What lives here: format conversion on upload (Julia CSC Int64 -> device CSR int32, plus the
-// index-free block-tridiagonal form when the pattern allows it), smoother set-up (block
-// extraction + partial-pivot LU inverse), launch logic for the kernels in kernels.hpp, the
-// on-device V-cycle driver and the HIP-event profiler.  No CPU compute fallback exists: every
-// hot-path entry point launches HIP kernels or fails.
+// What lives here: the context, operator / smoother / hierarchy handles, launch logic for the kernels
+// in kernels.hpp, the on-device V-cycle driver, the outer solver loops and the HIP-event profiler.
+// Set-up (upload, block LU, structured forms, cyclic-reduction factors) runs on the device: setup.hip;
+// the CG chain path: cgt.hip; element-partitioned runs: dist.hip; sparse set-up products: spops.hip.
+// No CPU compute fallback exists: every hot-path entry point launches HIP kernels or fails.
 #include "internal.hpp"
 
 // ---------------------------------------------------------------------------------------------
@@ -1285,6 +1285,27 @@ extern "C" int aggmg_vcycles_dev(aggmg_ctx* ctx, aggmg_hier* h, const double* x0
   Level& l0 = h->lv[0];
   const bool fusable = n >= 2 && l0.S && l0.S->btd && l0.S->A == l0.A && l0.tb && (l0.tb->ld || h->restriction == AGGMG_RESTRICT_EXPLICIT) &&
                        btd_fits(*l0.S, nPre + nPost, 1) && !l0.S->gs;
+  if (n >= 2 && l0.cgt_fused && ncycles > 1) {
+    // CG chain fine level: the same cross-cycle fusion with the chain kernel
+    h->last_coarse_ms = 0.0;
+    auto rest = [&]() -> int {  // levels 1.. of one cycle (their right-hand side is in place)
+      Level& c = h->lv[n - 1];
+      CHECK(coarse_solve(ctx, h, c.rhs, c.u[0]));
+      if (n > 2) CHECK(vcycle_up(ctx, h, b, nPost, alpha, nullptr, 1));
+      return AGGMG_OK;
+    };
+    CHECK(vcycle_down(ctx, h, x0, b, nPre, alpha, 0));
+    CHECK(rest());
+    double* cur = l0.u[0];
+    double* alt = l0.u[1];
+    for (int cyc = 1; cyc < ncycles; ++cyc) {
+      CHECK(cgt_mid(ctx, h, cur, alt, b, nPost + nPre, alpha));
+      std::swap(cur, alt);
+      CHECK(vcycle_down(ctx, h, nullptr, b, nPre, alpha, 1));
+      CHECK(rest());
+    }
+    return cgt_up(ctx, h, 0, b, nPost, alpha, x_out, cur);
+  }
   if (!fusable || ncycles == 1) {
     // plain sequence; intermediate iterates ping-pong between two vectors owned by the hierarchy
     if (ncycles > 1)

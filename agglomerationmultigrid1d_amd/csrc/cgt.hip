@@ -80,6 +80,7 @@ static CgtArgs cgt_args(const CgtDev& g) {
   std::memset(&a, 0, sizeof(a));
   a.lv = CgtLevel{g.dblk, g.subrow, g.supcol, g.ne};
   a.perm = g.perm;
+  a.affine = g.affine ? 1 : 0;
   return a;
 }
 
@@ -214,27 +215,57 @@ int cgt_down(aggmg_ctx* ctx, aggmg_hier* h, int k, const double* uin, const doub
 }
 
 // ascending half (src/solvers.jl:41-47): prolongation-add, nPost sweeps
-int cgt_up(aggmg_ctx* ctx, aggmg_hier* h, int k, const double* rhs, int nPost, double alpha, double* dst) {
+// src: the pre-smoothed iterate in block order (default: the level's u[0])
+int cgt_up(aggmg_ctx* ctx, aggmg_hier* h, int k, const double* rhs, int nPost, double alpha, double* dst, const double* src) {
   const int n = (int)h->lv.size();
   Level& l = h->lv[k];
   Level& c = h->lv[k + 1];
   const CgtDev& g = *l.S->cgt;
   CgtChain ch;
-  ch.src = l.u[0];
+  ch.src = src ? src : l.u[0];
   ch.src_ext = false;
   ch.b = rhs;
   ch.b_ext = (k == 0) || !l.native_io;
   ch.dst = dst;
   ch.dst_ext = (k == 0) || !l.native_io;
-  // launch 0 consumes u[0] and writes tmp; launch 1 may then overwrite u[0], and so on
+  // launch 0 consumes the source and writes tmp; launch 1 may then overwrite the source, and so on
   ch.t0 = l.tmp;
-  ch.t1 = l.u[0];
+  ch.t1 = const_cast<double*>(ch.src);
   CgtArgs first, none;
   std::memset(&first, 0, sizeof(first));
   std::memset(&none, 0, sizeof(none));
   first.tin = cgt_xfer(*l.tc, c.native_io);
   first.uc = (k + 1 == n - 1) ? c.u[0] : c.u[1];
   return cgt_run(ctx, g, ch, alpha, nPost, first, none, AGGMG_KIND_FUSED_UP, k);
+}
+
+// Between two cycles of multigrid()'s loop (src/solvers.jl:124-126) the fine level post-smooths and then
+// pre-smooths the same iterate with the same right-hand side: prolongation-add, nPost + nPre sweeps,
+// residual and restriction in ONE launch -- the fine operator is read once per cycle instead of twice.
+// cur -> alt, both in block order; b is the caller's vector.
+int cgt_mid(aggmg_ctx* ctx, aggmg_hier* h, const double* cur, double* alt, const double* b, int nsweeps, double alpha) {
+  const int n = (int)h->lv.size();
+  Level& l = h->lv[0];
+  Level& c = h->lv[1];
+  const CgtDev& g = *l.S->cgt;
+  CgtChain ch;
+  ch.src = cur;
+  ch.src_ext = false;
+  ch.b = b;
+  ch.b_ext = true;
+  ch.dst = alt;
+  ch.dst_ext = false;
+  ch.t0 = l.tmp;
+  if (nsweeps > 2 * cgt_max_sweeps(g.m)) CHECK(scratch(ctx, 0, g.ne * g.m, &ch.t1));
+  CgtArgs first, last;
+  std::memset(&first, 0, sizeof(first));
+  std::memset(&last, 0, sizeof(last));
+  first.tin = cgt_xfer(*l.tc, c.native_io);
+  first.uc = (1 == n - 1) ? c.u[0] : c.u[1];
+  last.do_residual = 1;
+  last.tout = cgt_xfer(*l.tc, c.native_io);
+  last.rc_out = c.rhs;
+  return cgt_run(ctx, g, ch, alpha, nsweeps, first, last, AGGMG_KIND_FUSED_MID, 0);
 }
 
 // ---------------------------------------------------------------------------------------------

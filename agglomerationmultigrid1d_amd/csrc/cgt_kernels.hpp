@@ -53,6 +53,8 @@ struct CgtXfer {
 struct CgtArgs {
   CgtLevel lv;
   const int32_t* perm;  // [ne*M] block order -> caller's numbering, -1 for padding rows
+  int affine;           // the order is the reference's own (vertices 0..ne-1, then M-1 interior nodes per element,
+                        // src/cg_mesh.jl:37-45,59-65): caller-side indices are computed instead of read from perm
   int ext;              // CgtExt mask
   const double* u_in;   // nullptr: iterate starts at zero (src/solvers.jl:29-31)
   const double* b;
@@ -132,7 +134,12 @@ __global__ __launch_bounds__(NT) void cgt_fused_kernel(CgtArgs a) {
 #pragma unroll
         for (int j = 0; j < (GRP ? 1 : M); ++j) sr[s][j] = a.lv.subrow[e * M + j];
       }
-      if (a.ext) pr[s] = a.perm[row];
+      if (a.ext) {
+        if (a.affine)
+          pr[s] = i == 0 ? (int32_t)e : (e == ne - 1 ? -1 : (int32_t)(ne + e * (M - 1) + (i - 1)));
+        else
+          pr[s] = a.perm[row];
+      }
       const int64_t rb = (a.ext & kExtB) ? (int64_t)pr[s] : row;
       if (rb >= 0) bb[s] = a.b[rb];
       if (a.u_in) {

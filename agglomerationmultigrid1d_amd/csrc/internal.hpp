@@ -15,7 +15,6 @@
 #include <cstring>
 #include <memory>
 #include <string>
-#include <thread>
 #include <vector>
 
 #include "kernels.hpp"
@@ -64,6 +63,7 @@ struct CsrDev {
   CsrView view() const { return CsrView{rowptr, colind, vals, nrows}; }
 };
 
+// host copy of a CSR (only the host banded LU fallback of the coarsest solve reads an operator back)
 struct HostCsr {
   std::vector<int32_t> rowptr, colind;
   std::vector<double> vals;
@@ -94,6 +94,7 @@ struct CgtDev {
   double *dblk = nullptr, *subrow = nullptr, *supcol = nullptr;
   int32_t* perm = nullptr;  // [ne*m] block order -> reference numbering, -1 = padding
   int32_t* inv = nullptr;   // [N]    reference numbering -> block order
+  bool affine = false;      // perm is the reference's vertices-first numbering: the kernel computes it
   ~CgtDev() {
     for (void* p : {(void*)dblk, (void*)subrow, (void*)supcol, (void*)perm, (void*)inv})
       if (p) (void)hipFree(p);
@@ -228,42 +229,6 @@ struct aggmg_hier {
 inline int default_restriction() { return AGGMG_RESTRICT_EXPLICIT; }
 
 // ---------------------------------------------------------------------------------------------
-// host-side parallel loop for the O(n) set-up passes (block extraction / inversion, format
-// conversion, cyclic-reduction factorisation).  Plain std::thread: no OpenMP runtime is pulled
-// into a process that already hosts numpy's and torch's.
-// ---------------------------------------------------------------------------------------------
-inline int setup_threads() {
-  static int n = [] {
-    const char* e = std::getenv("AGGMG_SETUP_THREADS");
-    int v = e ? std::atoi(e) : 0;
-    if (v <= 0) {
-      v = (int)std::thread::hardware_concurrency();
-      if (const char* o = std::getenv("OMP_NUM_THREADS")) v = std::min(v, std::max(1, std::atoi(o)));
-      v = std::min(v, 16);
-    }
-    return std::max(1, v);
-  }();
-  return n;
-}
-
-template <typename F>
-inline void parallel_for(int64_t n, F&& body) {  // body(begin, end)
-  const int nt = (int)std::min<int64_t>(setup_threads(), std::max<int64_t>(1, n / 4096));
-  if (nt <= 1) {
-    body((int64_t)0, n);
-    return;
-  }
-  std::vector<std::thread> th;
-  const int64_t chunk = (n + nt - 1) / nt;
-  for (int t = 0; t < nt; ++t) {
-    const int64_t b = t * chunk, e = std::min(n, b + chunk);
-    if (b >= e) break;
-    th.emplace_back([&body, b, e] { body(b, e); });
-  }
-  for (auto& t : th) t.join();
-}
-
-// ---------------------------------------------------------------------------------------------
 // error helpers
 // ---------------------------------------------------------------------------------------------
 inline int fail(aggmg_ctx* ctx, int code, const std::string& msg) {
@@ -356,7 +321,9 @@ int cgt_smooth_ext(aggmg_ctx* ctx, const CgtDev& g, const double* u_in, const do
                    double* u_out, int level);
 int cgt_residual_ext(aggmg_ctx* ctx, const CgtDev& g, const double* u, const double* b, double* r_out);
 int cgt_down(aggmg_ctx* ctx, aggmg_hier* h, int k, const double* uin, const double* rhs, int nPre, double alpha);
-int cgt_up(aggmg_ctx* ctx, aggmg_hier* h, int k, const double* rhs, int nPost, double alpha, double* dst);
+int cgt_up(aggmg_ctx* ctx, aggmg_hier* h, int k, const double* rhs, int nPost, double alpha, double* dst,
+           const double* src = nullptr);
+int cgt_mid(aggmg_ctx* ctx, aggmg_hier* h, const double* cur, double* alt, const double* b, int nsweeps, double alpha);
 
 // ---------------------------------------------------------------------------------------------
 // device-side set-up (setup.hip)

@@ -615,10 +615,12 @@ int cgt_build(aggmg_ctx* ctx, aggmg_smoother* sm, const int64_t* elems, int64_t 
   LAUNCH(chain_perm_kernel, nel, nel, m, N, el64.as<int64_t>(), base, g->perm, f.d);
   LAUNCH(perm_invert_kernel, Np, Np, (const int32_t*)g->perm, g->inv, f.d);
   LAUNCH(perm_cover_kernel, N, N, (const int32_t*)g->inv, f.d);
+  LAUNCH(chain_affine_check_kernel, Np, ne, m, (const int32_t*)g->perm, f.d);
   int h[4];
   CHECK(f.read(ctx, h));
   if (h[0]) return fail(ctx, AGGMG_ERR_DIMENSION, "aggmg_jacobi_setup_elements: node index out of range");
   if (h[1]) return AGGMG_OK;  // not a chain: generic path
+  g->affine = !h[3];
   CHECK(dalloc(ctx, &g->dblk, Np * m, true));
   CHECK(dalloc(ctx, &g->subrow, Np, true));
   CHECK(dalloc(ctx, &g->supcol, Np, true));

@@ -788,6 +788,17 @@ __global__ __launch_bounds__(kSetupThreads) void chain_perm_kernel(int64_t nel, 
   if (e == nel - 1) perm[nel * m] = (int32_t)(elems[e * m1 + 1] - base);
 }
 
+// is the block order the reference's vertices-first numbering itself?  flags[3] raised if not
+__global__ __launch_bounds__(kSetupThreads) void chain_affine_check_kernel(int64_t ne, int m, const int32_t* __restrict__ perm,
+                                                                           int* __restrict__ flags) {
+  const int64_t q = (int64_t)blockIdx.x * kSetupThreads + threadIdx.x;
+  if (q >= ne * m) return;
+  const int64_t e = q / m;
+  const int i = (int)(q - e * m);
+  const int64_t want = i == 0 ? e : (e == ne - 1 ? -1 : ne + e * (m - 1) + (i - 1));
+  if (perm[q] != want) flags[3] = 1;
+}
+
 // inverse of a block order (entries -1 = padding); flags[1] raised when a node is listed twice
 __global__ __launch_bounds__(kSetupThreads) void perm_invert_kernel(int64_t Np, const int32_t* __restrict__ perm,
                                                                     int32_t* __restrict__ inv, int* __restrict__ flags) {

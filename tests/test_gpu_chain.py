@@ -197,3 +197,25 @@ def test_multigrid_loop_on_chain_hierarchy(oracle, mg):
     assert np.allclose(resg, reso, rtol=1e-6, atol=1e-12 * reso[0])
     xd, itd, resd, _ = mg.multigrid(H, x0, b, 60, 1e-10, exact=False)
     assert itd == ito and rel(xd, xo) < 1e-8
+
+
+def test_vcycles_loop_fuses_across_cycles_bitwise(oracle, mg):
+    """aggmg_vcycles_dev on a chain fine level: post-smoothing of cycle i and pre-smoothing of cycle i+1 share
+    one launch (prolongation + 6 sweeps + residual + restriction); the result is bitwise that of separate cycles,
+    also when the fused sweep count needs more than one launch"""
+    o = oracle
+    Ho, b = o.build_cg_hierarchy(300, ps=(4, 2, 1), nDG=1, pDG=0)
+    H = mg.MeshHierarchy.from_reference(Ho)
+    ctx = H.ctx
+    N = len(b)
+    for nPre, nPost, ncyc in ((3, 3, 5), (1, 2, 3), (6, 7, 3), (0, 0, 2)):
+        x0 = o.splitmix_normal(N, 3)
+        db = ctx.to_device(b)
+        xa, xb = ctx.to_device(x0), ctx.alloc(N)
+        for _ in range(ncyc):
+            H.vcycle_dev(xa, db, xb, nPre, nPost, 0.6)
+            xa, xb = xb, xa
+        ref = xa.download()
+        out = ctx.alloc(N)
+        H.vcycles_dev(ctx.to_device(x0), db, out, ncyc, nPre, nPost, 0.6)
+        assert np.array_equal(out.download(), ref), (nPre, nPost, ncyc)

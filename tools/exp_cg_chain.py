@@ -71,6 +71,13 @@ def main():
         xa, xb = xb, xa
     ctx.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
+    out_loop = ctx.alloc(N)
+    H.vcycles_dev(xa, b, out_loop, args.steps)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    H.vcycles_dev(xa, b, out_loop, args.steps)
+    ctx.synchronize()
+    dt_loop = (time.perf_counter() - t0) / args.steps
     ctx.profile_enable(1)
     for _ in range(args.steps):
         H.vcycle_dev(xa, b, xb)
@@ -79,7 +86,7 @@ def main():
     ctx.profile_enable(False)
     prof = ctx.profile_collect()
     vb = sum(l["vcycle"] for l in bm)
-    out = {"n": n, "ps": ps, "N_fine": N, "ms_per_vcycle": 1e3 * dt, "dof_updates_per_s": N * 6 / dt,
+    out = {"n": n, "ps": ps, "N_fine": N, "ms_per_vcycle": 1e3 * dt, "ms_per_cycle_in_vcycles_loop": 1e3 * dt_loop, "dof_updates_per_s": N * 6 / dt,
            "algorithmic_GBs": vb / dt / 1e9, "frac_of_8TBs": vb / dt / 8e12,
            "kernels": {f"{k}_L{l}": round(v[0] / v[1], 4) for (k, l), v in sorted(prof.items())}}
     for k, lm in enumerate(bm):
