@@ -662,6 +662,53 @@ class MeshHierarchy:
                 coarse_mode=coarse_mode)
         return H
 
+    @classmethod
+    def from_cg_operators(cls, mMeshes, A, mInterpolation, nCG, dg_operators=None, mMassMatrices=(), ctx=None,
+                          keep_host=True, coarse_mode=_lib.COARSE_AUTO):
+        """MeshHierarchy(mMeshes, mesh, mBdConds, A; nCG, nDG, nAgg, CDir) (src/mesh_heirarchy.jl:30-138) given
+        the interpolation matrices of all levels: the CG chain's Galerkin operators `L'*A*L` (:53-59) and, below
+        the first DG / agglomerated level, the recurrences of :76-86 / :89-106 run on the device.  That first
+        DG level is RE-DISCRETISED in the reference (:65-72, dg_flux_operators -- assembly, outside the hot path):
+        its G, D, C come in through dg_operators = (G, D, C); mMassMatrices[i] is the BlockDiagonal mass matrix
+        of level nCG + i.  CG levels get cg_smoother(mesh, A, :jac) with the mesh's element lists, DG levels
+        dg_smoother(mesh, A, :blockJac)."""
+        ctx = ctx or default_context()
+        n = len(mMeshes)
+        if nCG <= 0:
+            raise ArgumentError("At least one CG mesh required.")
+        if len(mInterpolation) != n - 1 or (n > nCG and (dg_operators is None or len(mMassMatrices) != n - nCG)):
+            raise ArgumentError("Length of vector of meshes does not match inputed number of CG, DG, and "
+                                "agglomerated meshes.")
+        Ls = [_as_op(L, _lib.OP_TRANSFER, ctx) for L in mInterpolation]
+        St = [_as_op(A, _lib.OP_STIFFNESS, ctx)]
+        for i in range(nCG - 1):
+            Lt = Ls[i].transpose()
+            St.append(Lt.matmul(St[i]).matmul(Ls[i]))
+            Lt.free()
+        Gs, Ds, Cs = [], [], []
+        if n > nCG:
+            Gs.append(_as_op(dg_operators[0], _lib.OP_STIFFNESS, ctx))
+            Ds.append(_as_op(dg_operators[1], _lib.OP_STIFFNESS, ctx))
+            Cs.append(_as_op(dg_operators[2], _lib.OP_STIFFNESS, ctx))
+            lus = [M if isinstance(M, BlockDiagonalLU) else M.lu() for M in mMassMatrices]
+            St.append(Cs[0].sub(Ds[0].matmul(lus[0].solve(Gs[0]))))
+            for i in range(1, n - nCG):
+                L = Ls[nCG + i - 1]
+                Lt = L.transpose()
+                Gs.append(Lt.matmul(Gs[i - 1]).matmul(L))
+                Ds.append(Lt.matmul(Ds[i - 1]).matmul(L))
+                Cs.append(Lt.matmul(Cs[i - 1]).matmul(L))
+                St.append(Cs[i].sub(Ds[i].matmul(lus[i].solve(Gs[i]))))
+                Lt.free()
+        sms = []
+        for k in range(n - 1):
+            if k < nCG:
+                sms.append(cg_smoother(mMeshes[k], St[k], 'jac', ctx))
+            else:
+                sms.append(BlockJacobi(St[k], _mesh_block_inds(mMeshes[k]), ctx))
+        return cls(mMeshes, St, sms, Ls, mGradient=Gs, mDivergence=Ds, mC=Cs, ctx=ctx, keep_host=keep_host,
+                   coarse_mode=coarse_mode)
+
     @property
     def nlevels(self):
         return len(self._ops)

@@ -34,13 +34,18 @@ import numpy as np
 # ------------------------------------------------------------------------------------------
 # layout
 # ------------------------------------------------------------------------------------------
-def halo_widths(ratios, nPre, nPost):
+def halo_widths(ratios, nPre, nPost, gs=False):
     """Ghost elements per side for levels 0..len(ratios) (last = coarsest, held replicated but
     copied locally with W ghosts), nested so that a local level is exactly the children of the
     local next-coarser level: W_k = ratios[k] * W_{k+1}.  Smallest widths for which the owned part
-    of the V-cycle result is exact with a single exchange of x0 and the coarsest gather."""
+    of the V-cycle result is exact with a single exchange of x0 and the coarsest gather.
+    gs: red-black block Gauss-Seidel sweeps (the labelled extension) -- a sweep is two half-sweeps
+    and moves information by two elements (one when it starts from a zero iterate)."""
     nl = len(ratios) + 1
-    for w in range(0, 4096):
+    per = 2 if gs else 1
+    # (gs: the two colours are the parity of the LOCAL element index, so local ranges must start on even
+    # elements: even widths on every level)
+    for w in range(0, 4096, 2 if gs else 1):
         W = [0] * nl
         W[nl - 1] = w
         for k in range(nl - 2, -1, -1):
@@ -52,7 +57,7 @@ def halo_widths(ratios, nPre, nPost):
         for k in range(nl - 1):
             # levels below the finest start from u = 0 (src/solvers.jl:29-31): their first sweep
             # reads no neighbour and costs no margin
-            Pu[k] = min(Rm, W[k]) - (nPre if k == 0 else max(nPre - 1, 0))
+            Pu[k] = min(Rm, W[k]) - (per * nPre if k == 0 else max(per * nPre - 1, 0))
             if Pu[k] < 1:               # the residual needs one more valid neighbour
                 ok = False
                 break
@@ -62,7 +67,7 @@ def halo_widths(ratios, nPre, nPost):
         # ascending: margin of the post-smoothed u; coarsest solution is exact on all W ghosts
         V = W[nl - 1]
         for k in range(nl - 2, -1, -1):
-            V = min(Pu[k], ratios[k] * V) - nPost
+            V = min(Pu[k], ratios[k] * V) - per * nPost
             if V < 0:
                 ok = False
                 break
@@ -76,14 +81,15 @@ class RankLayout:
     own[k] = (lo, hi) owned elements, loc[k] = (lo, hi) local domain (owned + ghosts, clipped to
     the global domain), m[k] = DoFs per element, ne[k] = global element count."""
 
-    def __init__(self, n_fine, ratios, block_sizes, world, rank, nPre=3, nPost=3):
+    def __init__(self, n_fine, ratios, block_sizes, world, rank, nPre=3, nPost=3, gs=False):
         tot = int(np.prod(ratios)) if len(ratios) else 1
         if n_fine % (tot * world):
             raise ValueError("fine element count must be divisible by world_size * prod(ratios)")
         self.world, self.rank = world, rank
         self.ratios = tuple(ratios)
         self.m = list(block_sizes)
-        self.W = halo_widths(ratios, nPre, nPost)
+        self.W = halo_widths(ratios, nPre, nPost, gs)
+        self.gs = gs
         self.nPre, self.nPost = nPre, nPost
         self.ne, self.own, self.loc = [], [], []
         f = 1
@@ -98,6 +104,8 @@ class RankLayout:
             self.ne.append(ne)
             self.own.append((lo, hi))
             self.loc.append((max(0, lo - self.W[k]), min(ne, hi + self.W[k])))
+            if gs and k < len(ratios) and self.loc[-1][0] % 2:
+                raise ValueError("block Gauss-Seidel: a rank's local element range must start on an even element")
 
     def ghosts(self, k):
         return self.own[k][0] - self.loc[k][0], self.loc[k][1] - self.own[k][1]
@@ -621,14 +629,15 @@ class HipEngine:
             c.check(c.lib.aggmg_copy_segments_dev(c.handle, n, src, dst, rows, cols, sld, dld))
 
 
-def build_local_uniform(n, p, pAgg, ratios, layout, ctx, comm):
+def build_local_uniform(n, p, pAgg, ratios, layout, ctx, comm, smoother="blockJac"):
     """Local operators of this rank for the uniform model problem, uploaded through the CSC
     boundary, plus the global coarsest operator assembled from every rank's owned block rows.
     -> (HipEngine, U_local)"""
     import torch
     from . import _lib
-    from .api import BlockJacobi, DeviceOperator, MeshHierarchy
+    from .api import BlockGaussSeidel, BlockJacobi, DeviceOperator, MeshHierarchy
     from .uniform import UniformDgAggHierarchy, block_tridiag_to_csc, _csc
+    Smoother = {"blockJac": BlockJacobi, "blockGS": BlockGaussSeidel}[smoother]
     lo, hi = layout.loc[0]
     U = UniformDgAggHierarchy(n, p=p, pAgg=pAgg, ratios=ratios, elem_range=(lo, hi))
     nl = U.nlevels
@@ -637,7 +646,7 @@ def build_local_uniform(n, p, pAgg, ratios, layout, ctx, comm):
         op = DeviceOperator(U.stiffness_csc(k), _lib.OP_STIFFNESS, ctx)
         ops.append(op)
         if k < nl - 1:
-            sms.append(BlockJacobi(op, U.descriptor(k).mBlockInds, ctx))
+            sms.append(Smoother(op, U.descriptor(k).mBlockInds, ctx))
     Ls = [DeviceOperator(U.interpolation_csc(k), _lib.OP_TRANSFER, ctx) for k in range(nl - 1)]
     H = MeshHierarchy([U.descriptor(k) for k in range(nl)], ops, sms, Ls, ctx=ctx, keep_host=False,
                       coarse_mode=_lib.COARSE_EXTERNAL)

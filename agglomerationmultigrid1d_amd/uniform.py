@@ -467,11 +467,13 @@ class UniformDgAggHierarchy:
         return out
 
 
-def build_device_hierarchy(U, ctx=None, keep_host=False):
+def build_device_hierarchy(U, ctx=None, keep_host=False, smoother="blockJac"):
     """Upload a UniformDgAggHierarchy through the CSC boundary and return the product
-    MeshHierarchy (block-Jacobi on every smoothed level, src/mesh_heirarchy.jl:58,73,85,104)."""
-    from .api import BlockJacobi, DeviceOperator, MeshHierarchy
+    MeshHierarchy (block-Jacobi on every smoothed level, src/mesh_heirarchy.jl:58,73,85,104;
+    smoother="blockGS": the labelled red-black block Gauss-Seidel extension)."""
+    from .api import BlockGaussSeidel, BlockJacobi, DeviceOperator, MeshHierarchy
     from . import _lib
+    BlockJacobi = {"blockJac": BlockJacobi, "blockGS": BlockGaussSeidel}[smoother]
     n = U.nlevels
     ops, sms = [], []
     for k in range(n):

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, n, q, overlap=False, native=False):
+def _worker(rank, world, port, n, q, overlap=False, native=False, smoother="blockJac"):
     sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle")]
     import torch
     import torch.distributed as dist
@@ -30,8 +30,8 @@ def _worker(rank, world, port, n, q, overlap=False, native=False):
         ratios, p = (4, 2, 2), 3
         ctx = mg.Context(0)
         comm = D.Comm(world, rank, staged=True)
-        layout = D.RankLayout(n, ratios, [p + 1, 2, 2, 2], world, rank)
-        engine, U = D.build_local_uniform(n, p, 1, ratios, layout, ctx, comm)
+        layout = D.RankLayout(n, ratios, [p + 1, 2, 2, 2], world, rank, gs=(smoother == "blockGS"))
+        engine, U = D.build_local_uniform(n, p, 1, ratios, layout, ctx, comm, smoother=smoother)
         assert all(engine.H.structured_levels()) and engine.Hc.coarse_info()['on_device']
         if native:    # the schedule inside libaggmg_hip.so; its all-gathers call back into torch.distributed (gloo)
             dv = D.NativeDistributedVCycle(engine, layout, comm, collectives="torch")
@@ -48,7 +48,7 @@ def _worker(rank, world, port, n, q, overlap=False, native=False):
         # single-GPU run of the same library on the global hierarchy
         Ug = UniformDgAggHierarchy(n, p=p, pAgg=1, ratios=ratios)
         ctx2 = mg.Context(0)
-        Hg = build_device_hierarchy(Ug, ctx2)
+        Hg = build_device_hierarchy(Ug, ctx2, smoother=smoother)
         bg = ctx2.to_device(Ug.rhs())
         xa, xb = ctx2.to_device(np.zeros(len(Ug.rhs()))), ctx2.alloc(len(Ug.rhs()))
         for _ in range(3):
@@ -159,6 +159,27 @@ def test_native_schedule_matches_single_gpu(world, n, overlap, nex):
     for rank, err, scale, got_nex, chunked in sorted(q.get() for _ in range(world)):
         assert err == 0.0, (rank, err, scale)
         assert chunked == (n >= 2**16) and got_nex == nex, (chunked, got_nex)
+
+
+def test_block_gauss_seidel_partitioned():
+    """the labelled extension (red-black block Gauss-Seidel) under element partitioning: ghost
+    layers twice as deep per sweep, colours by the parity of the element index (local ranges start on even
+    elements); 2 and 4 ranks on the one GPU, library schedule, bitwise against the single-GPU Gauss-Seidel
+    cycle of the same library"""
+    import torch.multiprocessing as mp
+    from test_distributed_cpu import free_port
+    for world, overlap in ((2, False), (4, True)):
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        port = free_port()
+        procs = [ctx.Process(target=_worker, args=(r, world, port, 2**16, q, overlap, True, "blockGS")) for r in range(world)]
+        for pr in procs:
+            pr.start()
+        for pr in procs:
+            pr.join(900)
+        assert all(pr.exitcode == 0 for pr in procs), [pr.exitcode for pr in procs]
+        for rank, err, scale, nex, chunked in sorted(q.get() for _ in range(world)):
+            assert err == 0.0, (world, rank, err, scale)
 
 
 def _rccl_in_library_worker(port, q):

@@ -192,3 +192,23 @@ def test_dg_constructor_recurrences_on_device(oracle, mg, n, p, pAgg, nAgg, firs
     xr = o.multigrid_v_cycle(Ho, np.zeros(len(b)), b)
     assert np.linalg.norm(Ho.mStiffness[0] @ (x - xr)) <= 1e-12 * np.linalg.norm(b)
     assert np.linalg.norm(x - xr) <= 1e-8 * np.linalg.norm(xr)
+
+
+@pytest.mark.parametrize("kw", [dict(n=32, ps=(4, 2, 1)), dict(n=32, ps=(4, 2, 1), nDG=1, pDG=0), dict(n=32, ps=(2, 1), nAgg=3)])
+def test_cg_constructor_recurrences_on_device(oracle, mg, kw):
+    """MeshHierarchy.from_cg_operators: Galerkin operators of the CG chain and of the levels below the first
+    (re-discretised) DG / agglomerated level on the device -- against the oracle's CG-fine constructor"""
+    o = oracle
+    Ho, b = o.build_cg_hierarchy(**kw)
+    nCG = len(kw["ps"])
+    n = len(Ho.mMeshes)
+    dg_ops = (Ho.mGradient[0], Ho.mDivergence[0], Ho.mC[0]) if n > nCG else None
+    masses = [mg.BlockDiagonal(m.mMassMatrix.mBlocks) for m in Ho.mMeshes[nCG:]]
+    H = mg.MeshHierarchy.from_cg_operators(Ho.mMeshes, Ho.mStiffness[0], Ho.mInterpolation, nCG, dg_ops, masses)
+    for k in range(1, n):
+        assert relmax(H.mStiffness[k].to_scipy(), Ho.mStiffness[k]) < 1e-12, k
+    kinds = H.level_kinds()
+    assert kinds[:nCG - (1 if n == nCG else 0)] == ['fused_chain'] * (nCG - (1 if n == nCG else 0)), kinds
+    x = mg.multigrid_v_cycle(H, np.zeros(len(b)), b)
+    xr = o.multigrid_v_cycle(Ho, np.zeros(len(b)), b)
+    assert np.linalg.norm(Ho.mStiffness[0] @ (x - xr)) <= 1e-12 * np.linalg.norm(b)
