@@ -135,6 +135,8 @@ SYMBOLS = {
     "aggmg_dist_init_rccl": (c_int, [_P, _P, _P, c_int, POINTER(c_int)]),
     "aggmg_dist_set_allgather": (c_int, [_P, _P, _P, _P]),
     "aggmg_dist_set_loopback": (c_int, [_P, _P]),
+    "aggmg_dist_set_exchange_layout": (c_int, [_P, _P, c_int, c_int64, c_int] + [POINTER(c_int64)] * 3 + [c_int] +
+                                       [POINTER(c_int64)] * 3 + [c_int] + [POINTER(c_int64)] * 3),
     "aggmg_dist_allgather_dev": (c_int, [_P, _P, _P, _P, c_int64]),
     "aggmg_dist_exchange_ghosts_dev": (c_int, [_P, _P, _P, c_int]),
     "aggmg_dist_vcycle_dev": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_double, c_int]),

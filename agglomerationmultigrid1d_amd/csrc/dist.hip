@@ -91,6 +91,17 @@ struct DevBuf {
   }
 };
 
+// which entries of a local level vector travel in an interface exchange: `send` packs slices of the vector
+// into this rank's part of the all-gather (count doubles per rank), `left` / `right` unpack slices of the
+// left / right neighbour's part into the ghost entries
+struct ExSeg {
+  int64_t src, dst, len;
+};
+struct ExLayout {
+  int64_t count = 0;
+  std::vector<ExSeg> send, left, right;
+};
+
 struct aggmg_dist {
   aggmg_hier* H = nullptr;   // local hierarchy, AGGMG_COARSE_EXTERNAL
   aggmg_hier* Hc = nullptr;  // one-level hierarchy of the GLOBAL coarsest operator (replicated)
@@ -98,6 +109,7 @@ struct aggmg_dist {
   std::vector<int64_t> own_lo, own_hi, loc_lo, loc_hi, ne;
   std::vector<int> m, W;
   DevBuf send[2], recv[2];  // [0]: finest level, [1]: coarsest level ghosts
+  ExLayout ex[2];
   DevBuf rhs_g, sol_g, zero_g;
   bool chunked = false;
   int q = 0;
@@ -177,49 +189,58 @@ static int copy2(aggmg_ctx* ctx, int nseg, const double* const* src, double* con
   return aggmg_copy_segments_dev(ctx, nseg, src, dst, rows, cols, sld, dld);
 }
 
-// pack the first and last W owned elements of a local level vector
-static int pack_interface(aggmg_ctx* ctx, aggmg_dist* d, const double* x, int level, double* send) {
-  const int64_t m = d->m[level], wm = (int64_t)d->W[level] * m;
-  const int64_t o0 = (d->own_lo[level] - d->loc_lo[level]) * m;
-  const int64_t o1 = o0 + (d->own_hi[level] - d->own_lo[level]) * m;
-  const double* src[2] = {x + o0, x + o1 - wm};
-  double* dst[2] = {send, send + wm};
-  const int64_t rows[2] = {1, 1}, cols[2] = {wm, wm}, ld[2] = {wm, wm};
-  return copy2(ctx, 2, src, dst, rows, cols, ld, ld);
+// up to four slices per launch (aggmg_copy_segments_dev)
+static int copy_segs(aggmg_ctx* ctx, const std::vector<ExSeg>& segs, const double* src_base, double* dst_base) {
+  for (size_t i = 0; i < segs.size(); i += 4) {
+    const double* src[4];
+    double* dst[4];
+    int64_t rows[4], cols[4], ld[4];
+    int n = 0;
+    for (size_t j = i; j < segs.size() && n < 4; ++j) {
+      if (segs[j].len <= 0) continue;
+      src[n] = src_base + segs[j].src;
+      dst[n] = dst_base + segs[j].dst;
+      rows[n] = 1, cols[n] = segs[j].len, ld[n] = segs[j].len;
+      ++n;
+    }
+    if (n) CHECK(copy2(ctx, n, src, dst, rows, cols, ld, ld));
+  }
+  return AGGMG_OK;
 }
 
-// neighbours' interface elements -> ghost entries
-static int unpack_ghosts(aggmg_ctx* ctx, aggmg_dist* d, double* x, int level, const double* recv) {
+// the default layout of a level whose DoFs are contiguous per element (DG / agglomerated levels): the first
+// and last W owned elements travel, the neighbours' go into the ghost elements
+static ExLayout contiguous_layout(const aggmg_dist* d, int level) {
+  ExLayout L;
   const int64_t m = d->m[level], wm = (int64_t)d->W[level] * m;
   const int64_t gl = d->own_lo[level] - d->loc_lo[level], gr = d->loc_hi[level] - d->own_hi[level];
   const int64_t o0 = gl * m;
   const int64_t o1 = o0 + (d->own_hi[level] - d->own_lo[level]) * m;
-  const double* src[2];
-  double* dst[2];
-  int64_t rows[2], cols[2], ld[2];
-  int n = 0;
+  L.count = 2 * wm;
+  L.send = {ExSeg{o0, 0, wm}, ExSeg{o1 - wm, wm, wm}};
+  if (gl) L.left = {ExSeg{wm, 0, gl * m}};    // the left neighbour's last W elements
+  if (gr) L.right = {ExSeg{0, o1, gr * m}};   // the right neighbour's first W elements
+  return L;
+}
+
+static int pack_interface(aggmg_ctx* ctx, aggmg_dist* d, const double* x, int level, double* send) {
+  return copy_segs(ctx, d->ex[level == 0 ? 0 : 1].send, x, send);
+}
+
+// neighbours' interface entries -> ghost entries
+static int unpack_ghosts(aggmg_ctx* ctx, aggmg_dist* d, double* x, int level, const double* recv) {
+  const ExLayout& L = d->ex[level == 0 ? 0 : 1];
   const int r = d->rank;
-  if (gl) {  // the left neighbour's last W elements
-    src[n] = recv + (int64_t)(r - 1) * 2 * wm + wm;
-    dst[n] = x;
-    rows[n] = 1, cols[n] = gl * m, ld[n] = gl * m;
-    ++n;
-  }
-  if (gr) {
-    src[n] = recv + (int64_t)(r + 1) * 2 * wm;
-    dst[n] = x + o1;
-    rows[n] = 1, cols[n] = gr * m, ld[n] = gr * m;
-    ++n;
-  }
-  return n ? copy2(ctx, n, src, dst, rows, cols, ld, ld) : AGGMG_OK;
+  if (r > 0 && !L.left.empty()) CHECK(copy_segs(ctx, L.left, recv + (int64_t)(r - 1) * L.count, x));
+  if (r + 1 < d->world && !L.right.empty()) CHECK(copy_segs(ctx, L.right, recv + (int64_t)(r + 1) * L.count, x));
+  return AGGMG_OK;
 }
 
 static int exchange_ghosts(aggmg_ctx* ctx, aggmg_dist* d, double* x, int level) {
-  if (d->world == 1 || d->W[level] == 0) return AGGMG_OK;
   const int slot = level == 0 ? 0 : 1;
-  const int64_t wm = (int64_t)d->W[level] * d->m[level];
+  if (d->world == 1 || d->ex[slot].count == 0) return AGGMG_OK;
   CHECK(pack_interface(ctx, d, x, level, d->send[slot].p));
-  CHECK(dist_allgather(ctx, d, d->send[slot].p, d->recv[slot].p, 2 * wm));
+  CHECK(dist_allgather(ctx, d, d->send[slot].p, d->recv[slot].p, d->ex[slot].count));
   return unpack_ghosts(ctx, d, x, level, d->recv[slot].p);
 }
 
@@ -248,7 +269,8 @@ extern "C" int aggmg_dist_create(aggmg_ctx* ctx, aggmg_hier* local, aggmg_hier* 
     if (m[k] < 1 || W[k] < 0 || !(0 <= loc_lo[k] && loc_lo[k] <= own_lo[k] && own_lo[k] <= own_hi[k] &&
                                    own_hi[k] <= loc_hi[k] && loc_hi[k] <= ne[k]))
       return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_dist_create: inconsistent element ranges at level " + std::to_string(k + 1));
-    if ((loc_hi[k] - loc_lo[k]) * m[k] != local->lv[k].N)
+    // (a CG level holds one more DoF than elements x m: the last vertex)
+    if ((loc_hi[k] - loc_lo[k]) * m[k] != local->lv[k].N && (loc_hi[k] - loc_lo[k]) * m[k] + 1 != local->lv[k].N)
       return fail(ctx, AGGMG_ERR_DIMENSION, "aggmg_dist_create: local level size does not match the layout at level " + std::to_string(k + 1));
     const int64_t gl = own_lo[k] - loc_lo[k], gr = loc_hi[k] - own_hi[k];
     if ((gl && gl != W[k]) || (gr && gr != W[k]) || (world > 1 && own_hi[k] - own_lo[k] < W[k]))
@@ -262,9 +284,9 @@ extern "C" int aggmg_dist_create(aggmg_ctx* ctx, aggmg_hier* local, aggmg_hier* 
     return fail(ctx, AGGMG_ERR_DIMENSION, "aggmg_dist_create: global coarsest operator size does not match the layout");
   for (int s = 0; s < 2; ++s) {
     const int lev = s == 0 ? 0 : nc;
-    const int64_t wm = (int64_t)W[lev] * m[lev];
-    CHECK(d->send[s].alloc(ctx, 2 * wm));
-    CHECK(d->recv[s].alloc(ctx, 2 * wm * world));
+    d->ex[s] = contiguous_layout(d.get(), lev);
+    CHECK(d->send[s].alloc(ctx, d->ex[s].count));
+    CHECK(d->recv[s].alloc(ctx, d->ex[s].count * world));
   }
   const int64_t Ng = ne[nc] * m[nc];
   CHECK(d->rhs_g.alloc(ctx, Ng));
@@ -303,6 +325,52 @@ extern "C" int aggmg_dist_free(aggmg_ctx* ctx, aggmg_dist* d) {
   HIPCHK(hipStreamSynchronize(ctx->stream));
   if (d->side) HIPCHK(hipStreamSynchronize(d->side));
   delete d;
+  return AGGMG_OK;
+}
+
+// Levels whose DoFs are not contiguous per element (CG levels in the reference's vertices-first numbering:
+// the interface is a slice of the vertex part plus a slice of the interior part) describe their exchange
+// explicitly: `count` doubles per rank; send_*: slices of the local vector packed into this rank's part;
+// left_* / right_*: slices of the left / right neighbour's part unpacked into the ghost entries.
+extern "C" int aggmg_dist_set_exchange_layout(aggmg_ctx* ctx, aggmg_dist* d, int level, int64_t count, int nsend,
+                                              const int64_t* send_src, const int64_t* send_dst, const int64_t* send_len,
+                                              int nleft, const int64_t* left_src, const int64_t* left_dst,
+                                              const int64_t* left_len, int nright, const int64_t* right_src,
+                                              const int64_t* right_dst, const int64_t* right_len) {
+  if (!ctx || !d) return AGGMG_ERR_ARGUMENT;
+  if (level != 0 && level != d->nl - 1)
+    return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_dist_set_exchange_layout: only the finest and the coarsest level exchange ghosts");
+  if (count < 0 || nsend < 0 || nleft < 0 || nright < 0)
+    return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_dist_set_exchange_layout: negative count");
+  const int slot = level == 0 ? 0 : 1;
+  const int64_t N = d->H->lv[level].N;
+  ExLayout L;
+  L.count = count;
+  auto fill = [&](std::vector<ExSeg>& v, int n, const int64_t* a, const int64_t* b, const int64_t* len, int64_t lim_src,
+                  int64_t lim_dst) -> bool {
+    for (int i = 0; i < n; ++i) {
+      if (len[i] < 0 || a[i] < 0 || b[i] < 0 || a[i] + len[i] > lim_src || b[i] + len[i] > lim_dst) return false;
+      v.push_back(ExSeg{a[i], b[i], len[i]});
+    }
+    return true;
+  };
+  if (!fill(L.send, nsend, send_src, send_dst, send_len, N, count) || !fill(L.left, nleft, left_src, left_dst, left_len, count, N) ||
+      !fill(L.right, nright, right_src, right_dst, right_len, count, N))
+    return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_dist_set_exchange_layout: a slice leaves the vector or the exchange buffer");
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  d->ex[slot] = L;
+  d->send[slot].~DevBuf();
+  new (&d->send[slot]) DevBuf();
+  d->recv[slot].~DevBuf();
+  new (&d->recv[slot]) DevBuf();
+  CHECK(d->send[slot].alloc(ctx, count));
+  CHECK(d->recv[slot].alloc(ctx, count * d->world));
+  for (auto& g : d->graphs)   // captured cycles refer to the old buffers
+    if (g.exec) {
+      (void)hipGraphExecDestroy(g.exec);
+      g.exec = nullptr;
+      g.seen = 0;
+    }
   return AGGMG_OK;
 }
 
@@ -445,7 +513,7 @@ static int dist_vcycle_eager(aggmg_ctx* ctx, aggmg_dist* d, double* x0, const do
         (void)hipEventRecord(d->ev_ends, d->side);
         st = pack_interface(ctx, d, x_out, 0, d->send[0].p);
       }
-      if (st == AGGMG_OK) st = dist_allgather(ctx, d, d->send[0].p, d->recv[0].p, 2 * (int64_t)d->W[0] * d->m[0]);
+      if (st == AGGMG_OK) st = dist_allgather(ctx, d, d->send[0].p, d->recv[0].p, d->ex[0].count);
       (void)hipEventRecord(d->ev_side, d->side);
       ctx->stream = main;
       CHECK(st);

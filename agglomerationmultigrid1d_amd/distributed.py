@@ -118,6 +118,84 @@ class RankLayout:
         return slice(gl * self.m[k], (gl + self.own[k][1] - self.own[k][0]) * self.m[k])
 
 
+class CgRankLayout:
+    """Element ranges of one rank for a CG p-chain + DG p=0 hierarchy (BASELINE config 5 shape: CG p_0 >
+    p_1 > ... on the same elements, then DG p=0).  Every level has the same elements, so the ghost width is
+    the same on all of them: one element per sweep, residual, restriction and prolongation (conservatively
+    (nPre + nPost + 4) per smoothed level).  A CG level is numbered vertices-first ON THE RANK'S SUB-MESH
+    (src/cg_mesh.jl:37-45,59-65): local vertex v - loc_lo, then the interior nodes element by element; a rank
+    owns the vertices [own_lo, own_hi) (the last rank also the final vertex) and the interior nodes of its
+    elements.  `exchange_layout(level)` describes the interface slices for aggmg_dist_set_exchange_layout."""
+
+    def __init__(self, n, ps, world, rank, nPre=3, nPost=3):
+        if n % world:
+            raise ValueError("element count must be divisible by world_size")
+        self.world, self.rank = world, rank
+        self.ps = tuple(ps)
+        nl = len(ps) + 1
+        self.ratios = (1,) * (nl - 1)
+        self.m = list(ps) + [1]
+        w = len(ps) * (nPre + nPost + 4)
+        self.W = [w] * nl
+        self.nPre, self.nPost = nPre, nPost
+        per = n // world
+        if per < w + 1:
+            raise ValueError(f"each rank must own more than {w} elements")
+        lo, hi = rank * per, (rank + 1) * per
+        self.ne = [n] * nl
+        self.own = [(lo, hi)] * nl
+        self.loc = [(max(0, lo - w), min(n, hi + w))] * nl
+
+    def ghosts(self, k):
+        return self.own[k][0] - self.loc[k][0], self.loc[k][1] - self.own[k][1]
+
+    def local_dofs(self, k):
+        nloc = self.loc[k][1] - self.loc[k][0]
+        return nloc * self.m[k] + (1 if k < len(self.ps) else 0)
+
+    def owned_index(self, k):
+        """local indices of the owned DoFs of level k, in the order of the global numbering"""
+        gl, _ = self.ghosts(k)
+        nown = self.own[k][1] - self.own[k][0]
+        nloc = self.loc[k][1] - self.loc[k][0]
+        if k >= len(self.ps):
+            return np.arange(gl, gl + nown)
+        q = self.ps[k] - 1
+        last = 1 if self.own[k][1] == self.ne[k] else 0
+        v = np.arange(gl, gl + nown + last)
+        it = (nloc + 1) + np.arange(gl * q, (gl + nown) * q)
+        return np.concatenate([v, it])
+
+    def global_index(self, k):
+        """global numbers of the same DoFs"""
+        lo, hi = self.own[k]
+        n = self.ne[k]
+        if k >= len(self.ps):
+            return np.arange(lo, hi)
+        q = self.ps[k] - 1
+        last = 1 if hi == n else 0
+        return np.concatenate([np.arange(lo, hi + last), (n + 1) + np.arange(lo * q, hi * q)])
+
+    def exchange_layout(self, k):
+        """-> (count, send, left, right), each a list of (src, dst, len): the first W elements' nodes incl. the
+        vertex that closes them go to the left neighbour, the last W elements' nodes to the right one"""
+        if k >= len(self.ps):
+            return None                                    # contiguous elements: the library's default
+        W, q = self.W[k], self.ps[k] - 1
+        gl, gr = self.ghosts(k)
+        nown = self.own[k][1] - self.own[k][0]
+        nloc = self.loc[k][1] - self.loc[k][0]
+        I0 = nloc + 1                                      # start of the interior part of the local vector
+        # this rank's part: [first: W+1 vertices | first: W q interior | last: W vertices | last: W q interior]
+        o_fv, o_fi, o_lv, o_li = 0, W + 1, W + 1 + W * q, 2 * W + 1 + W * q
+        count = 2 * W + 1 + 2 * W * q
+        send = [(gl, o_fv, W + 1), (I0 + gl * q, o_fi, W * q),
+                (gl + nown - W, o_lv, W), (I0 + (gl + nown - W) * q, o_li, W * q)]
+        left = [(o_lv, 0, W), (o_li, I0, W * q)] if gl else []                       # left ghosts <- neighbour's last part
+        right = [(o_fv, gl + nown, W + 1), (o_fi, I0 + (gl + nown) * q, W * q)] if gr else []
+        return count, [s_ for s_ in send if s_[2] > 0], [s_ for s_ in left if s_[2] > 0], [s_ for s_ in right if s_[2] > 0]
+
+
 # ------------------------------------------------------------------------------------------
 # communicator (torch.distributed; device tensors for nccl, host staging for gloo)
 # ------------------------------------------------------------------------------------------
@@ -362,6 +440,16 @@ class NativeDistributedVCycle:
         self.handle = h
         self.collectives = collectives
         self.rccl_ranks = None
+        if hasattr(L, "exchange_layout"):      # levels whose interface is not "the first / last W elements"
+            for k in (0, nl - 1):
+                lay = L.exchange_layout(k)
+                if lay is None:
+                    continue
+                count, send, left, right = lay
+                arr = lambda segs, j: (ctypes.c_int64 * max(len(segs), 1))(*[int(t[j]) for t in segs])
+                ctx.check(ctx.lib.aggmg_dist_set_exchange_layout(
+                    ctx.handle, h, k, int(count), len(send), arr(send, 0), arr(send, 1), arr(send, 2),
+                    len(left), arr(left, 0), arr(left, 1), arr(left, 2), len(right), arr(right, 0), arr(right, 1), arr(right, 2)))
         if collectives in ("rccl", "loopback"):
             # nothing of the cycle goes through torch any more: run on the library's own (capturable,
             # non-blocking) stream instead of torch's current one; torch-side initialisation of the
@@ -666,6 +754,41 @@ def build_local_uniform(n, p, pAgg, ratios, layout, ctx, comm, smoother="blockJa
     allb = torch.empty(mine.numel() * comm.world, dtype=torch.float64, device=mine.device)
     comm.all_gather(allb, mine)
     allb = allb.cpu().numpy().reshape(comm.world, 3, no, mc, mc)
+    gsub, gdiag, gsup = (np.concatenate([allb[r, i] for r in range(comm.world)]) for i in range(3))
+    colptr, rowval, nzval, N = block_tridiag_to_csc(gsub, gdiag, gsup)
+    Ac = DeviceOperator(_csc(colptr, rowval, nzval, (N, N)), _lib.OP_STIFFNESS, ctx)
+    Hc = MeshHierarchy(None, [Ac], [], [], ctx=ctx, keep_host=False, coarse_mode=_lib.COARSE_AUTO)
+    return HipEngine(H, Hc, ctx), U
+
+
+def build_local_cg(n, ps, layout, ctx, comm):
+    """Local operators of this rank for the CG p-chain + DG p=0 model hierarchy (config 5 shape), uploaded
+    through the CSC boundary with the sub-mesh's element lists (chain kernels), plus the global coarsest
+    (DG p=0) operator assembled from every rank's owned rows.  -> (HipEngine, U_local)"""
+    import torch
+    from . import _lib
+    from .api import DeviceOperator, JacobiSmoother, MeshHierarchy
+    from .uniform import UniformCgDgHierarchy, block_tridiag_to_csc, _csc
+    lo, hi = layout.loc[0]
+    U = UniformCgDgHierarchy(n, ps=ps, elem_range=(lo, hi))
+    nl = U.nlevels
+    ops = [DeviceOperator(A, _lib.OP_STIFFNESS, ctx) for A in U.A]
+    sms = [JacobiSmoother(ops[k], ctx, U.element_nodes(k)) for k in range(nl - 1)]
+    Ls = [DeviceOperator(L, _lib.OP_TRANSFER, ctx) for L in U.L]
+    H = MeshHierarchy(None, ops, sms, Ls, ctx=ctx, keep_host=False, coarse_mode=_lib.COARSE_EXTERNAL)
+    # global coarsest operator: the owned rows of the local DG p=0 operator of every rank
+    nc = nl - 1
+    gl, _ = layout.ghosts(nc)
+    no = layout.own[nc][1] - layout.own[nc][0]
+    sub, diag, sup = (np.ascontiguousarray(x[gl:gl + no]) for x in U.dg0.levels[0]['A'])
+    mine = torch.from_numpy(np.stack([sub, diag, sup]).reshape(-1))
+    dev = torch.device("cuda", ctx.device) if (comm.world > 1 and not comm.staged and
+                                                comm.dist.get_backend() == "nccl") else None
+    if dev is not None:
+        mine = mine.to(dev)
+    allb = torch.empty(mine.numel() * comm.world, dtype=torch.float64, device=mine.device)
+    comm.all_gather(allb, mine)
+    allb = allb.cpu().numpy().reshape(comm.world, 3, no, 1, 1)
     gsub, gdiag, gsup = (np.concatenate([allb[r, i] for r in range(comm.world)]) for i in range(3))
     colptr, rowval, nzval, N = block_tridiag_to_csc(gsub, gdiag, gsup)
     Ac = DeviceOperator(_csc(colptr, rowval, nzval, (N, N)), _lib.OP_STIFFNESS, ctx)

@@ -505,14 +505,24 @@ class UniformCgDgHierarchy:
     CG numbering: vertices 1..n+1, then the p-1 interior nodes of every element in element order
     (src/cg_mesh.jl:37-45,59-65); node indices here are 0-based."""
 
-    def __init__(self, n, ps=(4, 2, 1), CDir=None, xin=0.0, xout=1.0, bc=None, func=np.cos):
-        self.n, self.ps = n, tuple(ps)
+    def __init__(self, n, ps=(4, 2, 1), CDir=None, xin=0.0, xout=1.0, bc=None, func=np.cos, elem_range=None):
+        """elem_range=(a, b): only the elements a..b-1 (0-based) and their nodes -- the local operators of one rank
+        of an element-partitioned run, numbered vertices-first on the sub-mesh.  Contributions of elements
+        outside the range are dropped (the cut vertices carry incomplete rows: ghost layers absorb that);
+        everything else equals the corresponding entries of the global operators."""
+        a, b = (0, n) if elem_range is None else (int(elem_range[0]), int(elem_range[1]))
+        if not (0 <= a < b <= n):
+            raise ValueError("elem_range must be a non-empty range of elements")
+        self.n_global, self.a, self.b = n, a, b
+        self.at_left, self.at_right = (a == 0), (b == n)
+        self.n, self.ps = b - a, tuple(ps)          # elements the arrays are built on
         self.CDir = 1000.0 * n if CDir is None else float(CDir)
         self.bc = bc or (('neu', -math.sin(xin)), ('dir', math.cos(xout)))
         self.func = func
-        i = np.arange(n + 1, dtype=np.float64)
+        i = np.arange(a, b + 1, dtype=np.float64)
         self.xv = xin + (i / n) * (xout - xin)
-        self.xv[0] = xin
+        if a == 0:
+            self.xv[0] = xin
         self.h = self.xv[1:] - self.xv[:-1]
         self.xc = (self.xv[:-1] + self.xv[1:]) / 2.0
         self.J = self.h / 2.0
@@ -527,7 +537,8 @@ class UniformCgDgHierarchy:
             self.A.append(self._assemble(self.ps[k], Ke, extra, None))
         # DG p = 0 level: re-discretised operator, lumped-mass transfer from the last CG level
         dg0 = UniformDgAggHierarchy(n, p=0, pAgg=0, ratios=(), CDir=self.CDir, xin=xin, xout=xout, bc=self.bc,
-                                    func=func)
+                                    func=func, elem_range=elem_range)
+        self.dg0 = dg0
         self.L.append(self._dg0_cg(self.ps[-1], self.refs[-1]))
         self.A.append(dg0.stiffness_csc(0))
 
@@ -551,9 +562,9 @@ class UniformCgDgHierarchy:
 
     def _dir_nodes(self):
         d = []
-        if self.bc[0][0] == 'dir':
+        if self.bc[0][0] == 'dir' and self.at_left:
             d.append((0, self.bc[0][1]))
-        if self.bc[1][0] == 'dir':
+        if self.bc[1][0] == 'dir' and self.at_right:
             d.append((self.n, self.bc[1][1]))
         return d
 
@@ -580,9 +591,9 @@ class UniformCgDgHierarchy:
         if p > 1:
             f[n + 1:] = fe[:, 2:].reshape(-1)
         (lk, lv), (rk, rv) = self.bc
-        if lk == 'neu':
+        if lk == 'neu' and self.at_left:
             f[0] += -lv
-        if rk == 'neu':
+        if rk == 'neu' and self.at_right:
             f[n] += rv
         extra = np.zeros(n + 1)
         dirv = np.zeros(n + 1, dtype=bool)
@@ -612,7 +623,8 @@ class UniformCgDgHierarchy:
         """value of L at (fine vertex v, coarse vertex v): the last element to touch a vertex writes it
         (src/interpolation.jl:47-52): local node 1 of the last element for vertex n, local node 0 otherwise"""
         vv = np.full(self.n + 1, lowVal[0, 0])
-        vv[self.n] = lowVal[1, 1]
+        if self.at_right:
+            vv[self.n] = lowVal[1, 1]
         return vv
 
     def _galerkin(self, Ke, extra, lowVal):

@@ -312,6 +312,17 @@ int aggmg_rccl_unique_id(aggmg_ctx* ctx, void* id_out, int nbytes);
 int aggmg_dist_init_rccl(aggmg_ctx* ctx, aggmg_dist* d, const void* id, int nbytes, int* nranks_out);
 int aggmg_dist_set_allgather(aggmg_ctx* ctx, aggmg_dist* d, aggmg_allgather_fn fn, void* user);
 int aggmg_dist_set_loopback(aggmg_ctx* ctx, aggmg_dist* d);
+/* Interface layout of a level whose DoFs are not contiguous per element (a CG level in the reference's
+ * vertices-first numbering, src/cg_mesh.jl:37-45,59-65: the interface is a slice of the vertex part plus
+ * a slice of the interior part).  count doubles per rank travel; send_*: slices [src, src + len) of the local
+ * vector packed at dst of this rank's part; left_* / right_*: slices of the left / right neighbour's part
+ * unpacked at dst of the local vector.  level: 0 (finest) or nlevels - 1 (coarsest).  Levels with contiguous
+ * elements need no call (first / last W elements, the default). */
+int aggmg_dist_set_exchange_layout(aggmg_ctx* ctx, aggmg_dist* d, int level, int64_t count, int nsend,
+                                   const int64_t* send_src, const int64_t* send_dst, const int64_t* send_len,
+                                   int nleft, const int64_t* left_src, const int64_t* left_dst, const int64_t* left_len,
+                                   int nright, const int64_t* right_src, const int64_t* right_dst,
+                                   const int64_t* right_len);
 /* One all-gather through the configured backend (count doubles per rank); also the smoke test of it. */
 int aggmg_dist_allgather_dev(aggmg_ctx* ctx, aggmg_dist* d, const double* send_dev, double* recv_dev, int64_t count);
 /* Fill the ghost entries of a local finest- or coarsest-level vector from the neighbours' owned

@@ -182,6 +182,69 @@ def test_block_gauss_seidel_partitioned():
             assert err == 0.0, (world, rank, err, scale)
 
 
+def _cg_worker(rank, world, port, n, ps, sweeps, q):
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle")]
+    import torch
+    import torch.distributed as dist
+    import agglomerationmultigrid1d_amd as mg
+    from agglomerationmultigrid1d_amd import distributed as D
+    from agglomerationmultigrid1d_amd.uniform import UniformCgDgHierarchy, build_device_cg_hierarchy
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        nPre, nPost = sweeps
+        ctx = mg.Context(0)
+        comm = D.Comm(world, rank, staged=True)
+        layout = D.CgRankLayout(n, ps, world, rank, nPre, nPost)
+        engine, U = D.build_local_cg(n, ps, layout, ctx, comm)
+        assert engine.H.level_kinds() == ['fused_chain'] * len(ps) + ['coarsest']
+        dv = D.NativeDistributedVCycle(engine, layout, comm, collectives="torch")
+        b = torch.from_numpy(U.rhs()).to(engine.dev)
+        x = engine.new(layout.local_dofs(0))
+        y = engine.new(layout.local_dofs(0))
+        for _ in range(3):
+            dv.vcycle(x, b, y, nPre, nPost, 2.0 / 3.0, overlap_next=True)
+            x, y = y, x
+        torch.cuda.synchronize()
+        got = x.cpu().numpy()[layout.owned_index(0)]
+        Ug = UniformCgDgHierarchy(n, ps=ps)
+        ctx2 = mg.Context(0)
+        Hg = build_device_cg_hierarchy(Ug, ctx2)
+        N = len(Ug.rhs())
+        bg = ctx2.to_device(Ug.rhs())
+        xa, xb = ctx2.to_device(np.zeros(N)), ctx2.alloc(N)
+        for _ in range(3):
+            Hg.vcycle_dev(xa, bg, xb, nPre, nPost, 2.0 / 3.0)
+            xa, xb = xb, xa
+        ref = xa.download()[layout.global_index(0)]
+        q.put((rank, float(np.max(np.abs(got - ref))), float(np.max(np.abs(ref))), dv.exchanges, dv.chunked))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n,ps,sweeps", [(2, 2048, (4, 2, 1), (3, 3)), (4, 2**13, (4, 2, 1), (3, 3)),
+                                              (2, 1024, (2, 1), (1, 2)), (3, 3 * 700, (3,), (2, 2))])
+def test_cg_chain_hierarchy_partitioned(world, n, ps, sweeps):
+    """BASELINE config 5's shape under element partitioning: CG p-chain (chain kernels on every rank's
+    sub-mesh, vertices-first local numbering, one shared vertex per interface) + DG p=0, the library's
+    schedule with its collectives over gloo -- owned vertices and interior nodes bitwise those of the
+    single-GPU cycle"""
+    import torch.multiprocessing as mp
+    from test_distributed_cpu import free_port
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=_cg_worker, args=(r, world, port, n, ps, sweeps, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    for pr in procs:
+        pr.join(900)
+    assert all(pr.exitcode == 0 for pr in procs), [pr.exitcode for pr in procs]
+    for rank, err, scale, nex, chunked in sorted(q.get() for _ in range(world)):
+        assert err == 0.0, (rank, err, scale)
+
+
 def _rccl_in_library_worker(port, q):
     sys.path[:0] = [ROOT]
     import torch
