@@ -13,10 +13,22 @@
 // ---------------------------------------------------------------------------------------------
 // tiles
 // ---------------------------------------------------------------------------------------------
+// slabs per thread (tile = NT / M * NS blocks): tuning knobs.  tools/exp_chain_tiles.sh on the config-5
+// hierarchy at 2^24 elements: one slab everywhere 4.22 ms per V-cycle, two 4.31, four (M <= 2) 4.36-4.41 --
+// occupancy beats the smaller halo share, as on the block-tridiagonal kernel
+#ifndef AGGMG_CGT_NS1
+#define AGGMG_CGT_NS1 1
+#endif
+#ifndef AGGMG_CGT_NS2
+#define AGGMG_CGT_NS2 1
+#endif
+#ifndef AGGMG_CGT_NS4
+#define AGGMG_CGT_NS4 1
+#endif
 template <int M>
 struct CgtTile {
   static constexpr int NT = kThreads;
-  static constexpr int NS = (M <= 4) ? 2 : 3;
+  static constexpr int NS = (M == 1) ? AGGMG_CGT_NS1 : (M == 2) ? AGGMG_CGT_NS2 : (M <= 4) ? AGGMG_CGT_NS4 : 3;
   static constexpr int EPS = NT / M;
   static constexpr int TE = EPS * NS;
 };

@@ -1,27 +1,42 @@
-"""Element-range partition of the V-cycle across the GPUs of one node (BASELINE config 4).
+"""Element-range partition of the V-cycle across the GPUs of one node (BASELINE configs 4 and 5).
 
-One process per GPU (`torch.distributed`, backend "nccl" == RCCL over xGMI; "gloo" for the CPU
-tests).  Rank r owns a contiguous range of fine elements and, level by level, the agglomerates
+One process per GPU (`torch.distributed`, backend "nccl" == RCCL over xGMI; "gloo" for the tests on
+one box).  Rank r owns a contiguous range of fine elements and, level by level, the agglomerates
 made of them; it stores its owned elements plus `W_k` ghost elements per side and runs the very
 same fused kernels on that local domain.
 
-Communication-avoiding schedule.  Block-Jacobi is order independent and in 1-D a sweep moves
-information by exactly one element, so instead of one interface exchange per operator
+Communication-avoiding schedule.  Jacobi / block-Jacobi sweeps are order independent and in 1-D a
+sweep moves information by exactly one element, so instead of one interface exchange per operator
 application (7 per level per cycle) the ghost layers are made deep enough that a whole V(nPre,
-nPost) cycle needs
+nPost) cycle needs THREE small all-gathers:
 
-    1. ONE all-gather of the interface DoFs of x0 (W_0 elements per side and rank), and
-    2. ONE all-gather of the owned part of the coarsest right-hand side,
+    1. the interface DoFs of x0 (W_0 elements per side and rank) -- issued under the previous cycle's
+       fine-level ascent on a second stream when the caller loops (overlap_next),
+    2. the coarsest solve across ranks: every rank eliminates the chunks of its own block range of the
+       cyclic reduction, the chunk-boundary system is all-gathered and solved redundantly,
+    3. after back substitution, the coarse ghost blocks
+       (small coarsest levels: ONE all-gather of the owned right-hand side + replicated solve instead
+       of 2 and 3),
 
 everything else being recomputed redundantly in the ghost layers (0.03 % extra work at 2^22
 elements on 8 ranks).  `halo_widths` derives the widths from (ratios, nPre, nPost) by tracking
-how far validity shrinks: a sweep costs one element per side, the residual one more, a transfer
-divides / multiplies by the ratio.  Owned values are bitwise those of the single-GPU run (same
-per-row arithmetic, tiles only differ in where they start).  The coarsest system is gathered
-and solved redundantly on every rank (block cyclic reduction on the device).
+how far validity shrinks: a sweep costs one element per side (two for the red-black Gauss-Seidel
+extension), the residual one more, a transfer divides / multiplies by the ratio.  Owned values are
+bitwise those of the single-GPU run (same per-row arithmetic, tiles only differ in where they start).
 
-The schedule is written against a small engine interface so that tests can run it on CPU
-(`gloo`, world_size 2) with a NumPy engine standing in for the GPU kernels.
+Two drivers of the same schedule:
+  * NativeDistributedVCycle -- the schedule inside libaggmg_hip.so (csrc/dist.hip, C ABI aggmg_dist_*):
+    one C call per cycle, RCCL all-gathers issued from C++ (or routed back to torch.distributed: the
+    gloo tests), optional hipGraph replay.  What bench.py runs.  DG / agglomerated hierarchies
+    (RankLayout, build_local_uniform; block Gauss-Seidel included) and CG p-chain hierarchies
+    (CgRankLayout, build_local_cg: vertices-first numbering on the rank's sub-mesh, one shared vertex
+    per interface).
+  * DistributedVCycle -- the same steps in Python against a small engine interface, so that CPU tests
+    can run it (`gloo`, world_size 2) with a NumPy engine standing in for the GPU kernels.
+
+No multi-GPU scaling curve has been measured: the build boxes have one GPU.  RCCL with more than one
+rank has never run here; the library's RCCL path is exercised with the single rank a box allows
+(tests/test_distributed_gpu.py) and the exchange pattern with 2 - 4 ranks over gloo.
 """
 import ctypes
 import json
@@ -812,11 +827,16 @@ def bench_main(args, rank, world, local_rank, nPre, nPost, alpha):
     dist.init_process_group(backend=backend, rank=rank, world_size=world)
     comm = Comm(world, rank, staged=(backend != "nccl"))
     ctx = mg.Context(device)
-    n = 2 ** args.log2_elems
+    cfg5 = getattr(args, "dist_config", 4) == 5
+    n = 2 ** (args.cg_log2_elems if cfg5 else args.log2_elems)
     ratios = (4, 2, 2)
     t_setup = time.perf_counter()
-    layout = RankLayout(n, ratios, [args.p + 1, 2, 2, 2], world, rank, nPre, nPost)
-    engine, U = build_local_uniform(n, args.p, 1, ratios, layout, ctx, comm)
+    if cfg5:      # CG p = 4, 2, 1 -> DG p = 0 (BASELINE config 5 shape), chain kernels on every rank's sub-mesh
+        layout = CgRankLayout(n, (4, 2, 1), world, rank, nPre, nPost)
+        engine, U = build_local_cg(n, (4, 2, 1), layout, ctx, comm)
+    else:
+        layout = RankLayout(n, ratios, [args.p + 1, 2, 2, 2], world, rank, nPre, nPost)
+        engine, U = build_local_uniform(n, args.p, 1, ratios, layout, ctx, comm)
     # the cycle runs inside the library (csrc/dist.hip).  Collectives: RCCL from C++ when the process
     # group is nccl; AGGMG_DIST_COLLECTIVES=torch routes them through torch.distributed instead (the
     # gloo rehearsal on a box with fewer GPUs than ranks needs that), =python keeps the Python schedule
@@ -838,7 +858,7 @@ def bench_main(args, rank, world, local_rank, nPre, nPost, alpha):
     bytes_model = U.algorithmic_bytes(nPre, nPost)
     del U
     t_setup = time.perf_counter() - t_setup
-    N = n * (args.p + 1)
+    N = (4 * n + 1) if cfg5 else n * (args.p + 1)
 
     src, dst = xa, xb
     # every cycle's output is the next cycle's x0 (the loop of multigrid, src/solvers.jl:124-126):
@@ -891,8 +911,10 @@ def bench_main(args, rank, world, local_rank, nPre, nPost, alpha):
             "unit": "DoF-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"config 4: config 3 hierarchy (DG p={args.p} n=2^{args.log2_elems} -> AggDG 4:1 -> "
-                                   f"2:1 -> 2:1, V(3,3)) partitioned by contiguous element range over {world} GPUs",
+            "config": {"workload": (f"config 5 shape: CG n=2^{args.cg_log2_elems} p=4 -> 2 -> 1 -> DG p=0, point-Jacobi, V(3,3), "
+                                    f"partitioned by contiguous element range over {world} GPUs" if cfg5 else
+                                    f"config 4: config 3 hierarchy (DG p={args.p} n=2^{args.log2_elems} -> AggDG 4:1 -> "
+                                    f"2:1 -> 2:1, V(3,3)) partitioned by contiguous element range over {world} GPUs"),
                        "fine_dofs": N, "nPre": nPre, "nPost": nPost,
                        "backend": backend,
                        "collectives": (getattr(dv, "collectives", "python schedule") if rccl_note is None else rccl_note),
@@ -903,9 +925,10 @@ def bench_main(args, rank, world, local_rank, nPre, nPost, alpha):
                                       f"(x0 interface exchange issued under the fine-level ascent), "
                                       + ("coarsest solve: chunk elimination on each rank's own blocks, boundary system replicated"
                                          if dv.chunked else "coarsest solve gathered and replicated")},
-            "roofline": {"bound": "hbm", "kernel": f"btd_fused_kernel<{args.p + 1},cmp> {dkind} level {dlevel + 1} (rank 0)",
+            "roofline": {"bound": "hbm", "kernel": (f"cgt_fused_kernel<4> {dkind} level {dlevel + 1} (rank 0)" if cfg5 else
+                                                    f"btd_fused_kernel<{args.p + 1},cmp> {dkind} level {dlevel + 1} (rank 0)"),
                          "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                         "traffic": None, "algorithmic_bytes_per_launch": per_launch,
+                         "frac_basis": "algorithmic", "traffic": None, "algorithmic_bytes_per_launch": per_launch,
                          "ms_per_launch": dms / dcnt, "launches_timed": dcnt},
             "kernels": {f"{k}_L{l}": {"ms_per_launch": v[0] / v[1], "launches": v[1]} for (k, l), v in sorted(prof.items())},
             "setup_s": t_setup,

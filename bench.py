@@ -58,6 +58,9 @@ def parse():
     ap.add_argument("--cpu-cycles", type=int, default=4)
     ap.add_argument("--cg-log2-elems", type=int, default=24,
                     help="N = 1 only: V-cycle on the CG p=4,2,1 -> DG p=0 hierarchy (config 5 shape) at 2^E elements; 0 = off")
+    ap.add_argument("--dist-config", type=int, default=4, choices=(4, 5),
+                    help="N > 1 only: 4 = the config-3 DG hierarchy partitioned (default, the north-star scaling series), "
+                         "5 = the CG p=4,2,1 -> DG p=0 hierarchy partitioned (2^cg-log2-elems elements)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-smoother-bench", action="store_true")
     return ap.parse_args()
@@ -287,6 +290,8 @@ def cg_bench(mg, ctx, args, nPre, nPost, alpha):
     ctx.profile_enable(False)
     prof = ctx.profile_collect()
     prof.update(dom)
+    H.vcycles_dev(state[0], b, state[1], steps, nPre, nPost, alpha)
+    dt_loop = _time_loop(ctx, lambda reps: H.vcycles_dev(state[0], b, state[1], reps, nPre, nPost, alpha), steps)
     vb = sum(l["vcycle"] for l in bm)
     kern = {f"{k}_L{l}": {"ms_per_launch": v[0] / v[1], "launches": v[1]} for (k, l), v in sorted(prof.items())}
     (dkind, dlevel), (dms, dcnt) = list(dom.items())[0]
@@ -307,6 +312,7 @@ def cg_bench(mg, ctx, args, nPre, nPost, alpha):
                         f"N_fine={N}, nnz(A_1)={nnz0}; level kernels {kinds}",
             "value": N * (nPre + nPost) * steps / dt, "unit": "DoF-updates/s", "ms_per_step": 1e3 * dt / steps,
             "median_ms_per_step": 1e3 * statistics.median(per),
+            "vcycles_loop_ms_per_cycle": 1e3 * dt_loop / steps,
             "achieved_algorithmic_GBs_vcycle": vb * steps / dt / 1e9, "frac_of_8TBs_vcycle": vb * steps / dt / 1e9 / HBM_PEAK_GBS,
             "roofline": {"bound": "hbm", "kernel": "cgt_fused_kernel<4> fused_down level 1 (3 sweeps + residual + restriction)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
