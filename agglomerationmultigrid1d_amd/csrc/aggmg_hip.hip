@@ -862,100 +862,132 @@ static void banded_solve(const BandedLU& f, double* b) {
 // coarsest-level direct solve on the device: block cyclic reduction (factored once on the device,
 // setup_cr in setup.hip; solved per cycle here)
 // ---------------------------------------------------------------------------------------------
+static int cr_env_int(const char* name, int dflt) {
+  const char* e = std::getenv(name);
+  return e && *e ? std::atoi(e) : dflt;
+}
+static int cr_stage_threads() {
+  static const int t = std::min(std::max(cr_env_int("AGGMG_CR_THREADS", kCrThreads), 64), kCrThreads);
+  return t;
+}
+
+static CrStageArgs cr_make_args(const CrDev& cr, const CrStage& S, bool tail) {
+  CrStageArgs A;
+  std::memset(&A, 0, sizeof(A));
+  A.q = S.q;
+  for (int l = 0; l < S.q; ++l) A.lv[l] = cr.lv[S.l0 + l];
+  A.nsteps = S.nsteps;
+  for (int s = 0; s <= kCrMaxSteps; ++s) {
+    A.step_a[s] = S.step_a[s];
+    A.lds_off[s] = S.lds_off[s];
+    A.lds_xoff[s] = S.lds_xoff[s];
+  }
+  A.lds_total = S.lds_total;
+  A.n_out = S.n_out;
+  A.stack = S.stack;
+  A.stack_stride = S.stack_stride;
+  A.tail = tail ? 1 : 0;
+  A.lu_last = cr.lu_last;
+  A.perm_last = cr.perm_last;
+  return A;
+}
+
+// Stages s0.. and the tail for the right-hand side d (+ db) of stage s0's input system into x:
+// forward launches stage by stage (the last one goes on to solve the tail system in its
+// last-arriving workgroup), then the back substitutions in reverse.
+template <int M>
+static int cr_solve_from(aggmg_ctx* ctx, CrDev& cr, int s0, const double* d, const double* db, double* x) {
+  const int ns = (int)cr.st.size();
+  const CrStageArgs T = cr_make_args(cr, cr.tail, true);
+  const size_t tail_lds = (size_t)cr.tail.lds_total * sizeof(double);
+  static const bool fuse_tail = [] {
+    const char* e = std::getenv("AGGMG_CR_FUSE_TAIL");
+    return e && e[0] == '1';
+  }();
+  if (s0 >= ns) {
+    hipLaunchKernelGGL((cr_tail_kernel<M>), dim3(1), dim3(kCrThreads), tail_lds, ctx->stream, T, d, db, x);
+    HIPCHK(hipGetLastError());
+    return AGGMG_OK;
+  }
+  const double *din = d, *dinb = db;
+  for (int s = s0; s < ns; ++s) {
+    const CrStage& S = cr.st[s];
+    const CrStageArgs A = cr_make_args(cr, S, false);
+    const unsigned grid = (unsigned)std::max<int64_t>(S.n_out, 1);
+    const size_t lds = (size_t)S.lds_total * sizeof(double);
+    if (s == ns - 1 && fuse_tail) {
+      hipLaunchKernelGGL((cr_stage_forward_kernel<M, true>), dim3(grid), dim3(cr_stage_threads()), std::max(lds, tail_lds),
+                         ctx->stream, A, din, dinb, S.partR, S.partL, T, S.xq, cr.ticket);
+    } else {
+      hipLaunchKernelGGL((cr_stage_forward_kernel<M, false>), dim3(grid), dim3(cr_stage_threads()), lds, ctx->stream, A, din,
+                         dinb, S.partR, S.partL, T, (double*)nullptr, (unsigned int*)nullptr);
+      if (s == ns - 1)
+        hipLaunchKernelGGL((cr_tail_kernel<M>), dim3(1), dim3(kCrThreads), tail_lds, ctx->stream, T,
+                           (const double*)S.partR, (const double*)S.partL, S.xq);
+    }
+    din = S.partR;
+    dinb = S.partL;
+  }
+  for (int s = ns - 1; s >= s0; --s) {
+    const CrStage& S = cr.st[s];
+    const CrStageArgs A = cr_make_args(cr, S, false);
+    const unsigned grid = (unsigned)std::max<int64_t>(S.n_out, 1);
+    const double* ds = s == s0 ? d : cr.st[s - 1].partR;
+    const double* dsb = s == s0 ? db : cr.st[s - 1].partL;
+    double* xs = s == s0 ? x : cr.st[s - 1].xq;
+    hipLaunchKernelGGL((cr_stage_backward_kernel<M>), dim3(grid), dim3(cr_stage_threads()), (size_t)S.lds_total * sizeof(double),
+                       ctx->stream, A, ds, dsb, (const double*)S.xq, xs);
+  }
+  HIPCHK(hipGetLastError());
+  return AGGMG_OK;
+}
+
 template <int M>
 static int cr_solve_t(aggmg_ctx* ctx, CrDev& cr, const double* rhs, double* out) {
-  const int nl = (int)cr.lv.size();
-  const int g = cr.nglobal, q = cr.q;
   const int64_t Npad = cr.n0 * M;
   // without padding the caller's vectors are used in place (no staging copies)
   const bool direct = (Npad == cr.N) && rhs != out;
-  const double* d0 = direct ? rhs : cr.d[0];
-  double* x0 = direct ? out : cr.x[0];
-  if (!direct) {
-    if (Npad > cr.N) HIPCHK(hipMemsetAsync(cr.d[0] + cr.N, 0, (Npad - cr.N) * sizeof(double), ctx->stream));
-    HIPCHK(hipMemcpyAsync(cr.d[0], rhs, cr.N * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+  if (direct) return cr_solve_from<M>(ctx, cr, 0, rhs, nullptr, out);
+  if (!cr.d0) {  // in-place call on an unpadded system: staging vectors on first use
+    for (double** p : {&cr.d0, &cr.x0}) {
+      HIPCHK(hipMalloc((void**)p, Npad * sizeof(double)));
+      cr.owned.push_back(*p);
+    }
   }
-  auto dl = [&](int l) -> const double* { return l == 0 ? d0 : cr.d[l]; };
-  auto xl = [&](int l) -> double* { return l == 0 ? x0 : cr.x[l]; };
-  for (int l = 0; l < g; ++l) {
-    const int64_t nt = cr.lv[l].n_even;
-    hipLaunchKernelGGL((cr_forward_kernel<M>), dim3((unsigned)((nt + kThreads - 1) / kThreads)), dim3(kThreads), 0,
-                       ctx->stream, cr.lv[l], dl(l), cr.d[l + 1]);
-  }
-  CrTail T;
-  std::memset(&T, 0, sizeof(T));
-  T.nlev = nl - (g + q);
-  for (int l = 0; l < T.nlev; ++l) T.lv[l] = cr.lv[g + q + l];
-  T.lu_last = cr.lu_last;
-  T.perm_last = cr.perm_last;
-  if (q > 0) {
-    CrChunk C;
-    std::memset(&C, 0, sizeof(C));
-    C.q = q;
-    for (int l = 0; l < q; ++l) C.lv[l] = cr.lv[g + l];
-    C.nq = g + q < nl ? cr.lv[g + q].n : 1;
-    C.stack = cr.stack;
-    C.stack_stride = cr.stack_stride;
-    // one workgroup per block surviving the chunk levels: chunk c = blocks [c 2^q, (c+1) 2^q]
-    const unsigned grid = (unsigned)C.nq;
-    hipLaunchKernelGGL((cr_chunk_forward_kernel<M>), dim3(std::max(grid, 1u)), dim3(kThreads), cr.chunk_lds,
-                       ctx->stream, C, dl(g), cr.partR, cr.partL);
-    hipLaunchKernelGGL((cr_tail_kernel<M>), dim3(1), dim3(1024), cr.tail_lds, ctx->stream, T,
-                       (const double*)cr.partR, (const double*)cr.partL, cr.xq);
-    hipLaunchKernelGGL((cr_chunk_backward_kernel<M>), dim3(std::max(grid, 1u)), dim3(kThreads), cr.chunk_lds,
-                       ctx->stream, C, dl(g), (const double*)cr.xq, xl(g));
-  } else {
-    hipLaunchKernelGGL((cr_tail_kernel<M>), dim3(1), dim3(1024), cr.tail_lds, ctx->stream, T, dl(g),
-                       (const double*)nullptr, xl(g));
-  }
-  for (int l = g - 1; l >= 0; --l) {
-    const int64_t nt = cr.lv[l].n;
-    hipLaunchKernelGGL((cr_backward_kernel<M>), dim3((unsigned)((nt + kThreads - 1) / kThreads)), dim3(kThreads), 0,
-                       ctx->stream, cr.lv[l], dl(l), (const double*)cr.x[l + 1], xl(l));
-  }
-  HIPCHK(hipGetLastError());
-  if (!direct) HIPCHK(hipMemcpyAsync(out, cr.x[0], cr.N * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+  double *d0 = cr.d0, *x0 = cr.x0;
+  if (Npad > cr.N) HIPCHK(hipMemsetAsync(d0 + cr.N, 0, (Npad - cr.N) * sizeof(double), ctx->stream));
+  HIPCHK(hipMemcpyAsync(d0, rhs, cr.N * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+  CHECK(cr_solve_from<M>(ctx, cr, 0, d0, nullptr, x0));
+  HIPCHK(hipMemcpyAsync(out, x0, cr.N * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
   return AGGMG_OK;
 }
 
 // ---- the three phases of the chunked solve, separately (element-partitioned runs: every rank
-// eliminates / back-substitutes only the chunks of its own block range, the boundary system is
-// gathered and solved redundantly) ------------------------------------------------------------
+// eliminates / back-substitutes only the stage-0 chunks of its own block range, the boundary system
+// is gathered and solved redundantly: later stages + tail) ---------------------------------------
 template <int M>
 static int cr_phase_t(aggmg_ctx* ctx, CrDev& cr, int phase, const double* d_owned, int64_t blk_lo, int64_t blk_hi,
                       double* partR, double* partL, const double* xq, double* x_owned) {
-  const int nl = (int)cr.lv.size();
-  const int q = cr.q;
-  CrTail T;
-  std::memset(&T, 0, sizeof(T));
-  T.nlev = nl - q;
-  for (int l = 0; l < T.nlev; ++l) T.lv[l] = cr.lv[q + l];
-  T.lu_last = cr.lu_last;
-  T.perm_last = cr.perm_last;
-  if (phase == 1) {  // boundary system
-    hipLaunchKernelGGL((cr_tail_kernel<M>), dim3(1), dim3(1024), cr.tail_lds, ctx->stream, T, (const double*)partR,
-                       (const double*)partL, const_cast<double*>(xq));
-    HIPCHK(hipGetLastError());
-    return AGGMG_OK;
-  }
-  CrChunk C;
-  std::memset(&C, 0, sizeof(C));
-  C.q = q;
-  for (int l = 0; l < q; ++l) C.lv[l] = cr.lv[l];
-  C.nq = q < nl ? cr.lv[q].n : 1;
-  C.stack = cr.stack;
-  C.stack_stride = cr.stack_stride;
-  C.c0 = blk_lo >> q;
+  if (phase == 1)  // boundary system
+    return cr_solve_from<M>(ctx, cr, 1, partR, partL, const_cast<double*>(xq));
+  const CrStage& S = cr.st[0];
+  CrStageArgs A = cr_make_args(cr, S, false);
+  const int q = S.q;
+  A.c0 = blk_lo >> q;
   const int64_t c1 = (blk_hi + ((int64_t)1 << q) - 1) >> q;
-  const unsigned grid = (unsigned)std::max<int64_t>(c1 - C.c0, 0);
+  const unsigned grid = (unsigned)std::max<int64_t>(c1 - A.c0, 0);
   if (!grid) return AGGMG_OK;
   const double* d0 = d_owned - blk_lo * M;  // global block indexing; only owned blocks are touched
-  if (phase == 0)
-    hipLaunchKernelGGL((cr_chunk_forward_kernel<M>), dim3(grid), dim3(kThreads), cr.chunk_lds, ctx->stream, C, d0,
-                       partR, partL);
-  else
-    hipLaunchKernelGGL((cr_chunk_backward_kernel<M>), dim3(grid), dim3(kThreads), cr.chunk_lds, ctx->stream, C, d0,
-                       xq, x_owned - blk_lo * M);
+  const size_t lds = (size_t)S.lds_total * sizeof(double);
+  if (phase == 0) {
+    CrStageArgs T;
+    std::memset(&T, 0, sizeof(T));
+    hipLaunchKernelGGL((cr_stage_forward_kernel<M, false>), dim3(grid), dim3(cr_stage_threads()), lds, ctx->stream, A, d0,
+                       (const double*)nullptr, partR, partL, T, (double*)nullptr, (unsigned int*)nullptr);
+  } else {
+    hipLaunchKernelGGL((cr_stage_backward_kernel<M>), dim3(grid), dim3(cr_stage_threads()), lds, ctx->stream, A, d0,
+                       (const double*)nullptr, xq, x_owned - blk_lo * M);
+  }
   HIPCHK(hipGetLastError());
   return AGGMG_OK;
 }
@@ -1496,9 +1528,9 @@ extern "C" int aggmg_coarse_plan(aggmg_ctx* ctx, const aggmg_hier* h, int* chunk
                                  int* block_size, int64_t* n_blocks) {
   if (!ctx || !h) return AGGMG_ERR_ARGUMENT;
   const CrDev& cr = h->cr;
-  const bool ok = cr.valid && cr.nglobal == 0 && cr.q > 0 && cr.n0 * cr.m == cr.N;
-  if (chunk_log2) *chunk_log2 = ok ? cr.q : -1;
-  if (n_boundary) *n_boundary = ok ? ((int)cr.lv.size() > cr.q ? cr.lv[cr.q].n : 1) : 0;
+  const bool ok = cr.valid && !cr.st.empty() && cr.n0 * cr.m == cr.N;
+  if (chunk_log2) *chunk_log2 = ok ? cr.st[0].q : -1;
+  if (n_boundary) *n_boundary = ok ? cr.st[0].n_out : 0;
   if (block_size) *block_size = cr.valid ? cr.m : 0;
   if (n_blocks) *n_blocks = cr.valid ? cr.n0 : 0;
   return AGGMG_OK;
@@ -1508,9 +1540,9 @@ static int coarse_phase_check(aggmg_ctx* ctx, aggmg_hier* h, int64_t blk_lo, int
   if (!ctx) return AGGMG_ERR_ARGUMENT;
   if (!h) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_coarse_*: NULL hierarchy");
   const CrDev& cr = h->cr;
-  if (!(cr.valid && cr.nglobal == 0 && cr.q > 0 && cr.n0 * cr.m == cr.N))
+  if (!(cr.valid && !cr.st.empty() && cr.n0 * cr.m == cr.N))
     return fail(ctx, AGGMG_ERR_UNSUPPORTED, "aggmg_coarse_*: this hierarchy has no chunked cyclic-reduction plan");
-  const int64_t mask = ((int64_t)1 << cr.q) - 1;
+  const int64_t mask = ((int64_t)1 << cr.st[0].q) - 1;
   if (blk_lo < 0 || blk_hi > cr.n0 || blk_lo > blk_hi || (blk_lo & mask) || ((blk_hi & mask) && blk_hi != cr.n0))
     return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_coarse_*: block range must be aligned to the chunk size");
   return AGGMG_OK;

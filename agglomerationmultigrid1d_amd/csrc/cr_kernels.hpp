@@ -1,0 +1,572 @@
+// Coarsest-level direct solve of libaggmg_hip: block cyclic reduction (gfx950, wave64, fp64),
+// factored once on the device (setup.hip), solved per cycle here.  Replaces `A_n \ rhs_n`
+// (UMFPACK) of src/solvers.jl:39.
+//
+// Level l holds n block rows  a_i x_{i-1} + b_i x_i + c_i x_{i+1} = d_i  (m x m blocks).
+// Odd rows are eliminated with their pivoted LU factors (never an explicit inverse):
+//   forward   d'_j     = d_{2j} - a_{2j} (b_{2j-1} \ d_{2j-1}) - c_{2j} (b_{2j+1} \ d_{2j+1})
+//   backward  x_{2j+1} = b_{2j+1} \ (d_{2j+1} - a_{2j+1} x_{2j} - c_{2j+1} x_{2j+2})
+//
+// Schedule.  A dependent chain of log2(n) levels is latency, not bandwidth, so the levels are
+// taken three at a time: a *thread* owns the 2^3 + 1 blocks [8b, 8b + 8] of its sub-chunk, keeps
+// them in registers and runs three levels on them without any synchronisation -- every factor it
+// needs is addressable up front, i.e. one memory round trip per step instead of one per level.
+// Sub-chunk boundary blocks stay even on all three levels; each of the two sub-chunks sharing one
+// adds its own side's terms (R: the right-hand sub-chunk incl. d itself, L: the left-hand one) and
+// the consumer sums the two.  A workgroup repeats such steps on the boundary blocks in LDS until
+// its chunk of 2^q blocks is down to its two end blocks (a "stage": one launch forward, one
+// backward; the first step streams the level's vector and factors from HBM, all later ones are
+// 8, 64, ... times smaller); the boundary system of all chunks is the next stage's input, and
+// what fits one workgroup (the "tail") is reduced to a single block and solved back in the same
+// launch -- by the workgroup of the last stage that finishes last.  2^24 scalar rows: one stage
+// (q = 12) + tail = 2 launches forward/tail, 1 backward.
+//
+// The forward pass touches the off-diagonal blocks of the even rows only, the backward pass those
+// of the odd rows: stored apart (parity-split, a and c of one row adjacent) so that every fetched
+// line is used in full.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace aggmg {
+
+constexpr int kCrThreads = 256;
+constexpr int kCrTailRows = 4096;  // scalar rows (blocks * m) the single-workgroup tail takes
+constexpr int kCrMaxLevels = 40;
+constexpr int kCrMaxStageLevels = 12;
+constexpr int kCrMaxSteps = 8;
+
+struct CrLevel {
+  const double* fe;    // [n_even][2][M][M]  (a_{2j}, c_{2j})
+  const double* fo;    // [n_odd][2][M][M]   (a_{2j+1}, c_{2j+1})
+  const double* lu;    // [n_odd][M][M]  unit-lower L and U of the row-permuted b_{2j+1}
+  const int32_t* perm; // [n_odd][M]     row permutation: (P b) = L U, solve uses rhs[perm[k]]
+  int64_t n, n_even, n_odd;
+};
+
+// levels a thread takes per step: register budget (2^Q + 1 + ... blocks of M doubles)
+template <int M>
+struct CrRadix {
+  static constexpr int Q = M <= 4 ? 3 : 2;
+};
+
+// One launch: q levels in steps; step s runs local levels [step_a[s], step_a[s + 1]).
+// LDS (doubles): for s = 1 .. nsteps the boundary vectors of local level step_a[s]:
+//   R at lds_off[s], L at lds_off[s] + cnt_s, X (back substitution) at lds_xoff[s];
+//   cnt_s = ((1 << (q - step_a[s])) + 1) * M.
+struct CrStageArgs {
+  CrLevel lv[kCrMaxStageLevels];
+  int q;
+  int nsteps;
+  int step_a[kCrMaxSteps + 1];
+  int lds_off[kCrMaxSteps + 1];
+  int lds_xoff[kCrMaxSteps + 1];
+  int lds_total;
+  int64_t n_out;  // blocks left after the q levels
+  int64_t c0;     // first chunk of this launch (element-partitioned runs launch a sub-range)
+  double* stack;  // [n_chunks][stack_stride]: summed inputs of steps 1 .. nsteps-1, or null
+  int stack_stride;
+  int tail;       // one chunk = the whole system, n_out == 1: the last block is solved with lu_last
+  const double* lu_last;
+  const int32_t* perm_last;
+};
+
+__device__ __forceinline__ int64_t cr_level_n(const CrStageArgs& A, int l) { return l < A.q ? A.lv[l].n : A.n_out; }
+
+// register-resident sub-chunk: sub-level i holds 2^(QS-i) + 1 blocks, stacked
+template <int QS, int I>
+struct CrOff {
+  static constexpr int blocks = CrOff<QS, I - 1>::blocks + (1 << (QS - (I - 1))) + 1;
+};
+template <int QS>
+struct CrOff<QS, 0> {
+  static constexpr int blocks = 0;
+};
+
+// (a, c) of one row: 2 M^2 doubles, 16-byte aligned
+template <int M>
+__device__ __forceinline__ void cr_load_pair(const double* __restrict__ p, double (&ac)[2 * M * M]) {
+  const double2* p2 = reinterpret_cast<const double2*>(p);
+#pragma unroll
+  for (int k = 0; k < M * M; ++k) {
+    const double2 t = p2[k];
+    ac[2 * k] = t.x;
+    ac[2 * k + 1] = t.y;
+  }
+}
+
+// y = b \ r for one block, r in registers: rows gathered through the stored permutation by select
+// chains, then unit-lower and upper substitution (the getrs order)
+template <int M>
+__device__ __forceinline__ void cr_lu_solve_reg(const double* __restrict__ lu, const int32_t* __restrict__ perm,
+                                                const double* r, double (&y)[M]) {
+  if constexpr (M == 1) {
+    y[0] = r[0] / lu[0];
+  } else {
+    double f[M * M];
+#pragma unroll
+    for (int k = 0; k < M * M; ++k) f[k] = lu[k];
+    // (opaque copies: left as loads, the selects are folded into a variable-offset access and the
+    // whole sub-chunk array drops out of registers into scratch)
+    double rv[M];
+#pragma unroll
+    for (int q = 0; q < M; ++q) {
+      rv[q] = r[q];
+      asm("" : "+v"(rv[q]));
+    }
+#pragma unroll
+    for (int k = 0; k < M; ++k) {
+      const int32_t pk = perm[k];
+      double v = rv[0];
+#pragma unroll
+      for (int q = 1; q < M; ++q) v = (pk == q) ? rv[q] : v;
+      y[k] = v;
+    }
+#pragma unroll
+    for (int i = 1; i < M; ++i) {
+      double s = y[i];
+#pragma unroll
+      for (int j = 0; j < i; ++j) s -= f[i * M + j] * y[j];
+      y[i] = s;
+    }
+#pragma unroll
+    for (int i = M - 1; i >= 0; --i) {
+      double s = y[i];
+#pragma unroll
+      for (int j = i + 1; j < M; ++j) s -= f[i * M + j] * y[j];
+      y[i] = s / f[i * M + i];
+    }
+  }
+}
+
+// The sub-chunk code below is branch-free on purpose: a load under a run-time condition cannot be
+// hoisted, and every sub-level would wait a full memory round trip of its own -- the very latency
+// chain this schedule is there to remove.  Rows past the end of the level are handled by clamping
+// their index to a row that exists (loads stay in bounds) and discarding the value with a select.
+
+// sub-levels I .. QS-1 of sub-chunk b forward: v[sub-level I] -> v[sub-level I + 1]
+template <int M, int QS, int I>
+__device__ __forceinline__ void cr_loc_fwd(const CrLevel* lv, int64_t b, double* v) {
+  if constexpr (I < QS) {
+    const CrLevel& L = lv[I];
+    constexpr int NB1 = 1 << (QS - I - 1);  // next sub-level: blocks 0 .. NB1
+    const int64_t tlo1 = b << (QS - I - 1);
+    int64_t thi = (b + 1) << (QS - I);
+    if (thi > L.n - 1) thi = L.n - 1;
+    const int64_t tlo = tlo1 << 1;
+    double* d = v + CrOff<QS, I>::blocks * M;
+    double* dn = v + CrOff<QS, I + 1>::blocks * M;
+    // b \ d of the odd rows, each used by both even neighbours; zero for rows that do not exist
+    double y[NB1][M];
+#pragma unroll
+    for (int jj = 0; jj < NB1; ++jj) {
+      const bool ok = tlo + 2 * jj + 1 <= thi;
+      int64_t idx = tlo1 + jj;
+      if (idx > L.n_odd - 1) idx = L.n_odd - 1;
+      double t[M];
+      cr_lu_solve_reg<M>(L.lu + idx * (M * M), L.perm + idx * M, d + (2 * jj + 1) * M, t);
+#pragma unroll
+      for (int e = 0; e < M; ++e) y[jj][e] = ok ? t[e] : 0.0;
+    }
+#pragma unroll
+    for (int jj = 0; jj <= NB1; ++jj) {
+      int64_t j = tlo1 + jj;
+      if (j > L.n_even - 1) j = L.n_even - 1;  // a row that does not exist: its result is never read
+      double ac[2 * M * M], acc[M];
+      cr_load_pair<M>(L.fe + j * (2 * M * M), ac);
+#pragma unroll
+      for (int e = 0; e < M; ++e) acc[e] = d[(2 * jj) * M + e];
+      if (jj > 0) {
+#pragma unroll
+        for (int i = 0; i < M; ++i)
+#pragma unroll
+          for (int k = 0; k < M; ++k) acc[i] -= ac[i * M + k] * y[jj > 0 ? jj - 1 : 0][k];
+      }
+      if (jj < NB1) {
+#pragma unroll
+        for (int i = 0; i < M; ++i)
+#pragma unroll
+          for (int k = 0; k < M; ++k) acc[i] -= ac[M * M + i * M + k] * y[jj < NB1 ? jj : 0][k];
+      }
+#pragma unroll
+      for (int e = 0; e < M; ++e) dn[jj * M + e] = acc[e];
+    }
+    cr_loc_fwd<M, QS, I + 1>(lv, b, v);
+  }
+}
+
+// sub-levels I .. 0 of sub-chunk b backward: x of sub-level I + 1 (in v) -> x of sub-level I,
+// overwriting the reduced right-hand sides in place (odd rows read only their own d)
+template <int M, int QS, int I>
+__device__ __forceinline__ void cr_loc_bwd(const CrLevel* lv, int64_t b, double* v) {
+  if constexpr (I >= 0) {
+    const CrLevel& L = lv[I];
+    constexpr int NB1 = 1 << (QS - I - 1);
+    const int64_t tlo1 = b << (QS - I - 1);
+    const int64_t tlo = tlo1 << 1;
+    double* d = v + CrOff<QS, I>::blocks * M;
+    const double* xn = v + CrOff<QS, I + 1>::blocks * M;
+#pragma unroll
+    for (int jj = 0; jj < NB1; ++jj) {  // odd rows 2 jj + 1 (rows past the end: values never written out)
+      const int64_t r = tlo + 2 * jj + 1;
+      int64_t idx = tlo1 + jj;
+      if (idx > L.n_odd - 1) idx = L.n_odd - 1;
+      double ac[2 * M * M], rhs[M], x[M];
+      cr_load_pair<M>(L.fo + idx * (2 * M * M), ac);
+      const bool has_next = r + 1 < L.n;
+      double xr[M];
+#pragma unroll
+      for (int k = 0; k < M; ++k) xr[k] = has_next ? xn[(jj + 1) * M + k] : 0.0;
+#pragma unroll
+      for (int i = 0; i < M; ++i) {
+        double s = d[(2 * jj + 1) * M + i];
+#pragma unroll
+        for (int k = 0; k < M; ++k) s -= ac[i * M + k] * xn[jj * M + k];
+#pragma unroll
+        for (int k = 0; k < M; ++k) s -= ac[M * M + i * M + k] * xr[k];
+        rhs[i] = s;
+      }
+      cr_lu_solve_reg<M>(L.lu + idx * (M * M), L.perm + idx * M, rhs, x);
+#pragma unroll
+      for (int e = 0; e < M; ++e) d[(2 * jj + 1) * M + e] = x[e];
+    }
+#pragma unroll
+    for (int jj = 0; jj <= NB1; ++jj)  // even rows: the coarser solution
+#pragma unroll
+      for (int e = 0; e < M; ++e) d[(2 * jj) * M + e] = xn[jj * M + e];
+    cr_loc_bwd<M, QS, I - 1>(lv, b, v);
+  }
+}
+
+// geometry of step s for chunk c
+struct CrStepGeom {
+  int a, a1;            // local levels in / out
+  int64_t lo_in, lo_out;
+  int64_t n_in, n_out;  // blocks of the two levels (whole system)
+  int nb;               // sub-chunks of this workgroup
+};
+
+template <int QS>
+__device__ __forceinline__ CrStepGeom cr_step_geom(const CrStageArgs& A, int s, int64_t c, bool wg_shared) {
+  CrStepGeom g;
+  g.a = A.step_a[s];
+  g.a1 = g.a + QS;
+  g.lo_in = c << (A.q - g.a);
+  g.lo_out = c << (A.q - g.a1);
+  g.n_in = cr_level_n(A, g.a);
+  g.n_out = cr_level_n(A, g.a1);
+  int64_t hi_out = (c + 1) << (A.q - g.a1);
+  if (hi_out > g.n_out - 1) hi_out = g.n_out - 1;
+  g.nb = (int)(hi_out - g.lo_out + 1) - (wg_shared ? 1 : 0);
+  return g;
+}
+
+// sub-level 0 of sub-chunk b from the step's input vector: global d0 (+ d0b) for step 0, the LDS
+// boundary vectors R + L otherwise.  A shared right boundary's value belongs to the next sub-chunk
+// (which reads R + L in full) -- except the workgroup's own right end in the later steps
+// (carry_rb): no sub-chunk of this workgroup owns it, and the L terms the earlier steps collected
+// for it have to travel on to partL.
+template <int M, int QS>
+__device__ __forceinline__ void cr_loc_load(const CrStageArgs& A, int s, const CrStepGeom& g, int64_t b,
+                                            const double* __restrict__ d0, const double* __restrict__ d0b,
+                                            const double* sh, double* v, int64_t& thi, bool& tshared,
+                                            bool carry_rb) {
+  constexpr int NB = 1 << QS;
+  const int64_t tlo = b << QS;
+  thi = (b + 1) << QS;
+  tshared = thi <= g.n_in - 1;
+  if (!tshared) thi = g.n_in - 1;
+  if (s == 0) {
+    if (tshared) {  // a full sub-chunk: NB * M contiguous doubles, 16-byte aligned
+      const double2* p = reinterpret_cast<const double2*>(d0 + tlo * M);
+      if (d0b) {
+        const double2* pb = reinterpret_cast<const double2*>(d0b + tlo * M);
+#pragma unroll
+        for (int k = 0; k < NB * M / 2; ++k) {
+          const double2 t = p[k], u = pb[k];
+          v[2 * k] = t.x + u.x;
+          v[2 * k + 1] = t.y + u.y;
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < NB * M / 2; ++k) {
+          const double2 t = p[k];
+          v[2 * k] = t.x;
+          v[2 * k + 1] = t.y;
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < M; ++e) v[NB * M + e] = 0.0;
+    } else {
+      // (the loads of one vector in one batch: a test of d0b per element would serialise them)
+#pragma unroll
+      for (int k = 0; k <= NB; ++k) {
+        const int64_t gk = tlo + k <= thi ? tlo + k : thi;
+#pragma unroll
+        for (int e = 0; e < M; ++e) v[k * M + e] = d0[gk * M + e];
+      }
+      if (d0b) {
+#pragma unroll
+        for (int k = 0; k <= NB; ++k) {
+          const int64_t gk = tlo + k <= thi ? tlo + k : thi;
+#pragma unroll
+          for (int e = 0; e < M; ++e) v[k * M + e] += d0b[gk * M + e];
+        }
+      }
+#pragma unroll
+      for (int k = 0; k <= NB; ++k) {
+        const bool ok = tlo + k <= thi;
+#pragma unroll
+        for (int e = 0; e < M; ++e) v[k * M + e] = ok ? v[k * M + e] : 0.0;
+      }
+    }
+  } else {
+    const int cnt = ((1 << (A.q - g.a)) + 1) * M;
+    const double* R = sh + A.lds_off[s];
+    const double* Lp = R + cnt;
+#pragma unroll
+    for (int k = 0; k <= NB; ++k) {
+      const bool ok = tlo + k <= thi && !(tshared && k == NB && !carry_rb);
+      const int idx = (int)((tlo + k <= thi ? tlo + k : thi) - g.lo_in) * M;
+#pragma unroll
+      for (int e = 0; e < M; ++e) {
+        const double x = R[idx + e] + Lp[idx + e];
+        v[k * M + e] = ok ? x : 0.0;
+      }
+    }
+  }
+}
+
+template <int M, int QS>
+__device__ __forceinline__ void cr_step_forward(const CrStageArgs& A, int s, int64_t c, bool wg_shared,
+                                                const double* __restrict__ d0, const double* __restrict__ d0b,
+                                                double* sh) {
+  const CrStepGeom g = cr_step_geom<QS>(A, s, c, wg_shared);
+  const int cnt_out = ((1 << (A.q - g.a1)) + 1) * M;
+  double* Rout = sh + A.lds_off[s + 1];
+  double* Lout = Rout + cnt_out;
+  for (int i = threadIdx.x; i < g.nb; i += blockDim.x) {
+    const int64_t b = g.lo_out + i;
+    double v[CrOff<QS, QS + 1>::blocks * M];
+    int64_t thi;
+    bool tshared;
+    cr_loc_load<M, QS>(A, s, g, b, d0, d0b, sh, v, thi, tshared, wg_shared && s > 0 && i == g.nb - 1);
+    cr_loc_fwd<M, QS, 0>(&A.lv[g.a], b, v);
+    const double* top = v + CrOff<QS, QS>::blocks * M;
+#pragma unroll
+    for (int e = 0; e < M; ++e) Rout[i * M + e] = top[e];
+    if (b + 1 <= g.n_out - 1) {
+#pragma unroll
+      for (int e = 0; e < M; ++e) Lout[(i + 1) * M + e] = top[M + e];
+    }
+  }
+}
+
+// xtop: x of the step's output level, indexed by block - xtop_lo (LDS, or the global boundary
+// solution); xout: x of the step's input level (LDS for s >= 1, the caller's vector for s == 0)
+template <int M, int QS>
+__device__ __forceinline__ void cr_step_backward(const CrStageArgs& A, int s, int64_t c, bool wg_shared,
+                                                 const double* __restrict__ d0, const double* __restrict__ d0b,
+                                                 const double* xtop, int64_t xtop_lo, double* xout, int64_t xout_lo,
+                                                 double* sh) {
+  constexpr int NB = 1 << QS;
+  const CrStepGeom g = cr_step_geom<QS>(A, s, c, wg_shared);
+  for (int i = threadIdx.x; i < g.nb; i += blockDim.x) {
+    const int64_t b = g.lo_out + i;
+    double v[CrOff<QS, QS + 1>::blocks * M];
+    int64_t thi;
+    bool tshared;
+    cr_loc_load<M, QS>(A, s, g, b, d0, d0b, sh, v, thi, tshared, wg_shared && s > 0 && i == g.nb - 1);
+    cr_loc_fwd<M, QS, 0>(&A.lv[g.a], b, v);
+    double* top = v + CrOff<QS, QS>::blocks * M;
+    const bool has_right = b + 1 <= g.n_out - 1;
+    const int64_t br = has_right ? b + 1 : b;
+#pragma unroll
+    for (int e = 0; e < M; ++e) {
+      top[e] = xtop[(b - xtop_lo) * M + e];
+      const double xr = xtop[(br - xtop_lo) * M + e];
+      top[M + e] = has_right ? xr : 0.0;
+    }
+    cr_loc_bwd<M, QS, QS - 1>(&A.lv[g.a], b, v);
+    const int64_t tlo = b << QS;
+    double* o = xout + (tlo - xout_lo) * M;
+    if (tshared && s == 0) {
+      double2* o2 = reinterpret_cast<double2*>(o);
+#pragma unroll
+      for (int k = 0; k < NB * M / 2; ++k) o2[k] = make_double2(v[2 * k], v[2 * k + 1]);
+    } else {
+      // own blocks; a shared right boundary is the next sub-chunk's, except that the last sub-chunk of
+      // the workgroup leaves it in LDS for the finer steps
+      const bool write_rb = tshared && s > 0 && i == g.nb - 1;
+#pragma unroll
+      for (int k = 0; k <= NB; ++k) {
+        const bool w = k < NB ? (tlo + k <= thi) : (tshared ? write_rb : (tlo + k <= thi));
+        if (w) {
+#pragma unroll
+          for (int e = 0; e < M; ++e) o[k * M + e] = v[k * M + e];
+        }
+      }
+    }
+  }
+}
+
+template <int M>
+__device__ __forceinline__ void cr_forward_steps(const CrStageArgs& A, int64_t c, bool wg_shared,
+                                                 const double* __restrict__ d0, const double* __restrict__ d0b,
+                                                 double* sh) {
+  constexpr int Q = CrRadix<M>::Q;
+  for (int s = 0; s < A.nsteps; ++s) {
+    const int qs = A.step_a[s + 1] - A.step_a[s];
+    if (qs == 1) {
+      cr_step_forward<M, 1>(A, s, c, wg_shared, d0, d0b, sh);
+    } else if (qs == 2) {
+      cr_step_forward<M, 2>(A, s, c, wg_shared, d0, d0b, sh);
+    } else {
+      if constexpr (Q >= 3) cr_step_forward<M, 3>(A, s, c, wg_shared, d0, d0b, sh);
+    }
+    __syncthreads();
+  }
+}
+
+// xq: the solution at the chunk's end blocks (global, level-q block index), or null when the top
+// vector is already in LDS (tail)
+template <int M>
+__device__ __forceinline__ void cr_backward_steps(const CrStageArgs& A, int64_t c, bool wg_shared,
+                                                  const double* __restrict__ d0, const double* __restrict__ d0b,
+                                                  const double* __restrict__ xq, double* __restrict__ x0, double* sh) {
+  constexpr int Q = CrRadix<M>::Q;
+  for (int s = A.nsteps - 1; s >= 0; --s) {
+    const int a = A.step_a[s], a1 = A.step_a[s + 1];
+    const int qs = a1 - a;
+    const bool top_global = xq && s == A.nsteps - 1;
+    const double* xtop = top_global ? xq : sh + A.lds_xoff[s + 1];
+    const int64_t xtop_lo = top_global ? 0 : (c << (A.q - a1));
+    double* xout = s ? sh + A.lds_xoff[s] : x0;
+    const int64_t xout_lo = s ? (c << (A.q - a)) : 0;
+    if (qs == 1) {
+      cr_step_backward<M, 1>(A, s, c, wg_shared, d0, d0b, xtop, xtop_lo, xout, xout_lo, sh);
+    } else if (qs == 2) {
+      cr_step_backward<M, 2>(A, s, c, wg_shared, d0, d0b, xtop, xtop_lo, xout, xout_lo, sh);
+    } else {
+      if constexpr (Q >= 3) cr_step_backward<M, 3>(A, s, c, wg_shared, d0, d0b, xtop, xtop_lo, xout, xout_lo, sh);
+    }
+    __syncthreads();
+  }
+}
+
+// the calling workgroup solves the whole tail system (T.tail) for d0 (+ d0b) into x0
+template <int M>
+__device__ __forceinline__ void cr_tail_body(const CrStageArgs& T, const double* __restrict__ d0,
+                                             const double* __restrict__ d0b, double* __restrict__ x0, double* sh) {
+  for (int t = threadIdx.x; t < T.lds_total; t += blockDim.x) sh[t] = 0.0;
+  __syncthreads();
+  if (T.nsteps == 0) {  // a single block
+    if (threadIdx.x == 0) {
+      double r[M], y[M];
+#pragma unroll
+      for (int e = 0; e < M; ++e) r[e] = d0b ? d0[e] + d0b[e] : d0[e];
+      cr_lu_solve_reg<M>(T.lu_last, T.perm_last, r, y);
+#pragma unroll
+      for (int e = 0; e < M; ++e) x0[e] = y[e];
+    }
+    return;
+  }
+  cr_forward_steps<M>(T, 0, false, d0, d0b, sh);
+  if (threadIdx.x == 0) {
+    const double* R = sh + T.lds_off[T.nsteps];
+    double r[M], y[M];
+#pragma unroll
+    for (int e = 0; e < M; ++e) r[e] = R[e] + R[2 * M + e];
+    cr_lu_solve_reg<M>(T.lu_last, T.perm_last, r, y);
+    double* X = sh + T.lds_xoff[T.nsteps];
+#pragma unroll
+    for (int e = 0; e < M; ++e) X[e] = y[e];
+  }
+  __syncthreads();
+  cr_backward_steps<M>(T, 0, false, d0, d0b, nullptr, x0, sh);
+}
+
+template <int M>
+__global__ __launch_bounds__(kCrThreads) void cr_tail_kernel(CrStageArgs T, const double* __restrict__ d0,
+                                                             const double* __restrict__ d0b,
+                                                             double* __restrict__ x0) {
+  extern __shared__ double sh[];
+  cr_tail_body<M>(T, d0, d0b, x0, sh);
+}
+
+// One workgroup per chunk c = blocks [c 2^q, (c+1) 2^q] of the stage's first level: the chunk's
+// end blocks go to partR[c] (this side's terms incl. d) / partL[c + 1] (terms for the next chunk's
+// left end).  FUSE_TAIL: the workgroup that finishes last (ticket counter) goes on to solve the
+// boundary system with the tail levels -- forward elimination and boundary solve in one launch.
+template <int M, bool FUSE_TAIL>
+__global__ __launch_bounds__(kCrThreads) void cr_stage_forward_kernel(CrStageArgs A, const double* __restrict__ d0,
+                                                                      const double* __restrict__ d0b, double* partR,
+                                                                      double* partL, CrStageArgs T, double* xq,
+                                                                      unsigned int* ticket) {
+  extern __shared__ double sh[];
+  __shared__ unsigned int s_ticket;
+  const int64_t c = A.c0 + blockIdx.x;
+  const bool wg_shared = ((c + 1) << A.q) <= A.lv[0].n - 1;
+  for (int t = threadIdx.x; t < A.lds_total; t += blockDim.x) sh[t] = 0.0;
+  __syncthreads();
+  cr_forward_steps<M>(A, c, wg_shared, d0, d0b, sh);
+  {
+    const double* R = sh + A.lds_off[A.nsteps];  // level q: blocks c, c + 1
+    if (threadIdx.x < M) {
+      partR[c * M + threadIdx.x] = R[threadIdx.x];
+      if (c + 1 <= A.n_out - 1) partL[(c + 1) * M + threadIdx.x] = R[2 * M + M + threadIdx.x];
+    }
+  }
+  // the summed inputs of the later steps are kept for the back substitution (a few hundred values
+  // per chunk) instead of recomputing every step there
+  if (A.stack) {
+    double* st = A.stack + c * (int64_t)A.stack_stride;
+    int o = 0;
+    for (int s = 1; s < A.nsteps; ++s) {
+      const int cnt = ((1 << (A.q - A.step_a[s])) + 1) * M;
+      const double* R = sh + A.lds_off[s];
+      for (int t = threadIdx.x; t < cnt; t += blockDim.x) st[o + t] = R[t] + R[cnt + t];
+      o += cnt;
+    }
+  }
+  if constexpr (FUSE_TAIL) {
+    __threadfence();  // partR / partL of this workgroup visible device-wide before the ticket
+    __syncthreads();
+    if (threadIdx.x == 0) s_ticket = atomicAdd(ticket, 1u);
+    __syncthreads();
+    if (s_ticket != gridDim.x - 1) return;
+    __threadfence();  // acquire: every other workgroup's partR / partL
+    cr_tail_body<M>(T, partR, partL, xq, sh);
+    if (threadIdx.x == 0) *ticket = 0u;  // ready for the next solve (stream-ordered)
+  }
+}
+
+template <int M>
+__global__ __launch_bounds__(kCrThreads) void cr_stage_backward_kernel(CrStageArgs A, const double* __restrict__ d0,
+                                                                       const double* __restrict__ d0b,
+                                                                       const double* __restrict__ xq,
+                                                                       double* __restrict__ x0) {
+  extern __shared__ double sh[];
+  const int64_t c = A.c0 + blockIdx.x;
+  const bool wg_shared = ((c + 1) << A.q) <= A.lv[0].n - 1;
+  for (int t = threadIdx.x; t < A.lds_total; t += blockDim.x) sh[t] = 0.0;
+  __syncthreads();
+  if (A.nsteps > 1) {
+    if (A.stack) {
+      const double* st = A.stack + c * (int64_t)A.stack_stride;
+      int o = 0;
+      for (int s = 1; s < A.nsteps; ++s) {
+        const int cnt = ((1 << (A.q - A.step_a[s])) + 1) * M;
+        double* R = sh + A.lds_off[s];
+        for (int t = threadIdx.x; t < cnt; t += blockDim.x) R[t] = st[o + t];
+        o += cnt;
+      }
+      __syncthreads();
+    } else {
+      cr_forward_steps<M>(A, c, wg_shared, d0, d0b, sh);
+    }
+  }
+  cr_backward_steps<M>(A, c, wg_shared, d0, d0b, xq, x0, sh);
+}
+
+}  // namespace aggmg

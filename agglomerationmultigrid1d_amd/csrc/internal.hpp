@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "kernels.hpp"
+#include "cr_kernels.hpp"
 #include "cgt_kernels.hpp"
 
 using namespace aggmg;
@@ -178,6 +179,20 @@ struct BandedLU {
 };
 
 // block cyclic reduction of the coarsest operator, factored once (device-resident)
+// one launch of the cyclic reduction: levels [l0, l0 + q) in steps of up to three thread-local levels
+// (cr_kernels.hpp); chunk stages reduce 2^q-block chunks to their end blocks, the tail takes the rest
+struct CrStage {
+  int l0 = 0, q = 0;
+  int64_t n_in = 0, n_out = 0;  // blocks before / after
+  int nsteps = 0;
+  int step_a[kCrMaxSteps + 1] = {0};
+  int lds_off[kCrMaxSteps + 1] = {0}, lds_xoff[kCrMaxSteps + 1] = {0};
+  int lds_total = 0;            // doubles
+  double *partR = nullptr, *partL = nullptr, *xq = nullptr;  // the stage's boundary system (n_out blocks)
+  double* stack = nullptr;      // per chunk: summed inputs of the steps after the first
+  int stack_stride = 0;
+};
+
 struct CrDev {
   bool valid = false;
   int m = 0;
@@ -186,15 +201,38 @@ struct CrDev {
   std::vector<void*> owned;     // every device allocation, for free
   const double* lu_last = nullptr;
   const int32_t* perm_last = nullptr;
-  int nglobal = 0;              // leading levels run as their own launches (only for very large systems)
-  int q = 0;                    // next q levels run chunk-wise in LDS (one launch forward, one backward)
-  std::vector<double*> d, x;    // per-level vectors for levels 0..nglobal
-  double *partR = nullptr, *partL = nullptr, *xq = nullptr;  // chunk-boundary vectors (level nglobal+q)
-  double* stack = nullptr;      // per-chunk reduced right-hand sides of the chunk levels
-  int stack_stride = 0;
-  size_t tail_lds = 0, chunk_lds = 0;
+  std::vector<CrStage> st;      // chunk stages ...
+  CrStage tail;                 // ... then the remaining levels in one workgroup
+  double *d0 = nullptr, *x0 = nullptr;  // staging for padded systems (N not a multiple of m) / in-place calls
+  unsigned int* ticket = nullptr;       // last-arriving-workgroup counter of the fused forward + tail launch
   double cond_est = 0.0;
 };
+
+// step split and LDS layout of a stage of q levels with block size m
+inline void cr_plan_steps(CrStage* S, int m) {
+  const int Q = m <= 4 ? 3 : 2;
+  S->nsteps = 0;
+  S->step_a[0] = 0;
+  for (int a = 0; a < S->q;) {
+    const int qs = std::min(Q, S->q - a);
+    a += qs;
+    S->step_a[++S->nsteps] = a;
+  }
+  int o = 0;
+  for (int s = 1; s <= S->nsteps; ++s) {
+    const int cnt = ((1 << (S->q - S->step_a[s])) + 1) * m;
+    S->lds_off[s] = o;
+    o += 2 * cnt;
+  }
+  for (int s = 1; s <= S->nsteps; ++s) {
+    const int cnt = ((1 << (S->q - S->step_a[s])) + 1) * m;
+    S->lds_xoff[s] = o;
+    o += cnt;
+  }
+  S->lds_total = o;
+  S->stack_stride = 0;
+  for (int s = 1; s < S->nsteps; ++s) S->stack_stride += ((1 << (S->q - S->step_a[s])) + 1) * m;
+}
 
 struct aggmg_hier {
   std::vector<Level> lv;

@@ -728,347 +728,4 @@ __global__ __launch_bounds__(NT) void btd_fused_kernel(FusedArgs a) {
   }
 }
 
-// ------------------------------------------------------------------------------------------
-// coarsest-level direct solve: block cyclic reduction, factored once on the host
-// ------------------------------------------------------------------------------------------
-// Level l holds n block rows  a_i x_{i-1} + b_i x_i + c_i x_{i+1} = d_i  (m x m blocks).
-// Odd rows are eliminated with their pivoted LU factors (never an explicit inverse):
-//   forward   d'_j   = d_{2j} - a_{2j} (b_{2j-1} \ d_{2j-1}) - c_{2j} (b_{2j+1} \ d_{2j+1})
-//   backward  x_{2j+1} = b_{2j+1} \ (d_{2j+1} - a_{2j+1} x_{2j} - c_{2j+1} x_{2j+2})
-// The Schur-complement blocks of the next level are formed on the host at set-up.
-struct CrLevel {
-  const double* a;     // [n][M][M]
-  const double* c;     // [n][M][M]
-  const double* lu;    // [n_odd][M][M]  unit-lower L and U of the row-permuted b_{2j+1}
-  const int32_t* perm; // [n_odd][M]     row permutation: (P b) = L U, solve uses rhs[perm[k]]
-  int64_t n, n_even, n_odd;
-};
-
-// y = b \ r for one block: r gathered through the stored row permutation, then unit-lower and
-// upper substitution (the getrs order)
-template <int M>
-__device__ __forceinline__ void cr_lu_solve(const double* __restrict__ lu, const int32_t* __restrict__ perm,
-                                            const double* r, double (&y)[M]) {
-#pragma unroll
-  for (int k = 0; k < M; ++k) y[k] = r[perm[k]];
-#pragma unroll
-  for (int i = 1; i < M; ++i) {
-    double s = y[i];
-#pragma unroll
-    for (int j = 0; j < i; ++j) s -= lu[i * M + j] * y[j];
-    y[i] = s;
-  }
-#pragma unroll
-  for (int i = M - 1; i >= 0; --i) {
-    double s = y[i];
-#pragma unroll
-    for (int j = i + 1; j < M; ++j) s -= lu[i * M + j] * y[j];
-    y[i] = s / lu[i * M + i];
-  }
-}
-
-// d'_j of the next level from this level's vector d (indexable by level-local block index);
-// neighbours outside [lo, hi] are skipped (domain ends, or chunk ends whose terms another
-// workgroup accounts for)
-template <int M>
-__device__ __forceinline__ void cr_forward_block_range(const CrLevel& L, int64_t j, const double* d, double* dn,
-                                                       int64_t lo, int64_t hi) {
-  double acc[M], y[M];
-#pragma unroll
-  for (int i = 0; i < M; ++i) acc[i] = d[(2 * j) * M + i];
-  if (2 * j - 1 >= lo) {
-    cr_lu_solve<M>(L.lu + (j - 1) * M * M, L.perm + (j - 1) * M, d + (2 * j - 1) * M, y);
-    const double* A = L.a + (2 * j) * M * M;
-#pragma unroll
-    for (int i = 0; i < M; ++i)
-#pragma unroll
-      for (int k = 0; k < M; ++k) acc[i] -= A[i * M + k] * y[k];
-  }
-  if (2 * j + 1 <= hi) {
-    cr_lu_solve<M>(L.lu + j * M * M, L.perm + j * M, d + (2 * j + 1) * M, y);
-    const double* C = L.c + (2 * j) * M * M;
-#pragma unroll
-    for (int i = 0; i < M; ++i)
-#pragma unroll
-      for (int k = 0; k < M; ++k) acc[i] -= C[i * M + k] * y[k];
-  }
-#pragma unroll
-  for (int i = 0; i < M; ++i) dn[j * M + i] = acc[i];
-}
-
-template <int M>
-__device__ __forceinline__ void cr_forward_block(const CrLevel& L, int64_t j, const double* d, double* dn) {
-  cr_forward_block_range<M>(L, j, d, dn, 0, L.n - 1);
-}
-
-// x of block row r (odd) given the coarser solution xn; rhs assembled in a small local array
-template <int M>
-__device__ __forceinline__ void cr_backward_block(const CrLevel& L, int64_t r, const double* d, const double* xn,
-                                                  double (&x)[M]) {
-  const int64_t j = r >> 1;
-  double rhs[M];
-#pragma unroll
-  for (int i = 0; i < M; ++i) rhs[i] = d[r * M + i];
-  const double* A = L.a + r * M * M;
-#pragma unroll
-  for (int i = 0; i < M; ++i)
-#pragma unroll
-    for (int k = 0; k < M; ++k) rhs[i] -= A[i * M + k] * xn[j * M + k];
-  if (r + 1 < L.n) {
-    const double* C = L.c + r * M * M;
-#pragma unroll
-    for (int i = 0; i < M; ++i)
-#pragma unroll
-      for (int k = 0; k < M; ++k) rhs[i] -= C[i * M + k] * xn[(j + 1) * M + k];
-  }
-  // permutation gather needs an addressable rhs: bounce through x (registers after unrolling)
-  double t[M];
-  const int32_t* perm = L.perm + j * M;
-#pragma unroll
-  for (int k = 0; k < M; ++k) {
-    double v = rhs[0];
-#pragma unroll
-    for (int q = 1; q < M; ++q) v = (perm[k] == q) ? rhs[q] : v;
-    t[k] = v;
-  }
-  const double* lu = L.lu + j * M * M;
-#pragma unroll
-  for (int i = 1; i < M; ++i) {
-    double s = t[i];
-#pragma unroll
-    for (int q = 0; q < i; ++q) s -= lu[i * M + q] * t[q];
-    t[i] = s;
-  }
-#pragma unroll
-  for (int i = M - 1; i >= 0; --i) {
-    double s = t[i];
-#pragma unroll
-    for (int q = i + 1; q < M; ++q) s -= lu[i * M + q] * t[q];
-    t[i] = s / lu[i * M + i];
-  }
-#pragma unroll
-  for (int i = 0; i < M; ++i) x[i] = t[i];
-}
-
-// one thread per even block row of this level -> block row of the next level
-template <int M>
-__global__ __launch_bounds__(kThreads) void cr_forward_kernel(CrLevel L, const double* __restrict__ d,
-                                                              double* __restrict__ dn) {
-  const int64_t j = (int64_t)blockIdx.x * kThreads + threadIdx.x;
-  if (j >= L.n_even) return;
-  cr_forward_block<M>(L, j, d, dn);
-}
-
-// one thread per block row of this level
-template <int M>
-__global__ __launch_bounds__(kThreads) void cr_backward_kernel(CrLevel L, const double* __restrict__ d,
-                                                               const double* __restrict__ xn,
-                                                               double* __restrict__ x) {
-  const int64_t r = (int64_t)blockIdx.x * kThreads + threadIdx.x;
-  if (r >= L.n) return;
-  if ((r & 1) == 0) {
-#pragma unroll
-    for (int i = 0; i < M; ++i) x[r * M + i] = xn[(r >> 1) * M + i];
-    return;
-  }
-  double xv[M];
-  cr_backward_block<M>(L, r, d, xn, xv);
-#pragma unroll
-  for (int i = 0; i < M; ++i) x[r * M + i] = xv[i];
-}
-
-// tail: all remaining levels (rows <= kCrTailRows) inside one workgroup, vectors in LDS
-constexpr int kCrTailRows = 2048;  // 2 * rows * 8 B of LDS stays well under the 64 KB default cap
-constexpr int kCrMaxLevels = 40;
-struct CrTail {
-  CrLevel lv[16];
-  int nlev;               // reducing levels handled here
-  const double* lu_last;  // [M][M] pivoted LU of the last remaining block
-  const int32_t* perm_last;
-};
-
-template <int M>
-__global__ __launch_bounds__(1024) void cr_tail_kernel(CrTail T, const double* __restrict__ d0,
-                                                       const double* __restrict__ d0b,
-                                                       double* __restrict__ x0) {
-  extern __shared__ double sh[];
-  // d of every tail level stacked (level l at off[l]); x overwrites d in place on the way back
-  __shared__ int off[18];
-  const int tid = threadIdx.x;
-  if (tid == 0) {
-    int o = 0;
-    for (int l = 0; l < T.nlev; ++l) {
-      off[l] = o;
-      o += (int)T.lv[l].n * M;
-    }
-    off[T.nlev] = o;  // the final single block
-  }
-  __syncthreads();
-  const int n0 = (int)(T.nlev ? T.lv[0].n : 1) * M;
-  for (int t = tid; t < n0; t += blockDim.x) sh[t] = d0b ? d0[t] + d0b[t] : d0[t];
-  __syncthreads();
-  for (int l = 0; l < T.nlev; ++l) {
-    const CrLevel L = T.lv[l];
-    for (int j = tid; j < (int)L.n_even; j += blockDim.x) cr_forward_block<M>(L, j, sh + off[l], sh + off[l + 1]);
-    __syncthreads();
-  }
-  if (tid == 0) {
-    double y[M];
-    double* dl = sh + off[T.nlev];
-    cr_lu_solve<M>(T.lu_last, T.perm_last, dl, y);
-#pragma unroll
-    for (int i = 0; i < M; ++i) dl[i] = y[i];
-  }
-  __syncthreads();
-  for (int l = T.nlev - 1; l >= 0; --l) {
-    const CrLevel L = T.lv[l];
-    double* d = sh + off[l];  // becomes x of this level
-    const double* xn = sh + off[l + 1];
-    // odd block rows read only their own d and xn: each thread may overwrite its own block
-    for (int r = tid; r < (int)L.n; r += blockDim.x) {
-      double xv[M];
-      if (r & 1) {
-        cr_backward_block<M>(L, r, d, xn, xv);
-      } else {
-#pragma unroll
-        for (int i = 0; i < M; ++i) xv[i] = xn[(r >> 1) * M + i];
-      }
-#pragma unroll
-      for (int i = 0; i < M; ++i) d[r * M + i] = xv[i];
-    }
-    __syncthreads();
-  }
-  for (int t = tid; t < n0; t += blockDim.x) x0[t] = sh[t];
-}
-
-// Chunked levels: the first q levels of the reduction only couple blocks less than 2^q apart, so a
-// workgroup can run them for the 2^q + 1 blocks [c 2^q, (c+1) 2^q] of its chunk entirely in LDS.
-// Chunk-boundary blocks stay even on all q levels; each of the two chunks sharing one adds its own
-// side's terms (partR: the right-hand chunk incl. d itself, partL: the left-hand chunk), the tail
-// kernel sums the two.  The back substitution recomputes the chunk's forward pass (interior values
-// do not depend on the boundary blocks) instead of storing q levels of vectors.
-constexpr int kCrMaxChunkLevels = 12;
-struct CrChunk {
-  CrLevel lv[kCrMaxChunkLevels];
-  int q;
-  int64_t nq;  // blocks left after the q chunk levels
-  int64_t c0;  // first chunk of this launch (element-partitioned runs launch a sub-range)
-  double* stack;     // [n_chunks][stack_stride] reduced right-hand sides of the chunk levels, or null
-  int stack_stride;
-};
-
-template <int M>
-__device__ __forceinline__ void cr_chunk_forward(const CrChunk& C, int64_t c, const double* __restrict__ d0,
-                                                 double* sh, const int* off, int64_t* lo, int64_t* hi) {
-  const int tid = threadIdx.x;
-  const int q = C.q;
-  for (int l = 0; l <= q; ++l) {
-    const int64_t nl = l < q ? C.lv[l].n : C.nq;
-    lo[l] = c << (q - l);
-    const int64_t h = (c + 1) << (q - l);
-    hi[l] = h < nl - 1 ? h : nl - 1;
-  }
-  const bool shared_right = ((c + 1) << q) <= C.lv[0].n - 1;
-  const int cnt0 = (int)(hi[0] - lo[0] + 1) * M;
-  for (int t = tid; t < cnt0; t += blockDim.x) {
-    const bool rb = shared_right && t >= cnt0 - M;  // the right boundary's own d belongs to the next chunk
-    sh[off[0] + t] = rb ? 0.0 : d0[lo[0] * M + t];
-  }
-  __syncthreads();
-  for (int l = 0; l < q; ++l) {
-    const double* d = sh + off[l] - lo[l] * M;
-    double* dn = sh + off[l + 1] - lo[l + 1] * M;
-    for (int64_t j = lo[l + 1] + tid; j <= hi[l + 1]; j += blockDim.x)
-      cr_forward_block_range<M>(C.lv[l], j, d, dn, lo[l], hi[l]);
-    __syncthreads();
-  }
-}
-
-template <int M>
-__global__ __launch_bounds__(kThreads) void cr_chunk_forward_kernel(CrChunk C, const double* __restrict__ d0,
-                                                                    double* __restrict__ partR,
-                                                                    double* __restrict__ partL) {
-  extern __shared__ double sh[];
-  __shared__ int off[kCrMaxChunkLevels + 2];
-  int64_t lo[kCrMaxChunkLevels + 1], hi[kCrMaxChunkLevels + 1];
-  if (threadIdx.x == 0) {
-    int o = 0;
-    for (int l = 0; l <= C.q; ++l) {
-      off[l] = o;
-      o += ((1 << (C.q - l)) + 1) * M;
-    }
-  }
-  __syncthreads();
-  const int64_t c = C.c0 + blockIdx.x;
-  cr_chunk_forward<M>(C, c, d0, sh, off, lo, hi);
-  const int q = C.q;
-  if (threadIdx.x < M) {
-    partR[c * M + threadIdx.x] = sh[off[q] + threadIdx.x];  // left boundary of this chunk (block c of level q)
-    if (hi[q] > lo[q]) partL[(c + 1) * M + threadIdx.x] = sh[off[q] + M + threadIdx.x];
-  }
-  // keep the reduced right-hand sides of all q levels for the back substitution (a few KB per
-  // chunk, L2 / Infinity-Cache resident) instead of recomputing the forward pass there
-  if (C.stack) {
-    const int len = off[q];
-    double* st = C.stack + c * (int64_t)C.stack_stride;
-    for (int t = threadIdx.x; t < len; t += blockDim.x) st[t] = sh[t];
-  }
-}
-
-template <int M>
-__global__ __launch_bounds__(kThreads) void cr_chunk_backward_kernel(CrChunk C, const double* __restrict__ d0,
-                                                                     const double* __restrict__ xq,
-                                                                     double* __restrict__ x0) {
-  extern __shared__ double sh[];
-  __shared__ int off[kCrMaxChunkLevels + 2];
-  int64_t lo[kCrMaxChunkLevels + 1], hi[kCrMaxChunkLevels + 1];
-  const int tid = threadIdx.x;
-  if (tid == 0) {
-    int o = 0;
-    for (int l = 0; l <= C.q; ++l) {
-      off[l] = o;
-      o += ((1 << (C.q - l)) + 1) * M;
-    }
-  }
-  __syncthreads();
-  const int64_t c = C.c0 + blockIdx.x;
-  const int q = C.q;
-  if (C.stack) {
-    for (int l = 0; l <= q; ++l) {
-      const int64_t nl = l < q ? C.lv[l].n : C.nq;
-      lo[l] = c << (q - l);
-      const int64_t h = (c + 1) << (q - l);
-      hi[l] = h < nl - 1 ? h : nl - 1;
-    }
-    const double* st = C.stack + c * (int64_t)C.stack_stride;
-    for (int t = tid; t < off[q]; t += blockDim.x) sh[t] = st[t];
-    __syncthreads();
-  } else {
-    cr_chunk_forward<M>(C, c, d0, sh, off, lo, hi);
-  }
-  const int cntq = (int)(hi[q] - lo[q] + 1) * M;
-  for (int t = tid; t < cntq; t += blockDim.x) sh[off[q] + t] = xq[lo[q] * M + t];
-  __syncthreads();
-  for (int l = q - 1; l >= 0; --l) {
-    const CrLevel& L = C.lv[l];
-    double* d = sh + off[l] - lo[l] * M;  // becomes x of this level
-    const double* xn = sh + off[l + 1] - lo[l + 1] * M;
-    for (int64_t r = lo[l] + tid; r <= hi[l]; r += blockDim.x) {
-      double xv[M];
-      if (r & 1) {
-        cr_backward_block<M>(L, r, d, xn, xv);
-      } else {
-#pragma unroll
-        for (int i = 0; i < M; ++i) xv[i] = xn[(r >> 1) * M + i];
-      }
-#pragma unroll
-      for (int i = 0; i < M; ++i) d[r * M + i] = xv[i];
-    }
-    __syncthreads();
-  }
-  const bool shared_right = ((c + 1) << q) <= C.lv[0].n - 1;
-  const int cnt0 = (int)(hi[0] - lo[0] + 1 - (shared_right ? 1 : 0)) * M;
-  for (int t = tid; t < cnt0; t += blockDim.x) x0[lo[0] * M + t] = sh[off[0] + t];
-}
-
 }  // namespace aggmg

@@ -416,16 +416,23 @@ static int cr_levels_t(aggmg_ctx* ctx, CrDev* cr, double* a, double* b, double* 
     LAUNCH((cr_schur_even_kernel<M>), ne, n, ne, (const double*)a, (const double*)b, (const double*)c, (const double*)Za,
            (const double*)Zc, a2, b2, c2);
     HIPCHK(hipStreamSynchronize(ctx->stream));  // Za / Zc leave scope
+    // the solve reads the off-diagonal blocks parity-split (forward: even rows, backward: odd rows)
+    double *fe = nullptr, *fo = nullptr;
+    CHECK(dalloc(ctx, &fe, ne * 2 * mm2, false));
+    own(fe);
+    CHECK(dalloc(ctx, &fo, std::max<int64_t>(no, 1) * 2 * mm2, false));
+    own(fo);
+    LAUNCH(cr_split_kernel, n * 2 * mm2, n, mm2, (const double*)a, (const double*)c, fe, fo);
+    HIPCHK(hipStreamSynchronize(ctx->stream));
     CrLevel L;
     L.n = n;
     L.n_even = ne;
     L.n_odd = no;
-    L.a = a;
-    L.c = c;
+    L.fe = fe;
+    L.fo = fo;
     L.lu = lu;
     L.perm = perm;
-    own(a);
-    own(c);
+    (void)hipFree(a), (void)hipFree(c);
     (void)hipFree(b);  // the diagonal blocks of this level live on in the odd factors and the next level
     cr->lv.push_back(L);
     a = a2;
@@ -536,50 +543,109 @@ int setup_cr(aggmg_ctx* ctx, const aggmg_op* Ac, int hint_m, CrDev* cr) {
     cr_release(cr);
     return AGGMG_OK;
   }
-  // plan: [g per-level launches, only if a chunk would not fit in LDS] -> q chunk levels -> the tail
+  // plan: chunk stages (one workgroup per 2^q-block chunk) until what is left fits the
+  // single-workgroup tail (cr_kernels.hpp)
   const int nl = (int)cr->lv.size();
   auto level_n = [&](int l) -> int64_t { return l < nl ? cr->lv[l].n : 1; };
-  int g = 0, q = 0;
-  for (;; ++g) {
-    q = 0;
-    while (g + q < nl && level_n(g + q) * m > kCrTailRows) ++q;
-    const size_t lds = ((size_t)(2 << q) + q + 2) * m * sizeof(double);
-    if (q <= kCrMaxChunkLevels && lds <= 48 * 1024) break;
-    if (g >= nl) break;
-  }
-  if (nl - (g + q) > 16) {
-    cr_release(cr);
-    return AGGMG_OK;
-  }
-  cr->nglobal = g;
-  cr->q = q;
-  {
-    size_t o = 0;
-    for (int l = 0; l <= q; ++l) o += ((size_t)(1 << (q - l)) + 1) * m;
-    cr->chunk_lds = o * sizeof(double);
-  }
-  int64_t rows = 0;
-  for (int l = g + q; l < nl; ++l) rows += cr->lv[l].n * m;
-  cr->tail_lds = (size_t)(rows + m) * sizeof(double);
   auto dz = [&](int64_t len, double** out) -> int {
     CHECK(dalloc(ctx, out, len, true));
     cr->owned.push_back(*out);
     return AGGMG_OK;
   };
-  for (int l = 0; l <= g; ++l) {
-    double *dd = nullptr, *xx = nullptr;
-    CHECK(dz(level_n(l) * m, &dd));
-    CHECK(dz(level_n(l) * m, &xx));
-    cr->d.push_back(dd);
-    cr->x.push_back(xx);
+  int l0 = 0;
+  while (l0 < nl && level_n(l0) * m > kCrTailRows) {
+    int need = 0;
+    while (l0 + need < nl && level_n(l0 + need) * m > kCrTailRows) ++need;
+    // large chunks (every thread at least one sub-chunk of the streaming first step) as long as a few
+    // hundred workgroups remain
+    int fill = 0;
+    {
+      const char* e = std::getenv("AGGMG_CR_FILL");
+      const int fmax = e && *e ? std::atoi(e) : 12;
+      const char* w = std::getenv("AGGMG_CR_MINWG");
+      const int minwg = w && *w ? std::atoi(w) : 256;
+      while (fill < fmax && (level_n(l0) >> (fill + 1)) >= minwg) ++fill;
+    }
+    CrStage S;
+    S.l0 = l0;
+    S.q = std::min({kCrMaxStageLevels, std::max(need, fill), nl - l0});
+    if (S.q < 1) break;
+    S.n_in = level_n(l0);
+    S.n_out = level_n(l0 + S.q);
+    cr_plan_steps(&S, m);
+    const int64_t nb = (S.n_out * m + 31) & ~(int64_t)31;  // the three boundary vectors in one allocation
+    CHECK(dz(3 * nb, &S.partR));
+    S.partL = S.partR + nb;  // partL[0] is never written: stays zero
+    S.xq = S.partL + nb;
+    if (S.stack_stride > 0) CHECK(dz((S.n_out + 1) * (int64_t)S.stack_stride, &S.stack));
+    cr->st.push_back(S);
+    l0 += S.q;
   }
-  if (q > 0) {
-    const int64_t nq = level_n(g + q) * m;
-    CHECK(dz(nq, &cr->partR));
-    CHECK(dz(nq, &cr->partL));  // partL[0] is never written: stays zero
-    CHECK(dz(nq, &cr->xq));
-    cr->stack_stride = (int)(cr->chunk_lds / sizeof(double));
-    CHECK(dz((level_n(g + q) + 1) * (int64_t)cr->stack_stride, &cr->stack));
+  if (nl - l0 > kCrMaxStageLevels || level_n(l0) * m > kCrTailRows) {
+    cr_release(cr);
+    return AGGMG_OK;
+  }
+  cr->tail.l0 = l0;
+  cr->tail.q = nl - l0;
+  cr->tail.n_in = level_n(l0);
+  cr->tail.n_out = 1;
+  cr_plan_steps(&cr->tail, m);
+  // The small levels (the tail and the last steps of the stage before it) are worked through by a
+  // few threads, one dependent step after the other: their factors go into ONE allocation, so that a
+  // step touches a couple of pages instead of four arrays per level each on a page of its own -- an
+  // address-translation miss per array is what such a step would otherwise wait for.
+  {
+    int pf = cr->tail.l0;
+    while (pf > 0 && level_n(pf - 1) * m <= 8 * kCrTailRows) --pf;
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t mm = (size_t)m * m;
+    size_t total = al(mm * sizeof(double)) + al(m * sizeof(int32_t));
+    for (int l = pf; l < nl; ++l) {
+      const CrLevel& L = cr->lv[l];
+      const size_t no = (size_t)std::max<int64_t>(L.n_odd, 1);
+      total += al(L.n_even * 2 * mm * sizeof(double)) + al(no * 2 * mm * sizeof(double)) + al(no * mm * sizeof(double)) +
+               al(no * m * sizeof(int32_t));
+    }
+    char* arena = nullptr;
+    HIPCHK(hipMalloc((void**)&arena, total));
+    size_t off = 0;
+    std::vector<void*> old;
+    auto move = [&](const void* src, size_t bytes) -> void* {
+      void* dst = arena + off;
+      (void)hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream);
+      off += al(bytes);
+      old.push_back(const_cast<void*>(src));
+      return dst;
+    };
+    for (int l = pf; l < nl; ++l) {
+      CrLevel& L = cr->lv[l];
+      const size_t no = (size_t)std::max<int64_t>(L.n_odd, 1);
+      L.fe = (const double*)move(L.fe, L.n_even * 2 * mm * sizeof(double));
+      L.fo = (const double*)move(L.fo, no * 2 * mm * sizeof(double));
+      L.lu = (const double*)move(L.lu, no * mm * sizeof(double));
+      L.perm = (const int32_t*)move(L.perm, no * m * sizeof(int32_t));
+    }
+    cr->lu_last = (const double*)move(cr->lu_last, mm * sizeof(double));
+    cr->perm_last = (const int32_t*)move(cr->perm_last, m * sizeof(int32_t));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    for (void* q : old) {
+      auto it = std::find(cr->owned.begin(), cr->owned.end(), q);
+      if (it != cr->owned.end()) cr->owned.erase(it);
+      (void)hipFree(q);
+    }
+    cr->owned.push_back(arena);
+  }
+  if (n * m != N) {
+    CHECK(dz(n * m, &cr->d0));
+    CHECK(dz(n * m, &cr->x0));
+  }
+  {
+    void* t = nullptr;
+    HIPCHK(hipMalloc(&t, sizeof(unsigned int)));
+    cr->owned.push_back(t);
+    cr->ticket = (unsigned int*)t;
+    HIPCHK(hipMemsetAsync(t, 0, sizeof(unsigned int), ctx->stream));
   }
   HIPCHK(hipStreamSynchronize(ctx->stream));
   cr->valid = true;

@@ -527,6 +527,18 @@ __global__ __launch_bounds__(kSetupThreads) void cr_pack_kernel(int64_t N, int m
   }
 }
 
+// parity-split storage of one level's off-diagonal blocks: fe[j] = (a_{2j}, c_{2j}), fo[j] = (a_{2j+1}, c_{2j+1})
+__global__ __launch_bounds__(kSetupThreads) void cr_split_kernel(int64_t n, int mm2, const double* __restrict__ a,
+                                                                 const double* __restrict__ c, double* __restrict__ fe,
+                                                                 double* __restrict__ fo) {
+  const int64_t t = (int64_t)blockIdx.x * kSetupThreads + threadIdx.x;
+  if (t >= n * 2 * mm2) return;
+  const int64_t r = t / (2 * mm2);
+  const int k = (int)(t - r * 2 * mm2);
+  double* dst = ((r & 1) ? fo : fe) + (r >> 1) * 2 * mm2 + k;
+  *dst = k < mm2 ? a[r * mm2 + k] : c[r * mm2 + k - mm2];
+}
+
 __device__ __forceinline__ void atomic_max_pos(double* addr, double v) {
   // non-negative doubles order like their bit patterns
   atomicMax(reinterpret_cast<unsigned long long*>(addr), (unsigned long long)__double_as_longlong(v));

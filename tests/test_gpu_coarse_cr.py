@@ -1,0 +1,126 @@
+"""The device coarsest solve on its own (csrc/cr_kernels.hpp; replaces `A_n \\ rhs_n`, src/solvers.jl:39):
+a one-level hierarchy's V-cycle IS the direct solve.  Block-tridiagonal systems of every instantiated block
+size and of sizes that take each path -- a single block, the single-workgroup tail alone, one chunk stage +
+tail (with and without the per-chunk stack, several sub-chunks per thread), ragged ends (n not a power of two,
+N not a multiple of m) -- against SciPy's sparse LU, on the residual (<= 1e-12 ||b||) and on
+the solution (cond * eps).  The phase-by-phase entry points of the element-partitioned driver
+(aggmg_coarse_chunk_forward_dev / _boundary_solve_dev / _chunk_backward_dev) are run for 1, 2 and 3 "ranks"
+on one GPU and must reproduce the one-call solve bit for bit."""
+import ctypes
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mg():
+    import agglomerationmultigrid1d_amd as mg
+    mg.default_context()
+    return mg
+
+
+def block_tridiag(nb, m, seed, ragged=0):
+    """random block-tridiagonal, block-diagonally dominant (pivot blocks well conditioned), not symmetric;
+    ragged: drop that many trailing rows/columns so that N is not a multiple of m"""
+    rng = np.random.default_rng(seed)
+    ii, jj = np.meshgrid(np.arange(m), np.arange(m), indexing="ij")
+    rows, cols, vals = [], [], []
+    for dr, dc, cnt, shift in ((0, 0, nb, 4.0 * m), (1, 0, nb - 1, 0.0), (0, 1, nb - 1, 0.0)):
+        if cnt <= 0:
+            continue
+        blk = rng.standard_normal((cnt, m, m)) + shift * np.eye(m)
+        e = np.arange(cnt)
+        rows.append(((e + dr)[:, None, None] * m + ii).ravel())
+        cols.append(((e + dc)[:, None, None] * m + jj).ravel())
+        vals.append(blk.ravel())
+    A = sp.csc_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(nb * m, nb * m))
+    N = nb * m - ragged
+    return sp.csc_matrix(A[:N, :N])
+
+
+def one_level(mg, A, mode=None):
+    from agglomerationmultigrid1d_amd import _lib
+    ctx = mg.default_context()
+    op = mg.DeviceOperator(A, _lib.OP_STIFFNESS, ctx)
+    H = mg.MeshHierarchy(None, [op], [], [], ctx=ctx, keep_host=False,
+                         coarse_mode=_lib.COARSE_DEVICE_CR if mode is None else mode)
+    return ctx, H
+
+
+CASES = [
+    # (blocks, m, ragged rows)
+    (1, 1, 0), (1, 3, 0), (2, 2, 0), (3, 1, 0), (7, 4, 0), (9, 2, 1),
+    (100, 1, 0), (513, 2, 0), (2048, 2, 0), (4096, 1, 0), (333, 5, 2), (500, 8, 3), (1000, 3, 0),   # tail only
+    (4097, 1, 0), (5000, 1, 0), (2049, 2, 0), (3001, 2, 1), (1500, 3, 0), (1025, 4, 0), (900, 5, 0), (600, 7, 0),
+    (513, 8, 0),                                                                                      # small stage
+    (1 << 15, 1, 0), ((1 << 15) + 3, 2, 0), ((1 << 16) - 1, 1, 0), (40000, 3, 2), (33000, 4, 0),      # stage + stack
+    ((1 << 17) + 5, 6, 0), (1 << 18, 2, 0), ((1 << 20) + 1, 1, 0), (1 << 21, 1, 0),                   # > 1 sub-chunk per thread
+]
+
+
+@pytest.mark.parametrize("nb,m,ragged", CASES)
+def test_cr_solve_matches_sparse_lu(mg, nb, m, ragged):
+    A = block_tridiag(nb, m, seed=nb * 31 + m, ragged=ragged)
+    N = A.shape[0]
+    ctx, H = one_level(mg, A)
+    info = H.coarse_info()
+    assert info["on_device"] and 1 <= info["block_size"] <= 8   # the smallest block size that fits the band
+    rng = np.random.default_rng(5)
+    b = rng.standard_normal(N)
+    bd, xd, z = ctx.to_device(b), ctx.alloc(N), ctx.to_device(np.zeros(N))
+    H.vcycle_dev(z, bd, xd, 0, 0, 1.0)
+    x = xd.download()
+    ref = spla.splu(A).solve(b)
+    assert np.linalg.norm(A @ x - b) <= 1e-12 * np.linalg.norm(b)
+    assert np.linalg.norm(x - ref) <= 1e-11 * np.linalg.norm(ref)
+    # further solves with the same handle (ticket counter / stack reuse)
+    b2 = rng.standard_normal(N)
+    y = ctx.alloc(N)
+    H.vcycle_dev(z, ctx.to_device(b2), y, 0, 0, 1.0)
+    x2 = y.download()
+    assert np.linalg.norm(A @ x2 - b2) <= 1e-12 * np.linalg.norm(b2)
+    H.vcycle_dev(z, bd, xd, 0, 0, 1.0)
+    assert np.array_equal(xd.download(), x)
+    H.free()
+
+
+@pytest.mark.parametrize("nb,m", [(1 << 14, 1), (1 << 15, 2), (3 << 13, 1), (1 << 16, 4), (1 << 20, 1)])
+def test_cr_phases_reproduce_the_one_call_solve(mg, nb, m):
+    """every 'rank' eliminates / back-substitutes the chunks of its own block range; the boundary system is solved
+    redundantly (here once).  Must equal the single-call solve bit for bit."""
+    A = block_tridiag(nb, m, seed=7 * nb + m)
+    N = A.shape[0]
+    ctx, H = one_level(mg, A)
+    c = ctx
+    q, nq, mb, nblk = ctypes.c_int(0), ctypes.c_int64(0), ctypes.c_int(0), ctypes.c_int64(0)
+    c.check(c.lib.aggmg_coarse_plan(c.handle, H.handle, ctypes.byref(q), ctypes.byref(nq), ctypes.byref(mb),
+                                    ctypes.byref(nblk)))
+    assert q.value > 0 and mb.value == m and nblk.value == nb
+    rng = np.random.default_rng(11)
+    b = rng.standard_normal(N)
+    bd, xd, z = ctx.to_device(b), ctx.alloc(N), ctx.to_device(np.zeros(N))
+    H.vcycle_dev(z, bd, xd, 0, 0, 1.0)
+    x = xd.download()
+    chunk = 1 << q.value
+    nchunks = (nb + chunk - 1) // chunk
+    for world in (1, 2, 3):
+        if nchunks < world:
+            continue
+        cuts = [((nchunks * r) // world) * chunk for r in range(world)] + [nb]
+        partR, partL = ctx.to_device(np.zeros((nq.value + 1) * m)), ctx.to_device(np.zeros((nq.value + 1) * m))
+        xq, out = ctx.alloc((nq.value + 1) * m), ctx.to_device(np.zeros(N))
+        for r in range(world):
+            lo, hi = cuts[r], cuts[r + 1]
+            c.check(c.lib.aggmg_coarse_chunk_forward_dev(c.handle, H.handle, bd.ptr.value + 8 * lo * m, lo, hi, partR.ptr,
+                                                         partL.ptr))
+        c.check(c.lib.aggmg_coarse_boundary_solve_dev(c.handle, H.handle, partR.ptr, partL.ptr, xq.ptr))
+        for r in range(world):
+            lo, hi = cuts[r], cuts[r + 1]
+            c.check(c.lib.aggmg_coarse_chunk_backward_dev(c.handle, H.handle, bd.ptr.value + 8 * lo * m, lo, hi, xq.ptr,
+                                                          out.ptr.value + 8 * lo * m))
+        assert np.array_equal(out.download(), x), world
+    H.free()

@@ -1,0 +1,61 @@
+"""Coarsest direct solve on its own (block cyclic reduction, csrc/cr_kernels.hpp): a one-level hierarchy's
+V-cycle is the solve.  Times it for the systems the benchmarked hierarchies end in -- 2^20 blocks of 2
+(config 3/4 at 2^24 elements), 2^24 scalar rows (config 5 at 2^24), and one rank's share of each."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import scipy.sparse as sp
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def block_tridiag(nb, m, seed=0):
+    rng = np.random.default_rng(seed)
+    ii, jj = np.meshgrid(np.arange(m), np.arange(m), indexing="ij")
+    rows, cols, vals = [], [], []
+    for dr, dc, cnt, shift in ((0, 0, nb, 4.0 * m), (1, 0, nb - 1, 0.0), (0, 1, nb - 1, 0.0)):
+        blk = rng.standard_normal((cnt, m, m)) + shift * np.eye(m)
+        e = np.arange(cnt)
+        rows.append(((e + dr)[:, None, None] * m + ii).ravel())
+        cols.append(((e + dc)[:, None, None] * m + jj).ravel())
+        vals.append(blk.ravel())
+    return sp.csc_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(nb * m, nb * m))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=str, default="24:1,20:2,21:1,17:2,18:2,14:1")
+    ap.add_argument("--steps", type=int, default=50)
+    args = ap.parse_args()
+    import agglomerationmultigrid1d_amd as mg
+    from agglomerationmultigrid1d_amd import _lib
+    ctx = mg.Context(0)
+    for case in args.cases.split(","):
+        lg, m = (int(v) for v in case.split(":"))
+        nb = 1 << lg
+        A = block_tridiag(nb, m)
+        N = A.shape[0]
+        op = mg.DeviceOperator(A, _lib.OP_STIFFNESS, ctx)
+        H = mg.MeshHierarchy(None, [op], [], [], ctx=ctx, keep_host=False, coarse_mode=_lib.COARSE_DEVICE_CR)
+        b = ctx.to_device(np.random.default_rng(1).standard_normal(N))
+        x, z = ctx.alloc(N), ctx.to_device(np.zeros(N))
+        for _ in range(3):
+            H.vcycle_dev(z, b, x, 0, 0, 1.0)
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            H.vcycle_dev(z, b, x, 0, 0, 1.0)
+        ctx.synchronize()
+        ms = 1e3 * (time.perf_counter() - t0) / args.steps
+        r = A @ x.download() - b.download()
+        print(json.dumps({"log2_blocks": lg, "m": m, "ms_per_solve": round(ms, 4), "rows_per_us": round(N / ms / 1e3, 1),
+                          "rel_residual": float(np.linalg.norm(r) / np.linalg.norm(b.download()))}), flush=True)
+        H.free()
+
+
+if __name__ == "__main__":
+    main()
