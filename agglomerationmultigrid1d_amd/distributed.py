@@ -487,15 +487,24 @@ class NativeDistributedVCycle:
         from . import _lib
         ctx, c = self.ctx, self.c
         buf = (ctypes.c_ubyte * _lib.RCCL_ID_BYTES)()
+        failed = None
         if c.rank == 0:
-            ctx.check(ctx.lib.aggmg_rccl_unique_id(ctx.handle, buf, _lib.RCCL_ID_BYTES))
+            try:
+                ctx.check(ctx.lib.aggmg_rccl_unique_id(ctx.handle, buf, _lib.RCCL_ID_BYTES))
+            except Exception as exc:      # still take part in the broadcast below: the other ranks are waiting in it
+                failed = exc
         if c.world > 1:
-            t = torch.tensor(list(buf), dtype=torch.uint8)
+            t = torch.tensor(list(buf) + [0 if failed else 1], dtype=torch.uint8)
             on_dev = (not c.staged) and c.dist.get_backend() == "nccl"
             if on_dev:
                 t = t.to(self.e.dev)
             c.dist.broadcast(t, src=0)
-            buf = (ctypes.c_ubyte * _lib.RCCL_ID_BYTES)(*t.cpu().tolist())
+            vals = t.cpu().tolist()
+            if not vals[-1]:
+                raise failed or RuntimeError("rank 0 could not create the RCCL unique id")
+            buf = (ctypes.c_ubyte * _lib.RCCL_ID_BYTES)(*vals[:-1])
+        elif failed:
+            raise failed
         n = ctypes.c_int(0)
         ctx.check(ctx.lib.aggmg_dist_init_rccl(ctx.handle, self.handle, buf, _lib.RCCL_ID_BYTES, ctypes.byref(n)))
         self.rccl_ranks = n.value
@@ -845,13 +854,22 @@ def bench_main(args, rank, world, local_rank, nPre, nPost, alpha):
     if mode == "python":
         dv = DistributedVCycle(engine, layout, comm)
     else:
+        dv, err = None, None
         try:
             dv = NativeDistributedVCycle(engine, layout, comm, collectives=mode)
-        except Exception as exc:         # RCCL not loadable / communicator failed: same schedule over torch.distributed
+        except Exception as exc:         # RCCL not loadable / communicator failed
             if mode != "rccl":
                 raise
-            rccl_note = f"in-library RCCL unavailable ({exc!r}); collectives through torch.distributed"
-            dv = NativeDistributedVCycle(engine, layout, comm, collectives="torch")
+            err = exc
+        if mode == "rccl":
+            # every rank has to take the same route: agree on the outcome before the first collective, and fall
+            # back together to the same schedule with its all-gathers issued through torch.distributed
+            ok = torch.tensor([0 if dv is None else 1], dtype=torch.int32,
+                              device=engine.dev if backend == "nccl" else "cpu")
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                rccl_note = f"in-library RCCL unavailable on at least one rank ({err!r}); collectives through torch.distributed"
+                dv = NativeDistributedVCycle(engine, layout, comm, collectives="torch")
     b = torch.from_numpy(U.rhs()).to(engine.dev)        # generated on the whole local domain
     xa = engine.new(layout.local_dofs(0))
     xb = engine.new(layout.local_dofs(0))

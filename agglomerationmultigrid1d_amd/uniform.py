@@ -20,6 +20,7 @@ followed by agglomerated levels (pAgg in {0,1}) with uniform ratios.  It is set-
 path itself never runs here.
 """
 import math
+import os
 
 import numpy as np
 import scipy.sparse as sp
@@ -84,6 +85,39 @@ class RefElement:
 
 
 # ------------------------------------------------------------------------------------------
+# element-range parallelism of the generators: NumPy releases the GIL inside its loops, so disjoint
+# element ranges are built by a few threads and concatenated (bit for bit the serial result)
+# ------------------------------------------------------------------------------------------
+_PAR_MIN_ELEMS = 1 << 18
+
+
+def _gen_workers():
+    env = os.environ.get("AGGMG_GEN_WORKERS")
+    if env:
+        return max(1, int(env))
+    try:
+        return max(1, min(16, len(os.sched_getaffinity(0))))
+    except AttributeError:
+        return max(1, min(16, os.cpu_count() or 1))
+
+
+def _pool_map(fn, items, workers):
+    if workers <= 1 or len(items) <= 1:
+        return [fn(x) for x in items]
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(workers) as ex:
+        return list(ex.map(fn, items))
+
+
+def _ranges(n, parts, align=1):
+    """<= parts contiguous ranges of [0, n) with boundaries at multiples of align"""
+    units = n // align
+    parts = max(1, min(parts, units))
+    cuts = [(units * i // parts) * align for i in range(parts)] + [n]
+    return [(cuts[i], cuts[i + 1]) for i in range(parts) if cuts[i + 1] > cuts[i]]
+
+
+# ------------------------------------------------------------------------------------------
 # block-banded helpers
 # ------------------------------------------------------------------------------------------
 def _shift_up(X):
@@ -105,27 +139,40 @@ def _lt_x_l(Lrow, X, Lcol):
     return np.matmul(np.matmul(Lrow.transpose(0, 2, 1), X), Lcol)
 
 
-def block_tridiag_to_csc(sub, diag, sup, keep_zeros=False):
+def block_tridiag_to_csc(sub, diag, sup, keep_zeros=False, workers=None):
     """CSC (0-based int64 colptr/rowval, values) of the block-tridiagonal matrix with blocks
     sub[k] = (k, k-1), diag[k] = (k, k), sup[k] = (k, k+1), keeping the numerically non-zero
     entries (the pattern `C - D*X` has in SparseArrays) in ascending row order
     per column."""
     ne, m, _ = diag.shape
-    # column strip of element k: rows of elements k-1 (sup[k-1]), k (diag[k]), k+1 (sub[k+1])
-    strip = np.zeros((ne, m, 3 * m))
-    strip[:, :, m:2 * m] = diag.transpose(0, 2, 1)
-    if ne > 1:
-        strip[1:, :, 0:m] = sup[:-1].transpose(0, 2, 1)
-        strip[:-1, :, 2 * m:] = sub[1:].transpose(0, 2, 1)
-    mask = np.ones(strip.shape, dtype=bool) if keep_zeros else (strip != 0.0)
-    mask[0, :, 0:m] = False
-    mask[-1, :, 2 * m:] = False
-    rows = (np.arange(ne, dtype=np.int64)[:, None, None] - 1) * m + np.arange(3 * m, dtype=np.int64)[None, None, :]
-    rows = np.broadcast_to(rows, strip.shape)
-    counts = mask.sum(axis=2).reshape(-1)
+    if workers is None:
+        workers = _gen_workers() if ne >= _PAR_MIN_ELEMS else 1
+
+    def part(rng):
+        e0, e1 = rng
+        k = e1 - e0
+        # column strip of element k: rows of elements k-1 (sup[k-1]), k (diag[k]), k+1 (sub[k+1])
+        strip = np.zeros((k, m, 3 * m))
+        strip[:, :, m:2 * m] = diag[e0:e1].transpose(0, 2, 1)
+        lo = max(e0, 1)
+        strip[lo - e0:, :, 0:m] = sup[lo - 1:e1 - 1].transpose(0, 2, 1)
+        hi = min(e1, ne - 1)
+        strip[:hi - e0, :, 2 * m:] = sub[e0 + 1:hi + 1].transpose(0, 2, 1)
+        mask = np.ones(strip.shape, dtype=bool) if keep_zeros else (strip != 0.0)
+        if e0 == 0:
+            mask[0, :, 0:m] = False
+        if e1 == ne:
+            mask[-1, :, 2 * m:] = False
+        rows = (np.arange(e0, e1, dtype=np.int64)[:, None, None] - 1) * m + np.arange(3 * m, dtype=np.int64)[None, None, :]
+        rows = np.broadcast_to(rows, strip.shape)
+        return mask.sum(axis=2).reshape(-1), rows[mask], strip[mask]
+
+    parts = _pool_map(part, _ranges(ne, workers), workers)
     colptr = np.zeros(ne * m + 1, dtype=np.int64)
-    np.cumsum(counts, out=colptr[1:])
-    return colptr, rows[mask], strip[mask], ne * m
+    np.cumsum(np.concatenate([q[0] for q in parts]) if len(parts) > 1 else parts[0][0], out=colptr[1:])
+    if len(parts) == 1:
+        return colptr, parts[0][1], parts[0][2], ne * m
+    return colptr, np.concatenate([q[1] for q in parts]), np.concatenate([q[2] for q in parts]), ne * m
 
 
 def _csc(colptr, rowval, nzval, shape):
@@ -161,11 +208,17 @@ class UniformDgAggHierarchy:
     CDir = 1000 n."""
 
     def __init__(self, n, p=3, pAgg=1, ratios=(4, 2, 2), CDir=None, xin=0.0, xout=1.0, bc=None,
-                 func=np.cos, elem_range=None):
+                 func=np.cos, elem_range=None, workers=None, _left_pad=False):
         """elem_range=(a, b): build only the rows/columns of fine elements a..b-1 (0-based, multiples
         of prod(ratios)) and of their agglomerates -- the local operators of one rank of an
         element-partitioned run.  Couplings to elements outside the range are dropped; everything
-        else equals the corresponding entries of the global operators."""
+        else equals the corresponding entries of the global operators.
+
+        workers: large meshes are built range by range in that many threads and concatenated
+        (default: the CPUs of the process, at most 16; bit for bit the serial result).
+        _left_pad (internal, the ranges of such a build): one coarsest-level element of padding on
+        the left as well, so that the block arrays also hold the couplings of the first agglomerates
+        to their left neighbours."""
         if pAgg not in (0, 1):
             raise ValueError("Only implemented for p = 0 and p = 1.")  # agglomerated_dg_mesh.jl:312
         if p < 1 and len(ratios):
@@ -183,16 +236,25 @@ class UniformDgAggHierarchy:
         # one coarsest-level element of padding on the right: the last local rows need their right
         # neighbour's mass matrix / gradient blocks (A = C - D*(M\G) couples k to k+1)
         pad = 0 if self.at_right else tot
+        self.padL = tot if (_left_pad and not self.at_left) else 0
         self.nloc = b - a
-        self.n = self.nloc + pad          # elements the arrays are built on (padding trimmed later)
+        self.n = self.nloc + pad + self.padL   # elements the arrays are built on (padding trimmed later)
         self.p, self.pAgg, self.ratios = p, pAgg, tuple(ratios)
         self.CDir = 1000.0 * n if CDir is None else float(CDir)
         self.bc = bc or (('neu', -math.sin(xin)), ('dir', math.cos(xout)))
         self.func = func
         self.ref = RefElement(p)
-        i = np.arange(a, a + self.n + 1, dtype=np.float64)
+        if elem_range is None:
+            workers = _gen_workers() if workers is None else int(workers)
+            rngs = _ranges(n, 4 * workers if n >= (1 << 22) else workers, tot)
+            if len(rngs) > 1 and (workers > 1) and (n >= _PAR_MIN_ELEMS or os.environ.get("AGGMG_GEN_FORCE_PARALLEL")):
+                self._build_by_ranges(rngs, workers, dict(p=p, pAgg=pAgg, ratios=ratios, CDir=self.CDir, xin=xin,
+                                                          xout=xout, bc=self.bc, func=func))
+                return
+        a0 = a - self.padL
+        i = np.arange(a0, a0 + self.n + 1, dtype=np.float64)
         self.xv = xin + (i / n) * (xout - xin)              # tests/mesh_generator.jl:11-13
-        if a == 0:
+        if a0 == 0:
             self.xv[0] = xin
         self.h = self.xv[1:] - self.xv[:-1]
         self.xc = (self.xv[:-1] + self.xv[1:]) / 2.0
@@ -207,23 +269,61 @@ class UniformDgAggHierarchy:
         self._trim()
 
     def _trim(self):
-        """drop the right padding from every level"""
+        """drop the padding from every level"""
         per = 1
         ne = self.nloc
+        off = self.padL
         for k, lv in enumerate(self.levels):
             if k > 0:
                 per = self.ratios[k - 1]
                 ne //= per
+                off //= per
+            sl = slice(off, off + ne)
             lv['ne'] = ne
-            lv['A'] = tuple(x[:ne] for x in lv['A'])
-            lv['M'] = lv['M'][:ne]
-            lv['C'] = lv['C'][:ne]
-            lv['G'] = tuple(x[:ne] for x in lv['G'])
-            lv['D'] = tuple(x[:ne] for x in lv['D'])
+            lv['A'] = tuple(x[sl] for x in lv['A'])
+            lv['M'] = lv['M'][sl]
+            lv['C'] = lv['C'][sl]
+            lv['G'] = tuple(x[sl] for x in lv['G'])
+            lv['D'] = tuple(x[sl] for x in lv['D'])
             if k < len(self.transfers):
-                self.transfers[k]['Lb'] = self.transfers[k]['Lb'][:ne]
-        self._rhs_full = self._rhs_full[:self.nloc * (self.p + 1)]
+                self.transfers[k]['Lb'] = self.transfers[k]['Lb'][sl]
+        m = self.p + 1
+        self._rhs_full = self._rhs_full[self.padL * m:(self.padL + self.nloc) * m]
         self.n = self.nloc
+        self.padL = 0
+
+    def _build_by_ranges(self, rngs, workers, kw):
+        """the whole mesh range by range (threads); every worker writes its slice of the stiffness blocks,
+        the interpolation rows and the right-hand side (the intermediate G, D, C, M blocks stay range-local)"""
+        n = self.n_global
+        m = [self.p + 1] + [self.pAgg + 1] * len(self.ratios)
+        ne = [n]
+        for rho in self.ratios:
+            ne.append(ne[-1] // rho)
+        A = [tuple(np.empty((ne[k], m[k], m[k])) for _ in range(3)) for k in range(len(m))]
+        Lb = [np.empty((ne[k], m[k], m[k + 1])) for k in range(len(self.ratios))]
+        rhs = np.empty(n * m[0])
+
+        def work(r):
+            q = UniformDgAggHierarchy(n, elem_range=r, _left_pad=True, **kw)
+            per = 1
+            for k in range(len(m)):
+                if k > 0:
+                    per *= self.ratios[k - 1]
+                sl = slice(r[0] // per, r[1] // per)
+                for i in range(3):
+                    A[k][i][sl] = q.levels[k]['A'][i]
+                if k < len(Lb):
+                    Lb[k][sl] = q.transfers[k]['Lb']
+            rhs[r[0] * m[0]:r[1] * m[0]] = q._rhs_full
+            return None
+
+        _pool_map(work, rngs, workers)
+        self.levels = [dict(m=m[k], ne=ne[k], G=None, D=None, C=None, M=None, A=A[k]) for k in range(len(m))]
+        self.transfers = [dict(Lb=Lb[k], rho=rho, mc=self.pAgg + 1) for k, rho in enumerate(self.ratios)]
+        self._rhs_full = rhs
+        self.n = self.nloc
+        self.padL = 0
 
     # ---- fine DG level -----------------------------------------------------------------------
     def _build_fine(self):
@@ -467,21 +567,23 @@ class UniformDgAggHierarchy:
         return out
 
 
-def build_device_hierarchy(U, ctx=None, keep_host=False, smoother="blockJac"):
+def build_device_hierarchy(U, ctx=None, keep_host=False, smoother="blockJac", csc=None):
     """Upload a UniformDgAggHierarchy through the CSC boundary and return the product
     MeshHierarchy (block-Jacobi on every smoothed level, src/mesh_heirarchy.jl:58,73,85,104;
-    smoother="blockGS": the labelled red-black block Gauss-Seidel extension)."""
+    smoother="blockGS": the labelled red-black block Gauss-Seidel extension).
+    csc = (stiffness list, interpolation list): matrices already assembled by the caller (bench.py times
+    the generator and the library set-up apart)."""
     from .api import BlockGaussSeidel, BlockJacobi, DeviceOperator, MeshHierarchy
     from . import _lib
     BlockJacobi = {"blockJac": BlockJacobi, "blockGS": BlockGaussSeidel}[smoother]
     n = U.nlevels
     ops, sms = [], []
     for k in range(n):
-        op = DeviceOperator(U.stiffness_csc(k), _lib.OP_STIFFNESS, ctx)
+        op = DeviceOperator(csc[0][k] if csc else U.stiffness_csc(k), _lib.OP_STIFFNESS, ctx)
         ops.append(op)
         if k < n - 1:
             sms.append(BlockJacobi(op, U.descriptor(k).mBlockInds, ctx))
-    Ls = [DeviceOperator(U.interpolation_csc(k), _lib.OP_TRANSFER, ctx) for k in range(n - 1)]
+    Ls = [DeviceOperator(csc[1][k] if csc else U.interpolation_csc(k), _lib.OP_TRANSFER, ctx) for k in range(n - 1)]
     H = MeshHierarchy([U.descriptor(k) for k in range(n)], ops, sms, Ls, ctx=ctx, keep_host=keep_host)
     return H
 

@@ -144,3 +144,24 @@ def test_cg_other_bcs(oracle):
     A, b = o.cg_stiffness_and_rhs(cg, mesh, math.sin, bd)
     assert relmax(U.A[0], A) < 1e-13 and same_maps(U.A[0], A)
     assert np.allclose(U.rhs(), b, rtol=1e-13, atol=1e-14)
+
+
+@pytest.mark.parametrize("workers", [2, 3, 7])
+def test_range_parallel_generator_is_bitwise_the_serial_one(monkeypatch, workers):
+    """large meshes are built element range by element range in threads (every range with one coarsest-level
+    element of padding on both sides) and written into the global block arrays: same bits as one pass"""
+    monkeypatch.setenv("AGGMG_GEN_FORCE_PARALLEL", "1")
+    n = 16 * 37
+    for bc in (None, (('dir', 0.3), ('neu', -0.2))):
+        U1 = UniformDgAggHierarchy(n, p=3, pAgg=1, ratios=(4, 2, 2), bc=bc, workers=1)
+        U2 = UniformDgAggHierarchy(n, p=3, pAgg=1, ratios=(4, 2, 2), bc=bc, workers=workers)
+        assert U2.levels[0]['G'] is None and U1.levels[0]['G'] is not None      # the second one took the range path
+        for k in range(U1.nlevels):
+            A1, A2 = U1.stiffness_csc(k), U2.stiffness_csc(k)
+            assert np.array_equal(A1.indptr, A2.indptr) and np.array_equal(A1.indices, A2.indices)
+            assert np.array_equal(A1.data, A2.data)
+        for k in range(U1.nlevels - 1):
+            L1, L2 = U1.interpolation_csc(k), U2.interpolation_csc(k)
+            assert np.array_equal(L1.indices, L2.indices) and np.array_equal(L1.data, L2.data)
+        assert np.array_equal(U1.rhs(), U2.rhs())
+        assert U1.algorithmic_bytes() == U2.algorithmic_bytes()

@@ -30,6 +30,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=str, default="24:1,20:2,21:1,17:2,18:2,14:1")
     ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--cold", action="store_true",
+                    help="stream 2 GB through the caches before every solve and time the solve with HIP events: "
+                         "inside a V-cycle the factors come from HBM, not from the Infinity Cache")
     args = ap.parse_args()
     import agglomerationmultigrid1d_amd as mg
     from agglomerationmultigrid1d_amd import _lib
@@ -46,11 +49,29 @@ def main():
         for _ in range(3):
             H.vcycle_dev(z, b, x, 0, 0, 1.0)
         ctx.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            H.vcycle_dev(z, b, x, 0, 0, 1.0)
-        ctx.synchronize()
-        ms = 1e3 * (time.perf_counter() - t0) / args.steps
+        if args.cold:
+            import ctypes
+            nflush = 1 << 27
+            big = [ctx.alloc(nflush), ctx.alloc(nflush)]
+            P, I = ctypes.c_void_p * 1, ctypes.c_int64 * 1
+            srcs, dsts = P(big[0].ptr.value), P(big[1].ptr.value)
+            rows, cols, ld = I(1), I(nflush), I(nflush)
+            ctx.profile_enable(1)
+            for _ in range(args.steps):
+                ctx.check(ctx.lib.aggmg_copy_segments_dev(ctx.handle, 1, srcs, dsts, rows, cols, ld, ld))
+                H.vcycle_dev(z, b, x, 0, 0, 1.0)
+            ctx.synchronize()
+            ctx.profile_enable(False)
+            prof = ctx.profile_collect()
+            tot, cnt = prof[("coarse", 0)]
+            ms = tot / cnt
+            del big
+        else:
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                H.vcycle_dev(z, b, x, 0, 0, 1.0)
+            ctx.synchronize()
+            ms = 1e3 * (time.perf_counter() - t0) / args.steps
         r = A @ x.download() - b.download()
         print(json.dumps({"log2_blocks": lg, "m": m, "ms_per_solve": round(ms, 4), "rows_per_us": round(N / ms / 1e3, 1),
                           "rel_residual": float(np.linalg.norm(r) / np.linalg.norm(b.download()))}), flush=True)
