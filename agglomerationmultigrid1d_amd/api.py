@@ -173,13 +173,14 @@ def _ptr(v):
 class DeviceOperator:
     """Device mirror of one SparseMatrixCSC{Float64,Int64} (H.mStiffness[k] / H.mInterpolation[k],
     src/mesh_heirarchy.jl:20,26).  `A` is a SciPy sparse matrix or the Julia triple
-    (m, n, colptr, rowval, nzval) with 1-based Int64 indices."""
+    (m, n, colptr, rowval, nzval) with 1-based Int64 indices (a sixth entry 0 marks 0-based index arrays)."""
 
     def __init__(self, A, kind=_lib.OP_STIFFNESS, ctx=None):
         self.ctx = ctx or default_context()
         if isinstance(A, tuple):
-            m, n, colptr, rowval, nzval = A
-            one_based = 1
+            # (m, n, colptr, rowval, nzval[, one_based]): the arrays of a SparseMatrixCSC as they lie in memory
+            m, n, colptr, rowval, nzval = A[:5]
+            one_based = int(A[5]) if len(A) > 5 else 1
         else:
             if not sp.issparse(A):
                 raise ArgumentError("DeviceOperator: dense operators are not supported "

@@ -167,12 +167,25 @@ def block_tridiag_to_csc(sub, diag, sup, keep_zeros=False, workers=None):
         rows = np.broadcast_to(rows, strip.shape)
         return mask.sum(axis=2).reshape(-1), rows[mask], strip[mask]
 
-    parts = _pool_map(part, _ranges(ne, workers), workers)
+    rngs = _ranges(ne, 4 * workers if workers > 1 else 1)
+    parts = _pool_map(part, rngs, workers)
     colptr = np.zeros(ne * m + 1, dtype=np.int64)
-    np.cumsum(np.concatenate([q[0] for q in parts]) if len(parts) > 1 else parts[0][0], out=colptr[1:])
     if len(parts) == 1:
+        np.cumsum(parts[0][0], out=colptr[1:])
         return colptr, parts[0][1], parts[0][2], ne * m
-    return colptr, np.concatenate([q[1] for q in parts]), np.concatenate([q[2] for q in parts]), ne * m
+    for (e0, e1), q in zip(rngs, parts):
+        colptr[e0 * m + 1:e1 * m + 1] = q[0]
+    np.cumsum(colptr, out=colptr)
+    nnz = int(colptr[-1])
+    rowval, nzval = np.empty(nnz, dtype=np.int64), np.empty(nnz)
+
+    def put(i):      # every range's entries straight to their place (the concatenation, in threads)
+        o = int(colptr[rngs[i][0] * m])
+        rowval[o:o + parts[i][1].size] = parts[i][1]
+        nzval[o:o + parts[i][2].size] = parts[i][2]
+
+    _pool_map(put, list(range(len(parts))), workers)
+    return colptr, rowval, nzval, ne * m
 
 
 def _csc(colptr, rowval, nzval, shape):
@@ -237,6 +250,9 @@ class UniformDgAggHierarchy:
         # neighbour's mass matrix / gradient blocks (A = C - D*(M\G) couples k to k+1)
         pad = 0 if self.at_right else tot
         self.padL = tot if (_left_pad and not self.at_left) else 0
+        # whether the ARRAYS (owned range + padding) end at the domain boundary: the padding elements carry
+        # their true blocks then (the coupling blocks of the owned elements next to them depend on that)
+        self.end_left, self.end_right = (a - self.padL == 0), (b + pad == n)
         self.nloc = b - a
         self.n = self.nloc + pad + self.padL   # elements the arrays are built on (padding trimmed later)
         self.p, self.pAgg, self.ratios = p, pAgg, tuple(ratios)
@@ -347,7 +363,7 @@ class UniformDgAggHierarchy:
         Du[:-1, nR, nL] += -1.0       # right end, qhat from element k+1
         # first / last element of the array: domain boundary (src/dg_mesh.jl:170-218) or, for a
         # partial element range, one more interior vertex
-        if not self.at_left:
+        if not self.end_left:
             Gl[0, nL, nR] += 1.0
             Dd[0, nL, nL] += 1.0
         elif lk == 'dir':
@@ -355,7 +371,7 @@ class UniformDgAggHierarchy:
             Cd[0, nL, nL] += self.CDir
         else:
             Gd[0, nL, nL] += 1.0
-        if not self.at_right:
+        if not self.end_right:
             Gd[-1, nR, nR] += -1.0
             Du[-1, nR, nL] += -1.0
         elif rk == 'dir':
@@ -383,13 +399,13 @@ class UniformDgAggHierarchy:
             f += (self.J[:, None] * ref.gw[l]) * ref.phi[l][None, :] * fq[:, l][:, None]
         r = np.zeros((n, p + 1))
         (lk, lv), (rk, rv) = self.bc
-        if self.at_left:
+        if self.end_left:
             if lk == 'dir':
                 f[0, nL] += self.CDir * lv
                 r[0, nL] += -lv
             else:
                 f[0, nL] += -lv
-        if self.at_right:
+        if self.end_right:
             if rk == 'dir':
                 f[-1, nR] += self.CDir * rv
                 r[-1, nR] += rv
@@ -523,24 +539,45 @@ class UniformDgAggHierarchy:
     def nlevels(self):
         return len(self.levels)
 
-    def stiffness_csc(self, k):
-        """H.mStiffness[k] as scipy CSC (numerical pattern of `C - D*(M\\G)`)."""
+    def stiffness_arrays(self, k):
+        """H.mStiffness[k] as the arrays of a SparseMatrixCSC: (m, n, colptr, rowval, nzval, one_based=0),
+        int64 indices (numerical pattern of `C - D*(M\\G)`) -- what DeviceOperator takes as it is"""
         sub, diag, sup = self.levels[k]['A']
         colptr, rowval, nzval, N = block_tridiag_to_csc(sub, diag, sup)
+        return (N, N, colptr, rowval, nzval, 0)
+
+    def stiffness_csc(self, k):
+        """H.mStiffness[k] as scipy CSC"""
+        N, _, colptr, rowval, nzval, _ = self.stiffness_arrays(k)
         return _csc(colptr, rowval, nzval, (N, N))
 
-    def interpolation_csc(self, k):
-        """H.mInterpolation[k] (level k+1 -> k): every column holds all rows of its agglomerate,
-        zeros included."""
+    def interpolation_arrays(self, k):
+        """H.mInterpolation[k] (level k+1 -> k) as (m, n, colptr, rowval, nzval, one_based=0): every column
+        holds all rows of its agglomerate, zeros included."""
         t = self.transfers[k]
         Lb, rho, mc = t['Lb'], t['rho'], t['mc']
         nef, mf, _ = Lb.shape
         nec = nef // rho
         R = rho * mf
-        vals = Lb.reshape(nec, R, mc).transpose(0, 2, 1).reshape(-1)
         colptr = np.arange(nec * mc + 1, dtype=np.int64) * R
-        rowval = (np.repeat(np.arange(nec, dtype=np.int64), mc)[:, None] * R + np.arange(R, dtype=np.int64)[None, :]).reshape(-1)
-        return _csc(colptr, rowval, vals, (nef * mf, nec * mc))
+        vals = np.empty(nec * mc * R)
+        rowval = np.empty(nec * mc * R, dtype=np.int64)
+        workers = _gen_workers() if nef >= _PAR_MIN_ELEMS else 1
+        r = np.arange(R, dtype=np.int64)
+
+        def part(rng):
+            c0, c1 = rng
+            vals[c0 * mc * R:c1 * mc * R] = Lb[c0 * rho:c1 * rho].reshape(c1 - c0, R, mc).transpose(0, 2, 1).reshape(-1)
+            rowval[c0 * mc * R:c1 * mc * R] = (np.repeat(np.arange(c0, c1, dtype=np.int64), mc)[:, None] * R
+                                                + r[None, :]).reshape(-1)
+
+        _pool_map(part, _ranges(nec, 4 * workers if workers > 1 else 1), workers)
+        return (nef * mf, nec * mc, colptr, rowval, vals, 0)
+
+    def interpolation_csc(self, k):
+        """H.mInterpolation[k] as scipy CSC"""
+        m, n, colptr, rowval, vals, _ = self.interpolation_arrays(k)
+        return _csc(colptr, rowval, vals, (m, n))
 
     def descriptor(self, k):
         lv = self.levels[k]

@@ -349,7 +349,8 @@ def main():
         n = 2 ** E
         t0 = time.perf_counter()
         U = UniformDgAggHierarchy(n, p=args.p, pAgg=1, ratios=(4, 2, 2))
-        csc = ([U.stiffness_csc(k) for k in range(U.nlevels)], [U.interpolation_csc(k) for k in range(U.nlevels - 1)])
+        # the colptr / rowval / nzval arrays of the SparseMatrixCSC inputs, as a Julia caller would hand them over
+        csc = ([U.stiffness_arrays(k) for k in range(U.nlevels)], [U.interpolation_arrays(k) for k in range(U.nlevels - 1)])
         t_gen = time.perf_counter() - t0          # the synthetic SparseMatrixCSC inputs (stands in for the reference's assembly)
         t0 = time.perf_counter()
         H = build_device_hierarchy(U, ctx, csc=csc)

@@ -151,8 +151,8 @@ def test_range_parallel_generator_is_bitwise_the_serial_one(monkeypatch, workers
     """large meshes are built element range by element range in threads (every range with one coarsest-level
     element of padding on both sides) and written into the global block arrays: same bits as one pass"""
     monkeypatch.setenv("AGGMG_GEN_FORCE_PARALLEL", "1")
-    n = 16 * 37
-    for bc in (None, (('dir', 0.3), ('neu', -0.2))):
+    # (one coarsest element per range too: its padding then holds the domain's end elements)
+    for n, bc in ((16 * 37, None), (16 * 37, (('dir', 0.3), ('neu', -0.2))), (32, None), (16 * workers, None)):
         U1 = UniformDgAggHierarchy(n, p=3, pAgg=1, ratios=(4, 2, 2), bc=bc, workers=1)
         U2 = UniformDgAggHierarchy(n, p=3, pAgg=1, ratios=(4, 2, 2), bc=bc, workers=workers)
         assert U2.levels[0]['G'] is None and U1.levels[0]['G'] is not None      # the second one took the range path
