@@ -13,4 +13,8 @@ from .api import (AbstractSmoother, AdditiveSchwarzSmoother, BlockDiagonal, Bloc
                   dot, iterative_smoother_solve, ldiv, multigrid, multigrid_dev, multigrid_v_cycle, norm2, pcg,
                   prolong_add, residual, restrict, smooth)
 
+from . import interpolation
+from .interpolation import (aggdg_aggdg_interpolation, aggdg_cg_interpolation, aggdg_dg_interpolation,
+                            aggdg_dg_interpolation2, cg_cg_interpolation, dg_cg_interpolation, dg_dg_interpolation)
+
 __all__ = [n for n in dir() if not n.startswith("_")]
