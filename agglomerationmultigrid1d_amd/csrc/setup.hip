@@ -552,10 +552,19 @@ int setup_cr(aggmg_ctx* ctx, const aggmg_op* Ac, int hint_m, CrDev* cr) {
     cr->owned.push_back(*out);
     return AGGMG_OK;
   };
+  // (AGGMG_CR_TAIL_ROWS / AGGMG_CR_MAX_Q shrink the tail and the chunks: the tests use them to run the
+  // several-stage plan of systems beyond 2^24 rows at sizes a CPU reference solves in seconds)
+  auto env_int = [](const char* name, int dflt, int lo, int hi) {
+    const char* e = std::getenv(name);
+    const int v = e && *e ? std::atoi(e) : dflt;
+    return std::min(std::max(v, lo), hi);
+  };
+  const int tail_rows = env_int("AGGMG_CR_TAIL_ROWS", kCrTailRows, 8, kCrTailRows);
+  const int max_q = env_int("AGGMG_CR_MAX_Q", kCrMaxStageLevels, 1, kCrMaxStageLevels);
   int l0 = 0;
-  while (l0 < nl && level_n(l0) * m > kCrTailRows) {
+  while (l0 < nl && level_n(l0) * m > tail_rows) {
     int need = 0;
-    while (l0 + need < nl && level_n(l0 + need) * m > kCrTailRows) ++need;
+    while (l0 + need < nl && level_n(l0 + need) * m > tail_rows) ++need;
     // large chunks (every thread at least one sub-chunk of the streaming first step) as long as a few
     // hundred workgroups remain
     int fill = 0;
@@ -568,7 +577,7 @@ int setup_cr(aggmg_ctx* ctx, const aggmg_op* Ac, int hint_m, CrDev* cr) {
     }
     CrStage S;
     S.l0 = l0;
-    S.q = std::min({kCrMaxStageLevels, std::max(need, fill), nl - l0});
+    S.q = std::min({max_q, std::max(need, fill), nl - l0});
     if (S.q < 1) break;
     S.n_in = level_n(l0);
     S.n_out = level_n(l0 + S.q);
@@ -581,7 +590,7 @@ int setup_cr(aggmg_ctx* ctx, const aggmg_op* Ac, int hint_m, CrDev* cr) {
     cr->st.push_back(S);
     l0 += S.q;
   }
-  if (nl - l0 > kCrMaxStageLevels || level_n(l0) * m > kCrTailRows) {
+  if (nl - l0 > kCrMaxStageLevels || level_n(l0) * m > tail_rows) {
     cr_release(cr);
     return AGGMG_OK;
   }

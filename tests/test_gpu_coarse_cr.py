@@ -124,3 +124,42 @@ def test_cr_phases_reproduce_the_one_call_solve(mg, nb, m):
                                                           out.ptr.value + 8 * lo * m))
         assert np.array_equal(out.download(), x), world
     H.free()
+
+
+@pytest.mark.parametrize("nb,m,tail_rows,max_q", [(1 << 15, 1, 64, 5), ((1 << 14) + 7, 2, 32, 4), (5000, 3, 16, 3),
+                                                  (1 << 16, 1, 8, 12)])
+def test_cr_several_stages(mg, monkeypatch, nb, m, tail_rows, max_q):
+    """systems beyond 2^24 rows chain several chunk stages (the boundary system of one stage is the input of the
+    next); the plan knobs shrink the tail and the chunks so that the same plan runs at a size SciPy solves in
+    seconds -- and the partitioned phases hand the boundary system to the remaining stages"""
+    monkeypatch.setenv("AGGMG_CR_TAIL_ROWS", str(tail_rows))
+    monkeypatch.setenv("AGGMG_CR_MAX_Q", str(max_q))
+    A = block_tridiag(nb, m, seed=nb + m)
+    N = A.shape[0]
+    ctx, H = one_level(mg, A)
+    rng = np.random.default_rng(2)
+    b = rng.standard_normal(N)
+    bd, xd, z = ctx.to_device(b), ctx.alloc(N), ctx.to_device(np.zeros(N))
+    H.vcycle_dev(z, bd, xd, 0, 0, 1.0)
+    x = xd.download()
+    assert np.linalg.norm(A @ x - b) <= 1e-12 * np.linalg.norm(b)
+    assert np.linalg.norm(x - spla.splu(A).solve(b)) <= 1e-11 * np.linalg.norm(x)
+    c = ctx
+    q, nq, mb, nblk = ctypes.c_int(0), ctypes.c_int64(0), ctypes.c_int(0), ctypes.c_int64(0)
+    c.check(c.lib.aggmg_coarse_plan(c.handle, H.handle, ctypes.byref(q), ctypes.byref(nq), ctypes.byref(mb),
+                                    ctypes.byref(nblk)))
+    assert 0 < q.value <= max_q and nq.value * m > tail_rows          # more than one stage
+    chunk = 1 << q.value
+    nchunks = (nb + chunk - 1) // chunk
+    cuts = [0, (nchunks // 3) * chunk, (2 * nchunks // 3) * chunk, nb]
+    partR, partL = ctx.to_device(np.zeros((nq.value + 1) * m)), ctx.to_device(np.zeros((nq.value + 1) * m))
+    xq, out = ctx.alloc((nq.value + 1) * m), ctx.to_device(np.zeros(N))
+    for r in range(3):
+        c.check(c.lib.aggmg_coarse_chunk_forward_dev(c.handle, H.handle, bd.ptr.value + 8 * cuts[r] * m, cuts[r], cuts[r + 1],
+                                                     partR.ptr, partL.ptr))
+    c.check(c.lib.aggmg_coarse_boundary_solve_dev(c.handle, H.handle, partR.ptr, partL.ptr, xq.ptr))
+    for r in range(3):
+        c.check(c.lib.aggmg_coarse_chunk_backward_dev(c.handle, H.handle, bd.ptr.value + 8 * cuts[r] * m, cuts[r], cuts[r + 1],
+                                                      xq.ptr, out.ptr.value + 8 * cuts[r] * m))
+    assert np.array_equal(out.download(), x)
+    H.free()
