@@ -3,10 +3,11 @@
 nothing else on the GPU, so that every kernel dispatch of the trace belongs to a cycle and the roles
 (fused descent / ascent per level, coarsest-solve kernels) can be read off the dispatch order.
 
-    python tools/profile_vcycle.py --kind dg|cg --log2-elems E [--steps K] [--warmup W]
+    python tools/profile_vcycle.py --kind dg|cg|cggeneric --log2-elems E [--steps K] [--warmup W]
 
 dg: BASELINE config 3/4 hierarchy (DG p=3 -> AggDG 4:1 -> 2:1 -> 2:1); cg: config 5 shape (CG p=4 -> 2 -> 1
--> DG p=0).  Summaries: tools/summarize_profiles.py."""
+-> DG p=0); cggeneric: the same operators handed over WITHOUT element lists, i.e. through the generic CSR kernels
+(csr_stream_kernel / csr_row_kernel), the fallback of operators without structure.  Summaries: tools/summarize_profiles.py."""
 import argparse
 import json
 import os
@@ -19,7 +20,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--kind", choices=("dg", "cg"), default="dg")
+    ap.add_argument("--kind", choices=("dg", "cg", "cggeneric"), default="dg",
+                    help="cggeneric: the config-5 operators without their element lists -- generic CSR kernels")
     ap.add_argument("--log2-elems", type=int, default=24)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
@@ -33,7 +35,7 @@ def main():
         H = uniform.build_device_hierarchy(U, ctx)
     else:
         U = uniform.UniformCgDgHierarchy(n, ps=(4, 2, 1))
-        H = uniform.build_device_cg_hierarchy(U, ctx)
+        H = uniform.build_device_cg_hierarchy(U, ctx, chain=(args.kind == "cg"))
     b = ctx.to_device(U.rhs())
     N = len(U.rhs())
     xa, xb = ctx.to_device(np.zeros(N)), ctx.alloc(N)
