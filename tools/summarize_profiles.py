@@ -34,10 +34,11 @@ def is_ours(name):
     return "aggmg::" in name and "dot_" not in name
 
 
-def period(seq):
-    """smallest S with the last three windows of length S equal"""
-    for S in range(1, len(seq) // 3 + 1):
-        if seq[-S:] == seq[-2 * S:-S] == seq[-3 * S:-2 * S]:
+def period(seq, windows=5):
+    """smallest S with the last `windows` windows of length S equal (the profiled command runs at least that many
+    cycles; fewer windows would take the repeated sweeps of one smoothing step for a cycle)"""
+    for S in range(1, len(seq) // windows + 1):
+        if all(seq[len(seq) - (w + 1) * S:len(seq) - w * S] == seq[-S:] for w in range(1, windows)):
             return S
     raise SystemExit("no periodic dispatch pattern found")
 
