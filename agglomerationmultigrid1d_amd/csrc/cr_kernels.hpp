@@ -21,18 +21,9 @@
 // launch -- by the workgroup of the last stage that finishes last.  2^24 scalar rows: one stage
 // (q = 12) + tail = 2 launches forward/tail, 1 backward.
 //
-// Factor layout.  The forward pass touches the off-diagonal blocks of the even rows only, the
-// backward pass those of the odd rows: stored apart (parity-split, a and c of one row adjacent).
-// A level belongs to exactly one step, and in that step sub-chunk b reads the rows
-// (b << k) + jj, jj = 0 .. NB1 -- contiguous per lane, 64-128 bytes apart between lanes, i.e. one
-// cache line per lane and load instruction, which makes the texture-address path of the CU the
-// limiter.  The factors are therefore stored "sub-chunk interleaved": for tile = b / 64, lane = b % 64
-//   fe   [tile][jj <= NB1][piece < M^2][lane]  16-byte pieces of (a, c) of even row (b << k) + jj
-//   fo   [tile][jj <  NB1][piece < M^2][lane]  the same for the odd rows
-//   lu   [tile][jj <  NB1][k < M^2][lane],   perm [tile][jj < NB1][k < M][lane]
-// so that every load instruction of a wave reads 64 consecutive pieces (the row shared by two
-// neighbouring sub-chunks is stored with both).  Slots past the end of the level hold zero blocks
-// and identity pivots: no index is ever clamped.
+// The forward pass touches the off-diagonal blocks of the even rows only, the backward pass those
+// of the odd rows: stored apart (parity-split, a and c of one row adjacent) so that every fetched
+// line is used in full.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -45,13 +36,11 @@ constexpr int kCrMaxLevels = 40;
 constexpr int kCrMaxStageLevels = 12;
 constexpr int kCrMaxSteps = 8;
 
-constexpr int kCrLanes = 64;  // sub-chunks per interleave tile
-
 struct CrLevel {
-  const double* fe;    // (a_{2j}, c_{2j}) of the even rows, sub-chunk interleaved (see above)
-  const double* fo;    // (a_{2j+1}, c_{2j+1}) of the odd rows
-  const double* lu;    // unit-lower L and U of the row-permuted b_{2j+1}
-  const int32_t* perm; // row permutation: (P b) = L U, solve uses rhs[perm[k]]
+  const double* fe;    // [n_even][2][M][M]  (a_{2j}, c_{2j})
+  const double* fo;    // [n_odd][2][M][M]   (a_{2j+1}, c_{2j+1})
+  const double* lu;    // [n_odd][M][M]  unit-lower L and U of the row-permuted b_{2j+1}
+  const int32_t* perm; // [n_odd][M]     row permutation: (P b) = L U, solve uses rhs[perm[k]]
   int64_t n, n_even, n_odd;
 };
 
@@ -94,12 +83,13 @@ struct CrOff<QS, 0> {
   static constexpr int blocks = 0;
 };
 
-// (a, c) of one row: M^2 pieces of 16 bytes, `stride` pieces apart
+// (a, c) of one row: 2 M^2 doubles, 16-byte aligned
 template <int M>
-__device__ __forceinline__ void cr_load_pair(const double2* __restrict__ p2, int stride, double (&ac)[2 * M * M]) {
+__device__ __forceinline__ void cr_load_pair(const double* __restrict__ p, double (&ac)[2 * M * M]) {
+  const double2* p2 = reinterpret_cast<const double2*>(p);
 #pragma unroll
   for (int k = 0; k < M * M; ++k) {
-    const double2 t = p2[k * stride];
+    const double2 t = p2[k];
     ac[2 * k] = t.x;
     ac[2 * k + 1] = t.y;
   }
@@ -109,13 +99,13 @@ __device__ __forceinline__ void cr_load_pair(const double2* __restrict__ p2, int
 // chains, then unit-lower and upper substitution (the getrs order)
 template <int M>
 __device__ __forceinline__ void cr_lu_solve_reg(const double* __restrict__ lu, const int32_t* __restrict__ perm,
-                                                int stride, const double* r, double (&y)[M]) {
+                                                const double* r, double (&y)[M]) {
   if constexpr (M == 1) {
     y[0] = r[0] / lu[0];
   } else {
     double f[M * M];
 #pragma unroll
-    for (int k = 0; k < M * M; ++k) f[k] = lu[k * stride];
+    for (int k = 0; k < M * M; ++k) f[k] = lu[k];
     // (opaque copies: left as loads, the selects are folded into a variable-offset access and the
     // whole sub-chunk array drops out of registers into scratch)
     double rv[M];
@@ -126,7 +116,7 @@ __device__ __forceinline__ void cr_lu_solve_reg(const double* __restrict__ lu, c
     }
 #pragma unroll
     for (int k = 0; k < M; ++k) {
-      const int32_t pk = perm[k * stride];
+      const int32_t pk = perm[k];
       double v = rv[0];
 #pragma unroll
       for (int q = 1; q < M; ++q) v = (pk == q) ? rv[q] : v;
@@ -151,9 +141,8 @@ __device__ __forceinline__ void cr_lu_solve_reg(const double* __restrict__ lu, c
 
 // The sub-chunk code below is branch-free on purpose: a load under a run-time condition cannot be
 // hoisted, and every sub-level would wait a full memory round trip of its own -- the very latency
-// chain this schedule is there to remove.  Rows past the end of the level read the padding slots of
-// the interleaved factor arrays (zero blocks, identity pivots) and their values are discarded with a
-// select.
+// chain this schedule is there to remove.  Rows past the end of the level are handled by clamping
+// their index to a row that exists (loads stay in bounds) and discarding the value with a select.
 
 // sub-levels I .. QS-1 of sub-chunk b forward: v[sub-level I] -> v[sub-level I + 1]
 template <int M, int QS, int I>
@@ -161,30 +150,30 @@ __device__ __forceinline__ void cr_loc_fwd(const CrLevel* lv, int64_t b, double*
   if constexpr (I < QS) {
     const CrLevel& L = lv[I];
     constexpr int NB1 = 1 << (QS - I - 1);  // next sub-level: blocks 0 .. NB1
+    const int64_t tlo1 = b << (QS - I - 1);
     int64_t thi = (b + 1) << (QS - I);
     if (thi > L.n - 1) thi = L.n - 1;
-    const int64_t tlo = b << (QS - I);
+    const int64_t tlo = tlo1 << 1;
     double* d = v + CrOff<QS, I>::blocks * M;
     double* dn = v + CrOff<QS, I + 1>::blocks * M;
-    const int64_t tile = b >> 6;
-    const int lane = (int)(b & (kCrLanes - 1));
-    const double2* feb = reinterpret_cast<const double2*>(L.fe) + tile * ((NB1 + 1) * M * M * kCrLanes) + lane;
-    const double* lub = L.lu + tile * (NB1 * M * M * kCrLanes) + lane;
-    const int32_t* pmb = L.perm + tile * (NB1 * M * kCrLanes) + lane;
     // b \ d of the odd rows, each used by both even neighbours; zero for rows that do not exist
     double y[NB1][M];
 #pragma unroll
     for (int jj = 0; jj < NB1; ++jj) {
       const bool ok = tlo + 2 * jj + 1 <= thi;
+      int64_t idx = tlo1 + jj;
+      if (idx > L.n_odd - 1) idx = L.n_odd - 1;
       double t[M];
-      cr_lu_solve_reg<M>(lub + jj * (M * M * kCrLanes), pmb + jj * (M * kCrLanes), kCrLanes, d + (2 * jj + 1) * M, t);
+      cr_lu_solve_reg<M>(L.lu + idx * (M * M), L.perm + idx * M, d + (2 * jj + 1) * M, t);
 #pragma unroll
       for (int e = 0; e < M; ++e) y[jj][e] = ok ? t[e] : 0.0;
     }
 #pragma unroll
-    for (int jj = 0; jj <= NB1; ++jj) {  // (a row that does not exist: zero blocks, its result is never read)
+    for (int jj = 0; jj <= NB1; ++jj) {
+      int64_t j = tlo1 + jj;
+      if (j > L.n_even - 1) j = L.n_even - 1;  // a row that does not exist: its result is never read
       double ac[2 * M * M], acc[M];
-      cr_load_pair<M>(feb + jj * (M * M * kCrLanes), kCrLanes, ac);
+      cr_load_pair<M>(L.fe + j * (2 * M * M), ac);
 #pragma unroll
       for (int e = 0; e < M; ++e) acc[e] = d[(2 * jj) * M + e];
       if (jj > 0) {
@@ -213,19 +202,17 @@ __device__ __forceinline__ void cr_loc_bwd(const CrLevel* lv, int64_t b, double*
   if constexpr (I >= 0) {
     const CrLevel& L = lv[I];
     constexpr int NB1 = 1 << (QS - I - 1);
-    const int64_t tlo = b << (QS - I);
+    const int64_t tlo1 = b << (QS - I - 1);
+    const int64_t tlo = tlo1 << 1;
     double* d = v + CrOff<QS, I>::blocks * M;
     const double* xn = v + CrOff<QS, I + 1>::blocks * M;
-    const int64_t tile = b >> 6;
-    const int lane = (int)(b & (kCrLanes - 1));
-    const double2* fob = reinterpret_cast<const double2*>(L.fo) + tile * (NB1 * M * M * kCrLanes) + lane;
-    const double* lub = L.lu + tile * (NB1 * M * M * kCrLanes) + lane;
-    const int32_t* pmb = L.perm + tile * (NB1 * M * kCrLanes) + lane;
 #pragma unroll
     for (int jj = 0; jj < NB1; ++jj) {  // odd rows 2 jj + 1 (rows past the end: values never written out)
       const int64_t r = tlo + 2 * jj + 1;
+      int64_t idx = tlo1 + jj;
+      if (idx > L.n_odd - 1) idx = L.n_odd - 1;
       double ac[2 * M * M], rhs[M], x[M];
-      cr_load_pair<M>(fob + jj * (M * M * kCrLanes), kCrLanes, ac);
+      cr_load_pair<M>(L.fo + idx * (2 * M * M), ac);
       const bool has_next = r + 1 < L.n;
       double xr[M];
 #pragma unroll
@@ -239,7 +226,7 @@ __device__ __forceinline__ void cr_loc_bwd(const CrLevel* lv, int64_t b, double*
         for (int k = 0; k < M; ++k) s -= ac[M * M + i * M + k] * xr[k];
         rhs[i] = s;
       }
-      cr_lu_solve_reg<M>(lub + jj * (M * M * kCrLanes), pmb + jj * (M * kCrLanes), kCrLanes, rhs, x);
+      cr_lu_solve_reg<M>(L.lu + idx * (M * M), L.perm + idx * M, rhs, x);
 #pragma unroll
       for (int e = 0; e < M; ++e) d[(2 * jj + 1) * M + e] = x[e];
     }
@@ -478,7 +465,7 @@ __device__ __forceinline__ void cr_tail_body(const CrStageArgs& T, const double*
       double r[M], y[M];
 #pragma unroll
       for (int e = 0; e < M; ++e) r[e] = d0b ? d0[e] + d0b[e] : d0[e];
-      cr_lu_solve_reg<M>(T.lu_last, T.perm_last, 1, r, y);
+      cr_lu_solve_reg<M>(T.lu_last, T.perm_last, r, y);
 #pragma unroll
       for (int e = 0; e < M; ++e) x0[e] = y[e];
     }
@@ -490,7 +477,7 @@ __device__ __forceinline__ void cr_tail_body(const CrStageArgs& T, const double*
     double r[M], y[M];
 #pragma unroll
     for (int e = 0; e < M; ++e) r[e] = R[e] + R[2 * M + e];
-    cr_lu_solve_reg<M>(T.lu_last, T.perm_last, 1, r, y);
+    cr_lu_solve_reg<M>(T.lu_last, T.perm_last, r, y);
     double* X = sh + T.lds_xoff[T.nsteps];
 #pragma unroll
     for (int e = 0; e < M; ++e) X[e] = y[e];

@@ -599,111 +599,51 @@ int setup_cr(aggmg_ctx* ctx, const aggmg_op* Ac, int hint_m, CrDev* cr) {
   cr->tail.n_in = level_n(l0);
   cr->tail.n_out = 1;
   cr_plan_steps(&cr->tail, m);
-  // Factor arrays into their final, sub-chunk interleaved layout (cr_kernels.hpp): level l is read by the
-  // sub-chunks of exactly one step -- QS levels per sub-chunk, l the I-th of them -- which fixes the order.
-  // The small levels (the tail and the last steps of the stage before it) are worked through by a few
-  // threads, one dependent step after the other: their factors go into ONE allocation, so that a step
-  // touches a couple of pages instead of four arrays per level each on a page of its own.
+  // The small levels (the tail and the last steps of the stage before it) are worked through by a
+  // few threads, one dependent step after the other: their factors go into ONE allocation, so that a
+  // step touches a couple of pages instead of four arrays per level each on a page of its own -- an
+  // address-translation miss per array is what such a step would otherwise wait for.
   {
-    struct LevelUse {
-      int shift = 0, nb1 = 1;     // row of sub-chunk b, slot jj = (b << shift) + jj; NB1 = 2^shift
-      int64_t nchunks = 1;
-    };
-    std::vector<LevelUse> use(nl);
-    auto mark = [&](const CrStage& S) {
-      for (int s = 0; s < S.nsteps; ++s) {
-        const int qs = S.step_a[s + 1] - S.step_a[s];
-        for (int I = 0; I < qs; ++I) {
-          LevelUse& u = use[S.l0 + S.step_a[s] + I];
-          u.shift = qs - I - 1;
-          u.nb1 = 1 << u.shift;
-          u.nchunks = level_n(S.l0 + S.step_a[s + 1]);
-        }
-      }
-    };
-    for (const CrStage& S : cr->st) mark(S);
-    mark(cr->tail);
     int pf = cr->tail.l0;
-    while (pf > 0 && level_n(pf - 1) * m <= 8 * tail_rows) --pf;
+    while (pf > 0 && level_n(pf - 1) * m <= 8 * kCrTailRows) --pf;
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
     const size_t mm = (size_t)m * m;
-    struct Sizes {
-      size_t fe, fo, lu, perm;    // bytes
-      int64_t tiles;
-    };
-    std::vector<Sizes> sz(nl);
     size_t total = al(mm * sizeof(double)) + al(m * sizeof(int32_t));
-    for (int l = 0; l < nl; ++l) {
-      const LevelUse& u = use[l];
-      Sizes& z = sz[l];
-      z.tiles = (u.nchunks + kCrLanes - 1) / kCrLanes;
-      z.fe = (size_t)z.tiles * (u.nb1 + 1) * mm * kCrLanes * 2 * sizeof(double);
-      z.fo = (size_t)z.tiles * u.nb1 * mm * kCrLanes * 2 * sizeof(double);
-      z.lu = (size_t)z.tiles * u.nb1 * mm * kCrLanes * sizeof(double);
-      z.perm = (size_t)z.tiles * u.nb1 * m * kCrLanes * sizeof(int32_t);
-      if (l >= pf) total += al(z.fe) + al(z.fo) + al(z.lu) + al(z.perm);
+    for (int l = pf; l < nl; ++l) {
+      const CrLevel& L = cr->lv[l];
+      const size_t no = (size_t)std::max<int64_t>(L.n_odd, 1);
+      total += al(L.n_even * 2 * mm * sizeof(double)) + al(no * 2 * mm * sizeof(double)) + al(no * mm * sizeof(double)) +
+               al(no * m * sizeof(int32_t));
     }
     char* arena = nullptr;
     HIPCHK(hipMalloc((void**)&arena, total));
-    cr->owned.push_back(arena);
     size_t off = 0;
     std::vector<void*> old;
-    auto place = [&](int l, size_t bytes, void** out) -> int {
-      if (l >= pf) {
-        *out = arena + off;
-        off += al(bytes);
-        return AGGMG_OK;
-      }
-      HIPCHK(hipMalloc(out, std::max<size_t>(bytes, 16)));
-      cr->owned.push_back(*out);
-      return AGGMG_OK;
-    };
-    for (int l = 0; l < nl; ++l) {
-      CrLevel& L = cr->lv[l];
-      const LevelUse& u = use[l];
-      const Sizes& z = sz[l];
-      void *fe = nullptr, *fo = nullptr, *lu = nullptr, *pm = nullptr;
-      CHECK(place(l, z.fe, &fe));
-      CHECK(place(l, z.fo, &fo));
-      CHECK(place(l, z.lu, &lu));
-      CHECK(place(l, z.perm, &pm));
-      const int64_t tfe = z.tiles * (u.nb1 + 1) * (int64_t)mm * kCrLanes, tfo = z.tiles * u.nb1 * (int64_t)mm * kCrLanes;
-      LAUNCH(cr_il_pairs_kernel, tfe, tfe, u.nb1 + 1, u.shift, (int)mm, L.n_even, (const double2*)L.fe, (double2*)fe);
-      LAUNCH(cr_il_pairs_kernel, tfo, tfo, u.nb1, u.shift, (int)mm, L.n_odd, (const double2*)L.fo, (double2*)fo);
-      LAUNCH(cr_il_lu_kernel, tfo, tfo, u.nb1, u.shift, m, L.n_odd, L.lu, (double*)lu);
-      const int64_t tpm = z.tiles * u.nb1 * (int64_t)m * kCrLanes;
-      LAUNCH(cr_il_perm_kernel, tpm, tpm, u.nb1, u.shift, m, L.n_odd, L.perm, (int32_t*)pm);
-      for (const void* q : {(const void*)L.fe, (const void*)L.fo, (const void*)L.lu, (const void*)L.perm})
-        old.push_back(const_cast<void*>(q));
-      L.fe = (const double*)fe;
-      L.fo = (const double*)fo;
-      L.lu = (const double*)lu;
-      L.perm = (const int32_t*)pm;
-      if (l % 4 == 3 || l == nl - 1) {   // release the plain-layout arrays as we go (peak memory)
-        HIPCHK(hipStreamSynchronize(ctx->stream));
-        for (void* q : old) {
-          auto it = std::find(cr->owned.begin(), cr->owned.end(), q);
-          if (it != cr->owned.end()) cr->owned.erase(it);
-          (void)hipFree(q);
-        }
-        old.clear();
-      }
-    }
-    {   // the last block's factors (contiguous) behind the small levels
+    auto move = [&](const void* src, size_t bytes) -> void* {
       void* dst = arena + off;
-      HIPCHK(hipMemcpyAsync(dst, cr->lu_last, mm * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
-      off += al(mm * sizeof(double));
-      void* dst2 = arena + off;
-      HIPCHK(hipMemcpyAsync(dst2, cr->perm_last, m * sizeof(int32_t), hipMemcpyDeviceToDevice, ctx->stream));
-      HIPCHK(hipStreamSynchronize(ctx->stream));
-      for (const void* q : {(const void*)cr->lu_last, (const void*)cr->perm_last}) {
-        auto it = std::find(cr->owned.begin(), cr->owned.end(), const_cast<void*>(q));
-        if (it != cr->owned.end()) cr->owned.erase(it);
-        (void)hipFree(const_cast<void*>(q));
-      }
-      cr->lu_last = (const double*)dst;
-      cr->perm_last = (const int32_t*)dst2;
+      (void)hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream);
+      off += al(bytes);
+      old.push_back(const_cast<void*>(src));
+      return dst;
+    };
+    for (int l = pf; l < nl; ++l) {
+      CrLevel& L = cr->lv[l];
+      const size_t no = (size_t)std::max<int64_t>(L.n_odd, 1);
+      L.fe = (const double*)move(L.fe, L.n_even * 2 * mm * sizeof(double));
+      L.fo = (const double*)move(L.fo, no * 2 * mm * sizeof(double));
+      L.lu = (const double*)move(L.lu, no * mm * sizeof(double));
+      L.perm = (const int32_t*)move(L.perm, no * m * sizeof(int32_t));
     }
+    cr->lu_last = (const double*)move(cr->lu_last, mm * sizeof(double));
+    cr->perm_last = (const int32_t*)move(cr->perm_last, m * sizeof(int32_t));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    for (void* q : old) {
+      auto it = std::find(cr->owned.begin(), cr->owned.end(), q);
+      if (it != cr->owned.end()) cr->owned.erase(it);
+      (void)hipFree(q);
+    }
+    cr->owned.push_back(arena);
   }
   if (n * m != N) {
     CHECK(dz(n * m, &cr->d0));

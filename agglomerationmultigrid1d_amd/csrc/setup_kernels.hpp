@@ -539,55 +539,6 @@ __global__ __launch_bounds__(kSetupThreads) void cr_split_kernel(int64_t n, int 
   *dst = k < mm2 ? a[r * mm2 + k] : c[r * mm2 + k - mm2];
 }
 
-// Sub-chunk interleaved factor arrays (cr_kernels.hpp): slot (tile, jj, piece, lane) holds piece `piece` of
-// source row ((tile * 64 + lane) << shift) + jj; rows past `nvalid` get the padding value.
-//   pairs: pieces are 16-byte halves of the (a, c) records (mm2 pieces per row), padding zero
-__global__ __launch_bounds__(kSetupThreads) void cr_il_pairs_kernel(int64_t total, int nbr, int shift, int npiece,
-                                                                    int64_t nvalid, const double2* __restrict__ src,
-                                                                    double2* __restrict__ dst) {
-  const int64_t t = (int64_t)blockIdx.x * kSetupThreads + threadIdx.x;
-  if (t >= total) return;
-  const int lane = (int)(t & 63);
-  int64_t r = t >> 6;
-  const int piece = (int)(r % npiece);
-  r /= npiece;
-  const int jj = (int)(r % nbr);
-  const int64_t tile = r / nbr;
-  const int64_t row = ((tile * 64 + lane) << shift) + jj;
-  dst[t] = row < nvalid ? src[row * npiece + piece] : make_double2(0.0, 0.0);
-}
-
-//   lu: pieces are the m*m entries of the factored pivot block, padding the identity
-__global__ __launch_bounds__(kSetupThreads) void cr_il_lu_kernel(int64_t total, int nbr, int shift, int m, int64_t nvalid,
-                                                                 const double* __restrict__ src, double* __restrict__ dst) {
-  const int64_t t = (int64_t)blockIdx.x * kSetupThreads + threadIdx.x;
-  if (t >= total) return;
-  const int mm2 = m * m;
-  const int lane = (int)(t & 63);
-  int64_t r = t >> 6;
-  const int k = (int)(r % mm2);
-  r /= mm2;
-  const int jj = (int)(r % nbr);
-  const int64_t tile = r / nbr;
-  const int64_t row = ((tile * 64 + lane) << shift) + jj;
-  dst[t] = row < nvalid ? src[row * mm2 + k] : ((k / m == k % m) ? 1.0 : 0.0);
-}
-
-//   perm: m row indices per pivot block, padding the identity permutation
-__global__ __launch_bounds__(kSetupThreads) void cr_il_perm_kernel(int64_t total, int nbr, int shift, int m, int64_t nvalid,
-                                                                   const int32_t* __restrict__ src, int32_t* __restrict__ dst) {
-  const int64_t t = (int64_t)blockIdx.x * kSetupThreads + threadIdx.x;
-  if (t >= total) return;
-  const int lane = (int)(t & 63);
-  int64_t r = t >> 6;
-  const int k = (int)(r % m);
-  r /= m;
-  const int jj = (int)(r % nbr);
-  const int64_t tile = r / nbr;
-  const int64_t row = ((tile * 64 + lane) << shift) + jj;
-  dst[t] = row < nvalid ? src[row * m + k] : k;
-}
-
 __device__ __forceinline__ void atomic_max_pos(double* addr, double v) {
   // non-negative doubles order like their bit patterns
   atomicMax(reinterpret_cast<unsigned long long*>(addr), (unsigned long long)__double_as_longlong(v));
