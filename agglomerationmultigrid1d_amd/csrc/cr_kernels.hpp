@@ -31,6 +31,11 @@
 namespace aggmg {
 
 constexpr int kCrThreads = 256;
+// (tuning hook: __attribute__((amdgpu_waves_per_eu(1, 2))) lets the compiler spend the register file on loads in
+// flight -- measured: -5 % at block size 2 with 256 workgroups, +25 % on the 4096-workgroup scalar system; off)
+#ifndef CR_WAVES_ATTR
+#define CR_WAVES_ATTR
+#endif
 constexpr int kCrTailRows = 4096;  // scalar rows (blocks * m) the single-workgroup tail takes
 constexpr int kCrMaxLevels = 40;
 constexpr int kCrMaxStageLevels = 12;
@@ -487,7 +492,7 @@ __device__ __forceinline__ void cr_tail_body(const CrStageArgs& T, const double*
 }
 
 template <int M>
-__global__ __launch_bounds__(kCrThreads) void cr_tail_kernel(CrStageArgs T, const double* __restrict__ d0,
+__global__ __launch_bounds__(kCrThreads) CR_WAVES_ATTR void cr_tail_kernel(CrStageArgs T, const double* __restrict__ d0,
                                                              const double* __restrict__ d0b,
                                                              double* __restrict__ x0) {
   extern __shared__ double sh[];
@@ -499,7 +504,7 @@ __global__ __launch_bounds__(kCrThreads) void cr_tail_kernel(CrStageArgs T, cons
 // left end).  FUSE_TAIL: the workgroup that finishes last (ticket counter) goes on to solve the
 // boundary system with the tail levels -- forward elimination and boundary solve in one launch.
 template <int M, bool FUSE_TAIL>
-__global__ __launch_bounds__(kCrThreads) void cr_stage_forward_kernel(CrStageArgs A, const double* __restrict__ d0,
+__global__ __launch_bounds__(kCrThreads) CR_WAVES_ATTR void cr_stage_forward_kernel(CrStageArgs A, const double* __restrict__ d0,
                                                                       const double* __restrict__ d0b, double* partR,
                                                                       double* partL, CrStageArgs T, double* xq,
                                                                       unsigned int* ticket) {
@@ -542,7 +547,7 @@ __global__ __launch_bounds__(kCrThreads) void cr_stage_forward_kernel(CrStageArg
 }
 
 template <int M>
-__global__ __launch_bounds__(kCrThreads) void cr_stage_backward_kernel(CrStageArgs A, const double* __restrict__ d0,
+__global__ __launch_bounds__(kCrThreads) CR_WAVES_ATTR void cr_stage_backward_kernel(CrStageArgs A, const double* __restrict__ d0,
                                                                        const double* __restrict__ d0b,
                                                                        const double* __restrict__ xq,
                                                                        double* __restrict__ x0) {
