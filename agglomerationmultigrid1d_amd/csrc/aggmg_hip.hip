@@ -381,10 +381,30 @@ struct TileSel {
   int64_t head = 0, tail = 0;
 };
 
+// the structured transfer of a level as the fused kernel's prolongation input / restriction output
+static void xfer_in(FusedArgs& a, const TransferBtd& t) {
+  a.mc_in = t.mc;
+  a.rho_in = t.rho;
+  a.par_in = t.rho ? nullptr : t.parent;
+}
+static void xfer_out(FusedArgs& a, const TransferBtd& t) {
+  a.mc_out = t.mc;
+  a.rho_out = t.rho;
+  a.par_out = t.rho ? nullptr : t.parent;
+  a.first_out = t.rho ? nullptr : t.first;
+  a.nec_out = t.nec;
+}
+
 template <int M, bool CMP>
 static int launch_btd_t(aggmg_ctx* ctx, FusedArgs a, int halo, const TileSel& sel) {
   using T = BtdTile<M, CMP>;
-  const int align = (a.lf_out || a.ld_out) ? a.rho_out : 1;
+  const bool vr = (a.lf_out || a.ld_out) && a.par_out;
+  const int align = ((a.lf_out || a.ld_out) && !vr) ? a.rho_out : 1;
+  if (vr) {
+    if (sel.mode != 0) return fail(ctx, AGGMG_ERR_UNSUPPORTED, "tile selection on a level with agglomerates of different sizes");
+    // agglomerates cut by a tile boundary are summed from two tiles
+    HIPCHK(hipMemsetAsync(a.rc_out, 0, (size_t)a.nec_out * a.mc_out * sizeof(double), ctx->stream));
+  }
   if (a.gs) halo += a.nsweeps;  // two half-sweeps per sweep, one element of halo each
   int owned = ((T::TE - 2 * halo) / align) * align;
   if (owned <= 0) return fail(ctx, AGGMG_ERR_UNSUPPORTED, "fused tile too small for the requested halo");
@@ -1165,8 +1185,7 @@ static int vcycle_down(aggmg_ctx* ctx, aggmg_hier* h, const double* x0, const do
       else
         a.lf_out = l.tb->lf;
       a.rc_out = c.rhs;
-      a.mc_out = l.tb->mc;
-      a.rho_out = l.tb->rho;
+      xfer_out(a, *l.tb);
       ProfScope ps(ctx, AGGMG_KIND_FUSED_DOWN, k);
       CHECK(launch_btd(ctx, *l.S->btd, a, nPre + 1));
     } else {
@@ -1238,8 +1257,7 @@ static int vcycle_up(aggmg_ctx* ctx, aggmg_hier* h, const double* b, int nPost, 
       a.gs = l.S->gs ? 2 : 0;  // post-smoothing in the reverse colour order: the cycle stays symmetric
       a.lf_in = l.tb->lf;
       a.uc = uc;
-      a.mc_in = l.tb->mc;
-      a.rho_in = l.tb->rho;
+      xfer_in(a, *l.tb);
       ProfScope ps(ctx, AGGMG_KIND_FUSED_UP, k);
       CHECK(launch_btd(ctx, *l.S->btd, a, std::max(nPost, 0), k == 0 ? sel : TileSel()));
     } else {
@@ -1379,16 +1397,14 @@ extern "C" int aggmg_vcycles_dev(aggmg_ctx* ctx, aggmg_hier* h, const double* x0
     a.nsweeps = nPost + nPre;
     a.lf_in = l0.tb->lf;
     a.uc = uc;
-    a.mc_in = l0.tb->mc;
-    a.rho_in = l0.tb->rho;
+    xfer_in(a, *l0.tb);
     a.do_residual = 1;
     if (h->restriction == AGGMG_RESTRICT_PRECONDITIONED)
       a.ld_out = l0.tb->ld;
     else
       a.lf_out = l0.tb->lf;
     a.rc_out = c1.rhs;
-    a.mc_out = l0.tb->mc;
-    a.rho_out = l0.tb->rho;
+    xfer_out(a, *l0.tb);
     {
       ProfScope ps(ctx, AGGMG_KIND_FUSED_MID, 0);
       CHECK(launch_btd(ctx, *l0.S->btd, a, nPost + nPre + 1));
@@ -1405,8 +1421,7 @@ extern "C" int aggmg_vcycles_dev(aggmg_ctx* ctx, aggmg_hier* h, const double* x0
     a.nsweeps = nPost;
     a.lf_in = l0.tb->lf;
     a.uc = uc;
-    a.mc_in = l0.tb->mc;
-    a.rho_in = l0.tb->rho;
+    xfer_in(a, *l0.tb);
     ProfScope ps(ctx, AGGMG_KIND_FUSED_UP, 0);
     CHECK(launch_btd(ctx, *l0.S->btd, a, nPost));
   }

@@ -293,6 +293,13 @@ struct FusedArgs {
   const double* ld_out;  // [N][mc_out] rows of (L_e' D_e)': rc = (L'D) w, w = B^{-1} r -- no D, no L read
   double* rc_out;        // restricted residual
   int mc_out, rho_out;
+  // agglomerates of different sizes (rho_in / rho_out unused then): coarse element of every fine element,
+  // first fine element of every coarse element.  An agglomerate cut by a tile boundary is restricted by
+  // both tiles, each adding its part atomically (rc_out zeroed by the caller; two parts: order-independent)
+  const int32_t* par_in;
+  const int32_t* par_out;
+  const int32_t* first_out;
+  int64_t nec_out;  // coarse elements behind rc_out
   // tiling
   int owned;      // owned elements per tile (multiple of rho_out)
   int halo_left;  // elements of halo on the left of the owned range
@@ -380,7 +387,7 @@ __global__ __launch_bounds__(NT) void btd_fused_kernel(FusedArgs a) {
   // rows of L' (or (L'D)') for the restriction, fetched with the tile's other streams when the
   // coarse space has two modes per element (one 16-byte load per row)
   const double* lfo_pre = a.ld_out ? a.ld_out : a.lf_out;
-  const bool pre2 = a.do_residual && lfo_pre && a.mc_out == 2;
+  const bool pre2 = a.do_residual && lfo_pre && a.mc_out == 2 && !a.par_out;
   double l2x[NS], l2y[NS];
   double g[NS], bb[NS], uu[NS];
   double bi[NS][M];                              // B^{-1} rows, dead after g is formed
@@ -447,7 +454,7 @@ __global__ __launch_bounds__(NT) void btd_fused_kernel(FusedArgs a) {
         }
       }
       if (a.lf_in) {  // u += L uc : J = e / rho, ascending mode order (CSC scatter order)
-        const int64_t J = e / a.rho_in;
+        const int64_t J = a.par_in ? (int64_t)a.par_in[e] : e / a.rho_in;
         double add = 0.0;
         if (a.mc_in == 2) {  // one 16-byte load each for the L row and the coarse pair
           typedef double v2d __attribute__((ext_vector_type(2)));
@@ -679,6 +686,35 @@ __global__ __launch_bounds__(NT) void btd_fused_kernel(FusedArgs a) {
     }
   }
   if (!lfo) return;
+
+  if (a.par_out) {
+    // ---- restriction onto agglomerates of different sizes: r through LDS, one thread per (J, mode) over the
+    // part of the agglomerate this tile owns
+    const int mc = a.mc_out;
+    const int64_t eo0 = e0 + xo0 > 0 ? e0 + xo0 : 0;
+    const int64_t eo1 = e0 + xo1 < ne ? e0 + xo1 : ne;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const int x = s * EPS + le;
+      if (active) nxt[x * M + i] = rr[s];
+    }
+    __syncthreads();
+    if (eo1 <= eo0) return;
+    const int64_t Ja = a.par_out[eo0], Jb = a.par_out[eo1 - 1];
+    for (int64_t t = tid; t < (Jb - Ja + 1) * mc; t += NT) {
+      const int64_t J = Ja + t / mc;
+      const int c = (int)(t - (J - Ja) * mc);
+      const int64_t f0 = a.first_out[J], f1 = a.first_out[J + 1];
+      const int64_t lo = f0 > eo0 ? f0 : eo0, hi = f1 < eo1 ? f1 : eo1;
+      double acc = 0.0;
+      for (int64_t k = lo * M; k < hi * M; ++k) acc += lfo[k * mc + c] * nxt[k - e0 * M];  // ascending fine row
+      if (lo == f0 && hi == f1)
+        a.rc_out[J * mc + c] = acc;
+      else
+        atomicAdd(&a.rc_out[J * mc + c], acc);
+    }
+    return;
+  }
 
   const int rho = a.rho_out, mc = a.mc_out;
   const int ncoarse = a.owned / rho;  // owned coarse elements of this tile

@@ -381,6 +381,42 @@ int setup_transfer_btd(aggmg_ctx* ctx, const aggmg_op* L, const BtdDev* Abtd, in
     }
     out->mc = mc;
     out->rho = (int)rho;
+    out->nec = nec;
+    *ok = true;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return AGGMG_OK;
+  }
+  // agglomerates of different sizes (contiguous runs of fine elements, at most 64 each)
+  if (nef >= ((int64_t)1 << 31)) return AGGMG_OK;
+  for (int mc = 1; mc <= 16; ++mc) {
+    if (hint_mc > 0 && mc != hint_mc) continue;
+    if (Nc % mc) continue;
+    const int64_t nec = Nc / mc;
+    if (nec == 0 || nec > nef) continue;
+    double* lf = nullptr;
+    int32_t *first = nullptr, *parent = nullptr;
+    CHECK(dalloc(ctx, &lf, Nf * mc, true));
+    CHECK(dalloc(ctx, &first, nec + 1, true));
+    CHECK(dalloc(ctx, &parent, nef, true));
+    CHECK(bad.clear(ctx));
+    LAUNCH(transfer_vr_kernel, nec, nec, nef, mf, mc, 64, (const int32_t*)L->csc.rowptr, (const int32_t*)L->csc.colind,
+           (const double*)L->csc.vals, first, parent, lf, bad.d);
+    int b1 = 0;
+    CHECK(bad.read(ctx, &b1));
+    if (b1) {
+      (void)hipFree(lf), (void)hipFree(first), (void)hipFree(parent);
+      continue;
+    }
+    out->lf = lf;
+    out->first = first;
+    out->parent = parent;
+    if (Abtd && Abtd->dblk) {
+      CHECK(dalloc(ctx, &out->ld, Nf * mc, false));
+      LAUNCH(transfer_ld_kernel, Nf, nef, mf, mc, (const double*)lf, (const double*)Abtd->dblk, out->ld);
+    }
+    out->mc = mc;
+    out->rho = 0;
+    out->nec = nec;
     *ok = true;
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return AGGMG_OK;

@@ -461,6 +461,53 @@ __global__ __launch_bounds__(kSetupThreads) void transfer_scatter_kernel(int64_t
   }
 }
 
+// agglomerates of different sizes: every one of the mc columns of coarse element J stores the same contiguous run
+// of fine rows [first[J] mf, first[J+1] mf), the runs of consecutive J follow each other and cover all fine rows.
+// first[J], parent[e] and lf[(row)][mc]; bad[0] raised otherwise
+__global__ __launch_bounds__(kSetupThreads) void transfer_vr_kernel(int64_t nec, int64_t nef, int mf, int mc, int maxch,
+                                                                     const int32_t* __restrict__ colptr,
+                                                                     const int32_t* __restrict__ rowval,
+                                                                     const double* __restrict__ vals,
+                                                                     int32_t* __restrict__ first, int32_t* __restrict__ parent,
+                                                                     double* __restrict__ lf, int* __restrict__ bad) {
+  const int64_t J = (int64_t)blockIdx.x * kSetupThreads + threadIdx.x;
+  if (J >= nec) return;
+  const int32_t p0 = colptr[J * mc];
+  const int64_t len = colptr[J * mc + 1] - p0;
+  if (len <= 0 || len % mf || len / mf > maxch) {
+    bad[0] = 1;
+    return;
+  }
+  const int64_t r0 = rowval[p0];
+  if (r0 % mf) {
+    bad[0] = 1;
+    return;
+  }
+  // the run of the next coarse element must start where this one ends (the last one ends at the last fine row)
+  const int64_t rnext = J + 1 < nec ? (int64_t)rowval[colptr[(J + 1) * mc]] : nef * mf;
+  if ((J == 0 && r0 != 0) || r0 + len != rnext) {
+    bad[0] = 1;
+    return;
+  }
+  for (int c = 0; c < mc; ++c) {
+    const int32_t pc = colptr[J * mc + c];
+    if (colptr[J * mc + c + 1] - pc != len) {
+      bad[0] = 1;
+      return;
+    }
+    for (int64_t k = 0; k < len; ++k) {
+      if (rowval[pc + k] != r0 + k) {
+        bad[0] = 1;
+        return;
+      }
+      lf[(r0 + k) * mc + c] = vals[pc + k];
+    }
+  }
+  first[J] = (int32_t)(r0 / mf);
+  if (J == nec - 1) first[nec] = (int32_t)nef;
+  for (int64_t e = r0 / mf; e < (r0 + len) / mf; ++e) parent[e] = (int32_t)J;
+}
+
 // ld[(e, j)][c] = sum_i lf[(e, i)][c] * D_e[i][j]   (rows of (L_e' D_e)')
 __global__ __launch_bounds__(kSetupThreads) void transfer_ld_kernel(int64_t nef, int mf, int mc,
                                                                     const double* __restrict__ lf,

@@ -216,14 +216,15 @@ def test_cg_constructor_recurrences_on_device(oracle, mg, kw):
     assert np.linalg.norm(Ho.mStiffness[0] @ (x - xr)) <= 1e-12 * np.linalg.norm(b)
 
 
-def test_nonuniform_mesh_ragged_agglomerates_end_to_end(oracle, mg):
+@pytest.mark.parametrize("n", [46, 1403])
+def test_nonuniform_mesh_ragged_agglomerates_end_to_end(oracle, mg, n):
     """a12 + a13 on a mesh the uniform generator cannot make: perturbed vertices, agglomerates of 4/2/3, then 2/3,
     then 2 sub-elements.  The fine-level G, D, C, A come from the assembly (the oracle's restatement: out of scope);
     every L_k and mass block from the product's builders (interpolation.py), the Galerkin recurrences, A_k and the
     block smoothers from the device -- against the oracle's constructor on the same mesh, then V-cycles."""
     from agglomerationmultigrid1d_amd import interpolation as ip
     o = oracle
-    n, p, pAgg = 46, 3, 1
+    p, pAgg = 3, 1
     mesh = o.create_uniform_mesh(n, 0.0, 1.0)
     rng = np.random.default_rng(3)
     for v in mesh.mVertices[1:-1]:
@@ -264,15 +265,27 @@ def test_nonuniform_mesh_ragged_agglomerates_end_to_end(oracle, mg):
     H = mg.MeshHierarchy.from_dg_operators(meshes, A, G, D, C, Ls, masses)
     for k in range(1, len(meshes)):
         assert relmax(H.mStiffness[k].to_scipy(), Ho.mStiffness[k]) < 1e-11, k
-    # the fused block-tridiagonal kernels take transfers with ONE agglomeration ratio per level; ragged levels run
-    # the generic per-operator kernels (same arithmetic, more passes over HBM)
-    assert set(H.level_kinds()[:-1]) <= {'fused_btd', 'generic'}, H.level_kinds()
+    # agglomerates of different sizes run the fused kernels too (parent / first-child maps instead of one ratio; at
+    # n = 1403 the fine level has a dozen tiles, so agglomerates are cut by tile boundaries and restricted in two parts)
+    assert all(kind == 'fused_btd' for kind in H.level_kinds()[:-1]), H.level_kinds()
     x, xr = np.zeros(len(b)), np.zeros(len(b))
     for _ in range(3):
         x = mg.multigrid_v_cycle(H, x, b)
         xr = o.multigrid_v_cycle(Ho, xr, b)
     assert np.linalg.norm(A @ (x - xr)) <= 1e-12 * np.linalg.norm(b)
     assert np.linalg.norm(A @ x - b) < 0.05 * np.linalg.norm(b)
+    # the multi-cycle entry point (post- and pre-smoothing of consecutive cycles in one launch) and determinism
+    ctx = H.ctx
+    yd = ctx.alloc(len(b))
+    H.vcycles_dev(ctx.to_device(np.zeros(len(b))), ctx.to_device(b), yd, 3)
+    # (agglomerates of ONE size: bit for bit the separate cycles; here the fused post+pre launch has a deeper halo,
+    # cuts the agglomerates elsewhere and sums their two parts in a different association: round-off)
+    y = yd.download()
+    assert np.linalg.norm(A @ (y - x)) <= 1e-13 * np.linalg.norm(b) and np.linalg.norm(y - x) <= 1e-12 * np.linalg.norm(x)
+    x2 = np.zeros(len(b))
+    for _ in range(3):
+        x2 = mg.multigrid_v_cycle(H, x2, b)
+    assert np.array_equal(x2, x)
 
 
 def test_nonuniform_cg_chain_with_dg0_end_to_end(oracle, mg):
