@@ -78,6 +78,11 @@ extern "C" int aggmg_set_option(aggmg_ctx* ctx, int option, int value) {
     case AGGMG_OPT_SYMMETRIC_PACKING:
       ctx->sym_packing = value != 0;
       return AGGMG_OK;
+    case AGGMG_OPT_COARSE_CHUNK_LOG2:
+      if (value < 1 || value > kCrMaxStageLevels)
+        return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_set_option: AGGMG_OPT_COARSE_CHUNK_LOG2 takes 1 .. 12");
+      ctx->cr_max_q = value;
+      return AGGMG_OK;
   }
   return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_set_option: unknown option");
 }

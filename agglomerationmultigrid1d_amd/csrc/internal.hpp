@@ -39,6 +39,7 @@ struct aggmg_ctx {
   hipStream_t stream = nullptr;
   std::string err;
   bool sym_packing = true;  // AGGMG_OPT_SYMMETRIC_PACKING
+  int cr_max_q = 12;        // AGGMG_OPT_COARSE_CHUNK_LOG2
   int profiling = 0;  // 0 off, 1 every launch, 2 only the fine-level fused-down launch (dominant kernel)
   std::vector<ProfEvent> prof;
   std::vector<hipEvent_t> ev_pool;

@@ -596,7 +596,7 @@ int setup_cr(aggmg_ctx* ctx, const aggmg_op* Ac, int hint_m, CrDev* cr) {
     return std::min(std::max(v, lo), hi);
   };
   const int tail_rows = env_int("AGGMG_CR_TAIL_ROWS", kCrTailRows, 8, kCrTailRows);
-  const int max_q = env_int("AGGMG_CR_MAX_Q", kCrMaxStageLevels, 1, kCrMaxStageLevels);
+  const int max_q = env_int("AGGMG_CR_MAX_Q", ctx->cr_max_q, 1, kCrMaxStageLevels);
   int l0 = 0;
   while (l0 < nl && level_n(l0) * m > tail_rows) {
     int need = 0;

@@ -741,6 +741,20 @@ class HipEngine:
             c.check(c.lib.aggmg_copy_segments_dev(c.handle, n, src, dst, rows, cols, sld, dld))
 
 
+def _replicated_coarse_hierarchy(Ac, ctx, world):
+    """one-level hierarchy of the GLOBAL coarsest operator (every rank holds it; the chunk elimination follows the
+    partition).  A rank runs only its share of the chunks: smaller chunks than on one GPU keep its CUs busy"""
+    from . import _lib
+    from .api import MeshHierarchy
+    if world > 1:
+        ctx.set_option(_lib.OPT_COARSE_CHUNK_LOG2, 10)
+    try:
+        return MeshHierarchy(None, [Ac], [], [], ctx=ctx, keep_host=False, coarse_mode=_lib.COARSE_AUTO)
+    finally:
+        if world > 1:
+            ctx.set_option(_lib.OPT_COARSE_CHUNK_LOG2, 12)
+
+
 def build_local_uniform(n, p, pAgg, ratios, layout, ctx, comm, smoother="blockJac"):
     """Local operators of this rank for the uniform model problem, uploaded through the CSC
     boundary, plus the global coarsest operator assembled from every rank's owned block rows.
@@ -781,7 +795,7 @@ def build_local_uniform(n, p, pAgg, ratios, layout, ctx, comm, smoother="blockJa
     gsub, gdiag, gsup = (np.concatenate([allb[r, i] for r in range(comm.world)]) for i in range(3))
     colptr, rowval, nzval, N = block_tridiag_to_csc(gsub, gdiag, gsup)
     Ac = DeviceOperator(_csc(colptr, rowval, nzval, (N, N)), _lib.OP_STIFFNESS, ctx)
-    Hc = MeshHierarchy(None, [Ac], [], [], ctx=ctx, keep_host=False, coarse_mode=_lib.COARSE_AUTO)
+    Hc = _replicated_coarse_hierarchy(Ac, ctx, comm.world)
     return HipEngine(H, Hc, ctx), U
 
 
@@ -816,7 +830,7 @@ def build_local_cg(n, ps, layout, ctx, comm):
     gsub, gdiag, gsup = (np.concatenate([allb[r, i] for r in range(comm.world)]) for i in range(3))
     colptr, rowval, nzval, N = block_tridiag_to_csc(gsub, gdiag, gsup)
     Ac = DeviceOperator(_csc(colptr, rowval, nzval, (N, N)), _lib.OP_STIFFNESS, ctx)
-    Hc = MeshHierarchy(None, [Ac], [], [], ctx=ctx, keep_host=False, coarse_mode=_lib.COARSE_AUTO)
+    Hc = _replicated_coarse_hierarchy(Ac, ctx, comm.world)
     return HipEngine(H, Hc, ctx), U
 
 

@@ -60,6 +60,11 @@ int aggmg_synchronize(aggmg_ctx* ctx);
  * level, as between any two LU implementations; residuals and restrictions always use the operator's
  * own entries.  0 switches it off (the kernels then read B^{-1} and B^{-1} Sub as factored). */
 #define AGGMG_OPT_SYMMETRIC_PACKING 1
+/* AGGMG_OPT_COARSE_CHUNK_LOG2 (default 12): the largest chunk, in blocks (log2), one workgroup of the device
+ * coarsest solve eliminates (hierarchies created afterwards).  An element-partitioned run gives every rank only its
+ * share of the chunks of the replicated coarsest system: smaller chunks keep its CUs busy (measured on one rank's
+ * share of an 8-rank 2^24 job: 0.448 ms per cycle with 10, 0.474 ms with 12).  Values 1 .. 12. */
+#define AGGMG_OPT_COARSE_CHUNK_LOG2 2
 int aggmg_set_option(aggmg_ctx* ctx, int option, int value);
 /* Raw device memory owned by the context's device (plumbing for harnesses without torch). */
 int aggmg_dev_alloc(aggmg_ctx* ctx, int64_t nbytes, void** out);

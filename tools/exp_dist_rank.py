@@ -89,7 +89,7 @@ def main():
         g[i][-4:] = Ur.levels[nc]['A'][i][-4:]
     colptr, rowval, nzval, N = block_tridiag_to_csc(*g)
     Ac = mg.DeviceOperator(_csc(colptr, rowval, nzval, (N, N)), _lib.OP_STIFFNESS, ctx)
-    Hc = mg.MeshHierarchy(None, [Ac], [], [], ctx=ctx, keep_host=False, coarse_mode=_lib.COARSE_AUTO)
+    Hc = D._replicated_coarse_hierarchy(Ac, ctx, args.world)     # as build_local_uniform does
     engine = D.HipEngine(H, Hc, ctx)
     if args.python_schedule:
         dv = D.DistributedVCycle(engine, layout, comm)
