@@ -109,6 +109,25 @@ def _pool_map(fn, items, workers):
         return list(ex.map(fn, items))
 
 
+def _par_concat(parts, workers):
+    """np.concatenate of 1-D pieces with the copies spread over threads"""
+    if workers <= 1 or sum(q.size for q in parts) < (1 << 22):
+        return np.concatenate(parts)
+    out = np.empty(sum(q.size for q in parts), dtype=parts[0].dtype)
+    jobs, o = [], 0
+    step = 1 << 24
+    for q in parts:
+        for a in range(0, q.size, step):
+            jobs.append((o + a, q, a, min(a + step, q.size)))
+        o += q.size
+
+    def put(j):
+        out[j[0]:j[0] + j[3] - j[2]] = j[1][j[2]:j[3]]
+
+    _pool_map(put, jobs, workers)
+    return out
+
+
 def _ranges(n, parts, align=1):
     """<= parts contiguous ranges of [0, n) with boundaries at multiples of align"""
     units = n // align
@@ -666,20 +685,34 @@ class UniformCgDgHierarchy:
         self.xc = (self.xv[:-1] + self.xv[1:]) / 2.0
         self.J = self.h / 2.0
         self.refs = [RefElement(p) for p in self.ps]
-        self.A, self.L = [], []
+        nlev = len(self.ps) + 1
+        self.A, self.L = [None] * nlev, [None] * (nlev - 1)
+        # the element matrices of the levels follow from each other (cheap); every assembly / transfer after that
+        # is independent of the others: large meshes run them as tasks in threads (same functions, same bits)
         Ke, extra, dirv, self.b = self._cg_element_matrices_and_rhs(self.ps[0], self.refs[0])
-        self.A.append(self._assemble(self.ps[0], Ke, extra, dirv))
+        tasks = [lambda Ke=Ke, extra=extra: self.A.__setitem__(0, self._assemble(self.ps[0], Ke, extra, dirv))]
         for k in range(1, len(self.ps)):
             lowVal = self._low_val(self.refs[k], self.refs[k - 1])
-            self.L.append(self._cg_cg(self.ps[k], self.ps[k - 1], lowVal))
+            tasks.append(lambda k=k, lowVal=lowVal: self.L.__setitem__(k - 1, self._cg_cg(self.ps[k], self.ps[k - 1], lowVal)))
             Ke, extra = self._galerkin(Ke, extra, lowVal)
-            self.A.append(self._assemble(self.ps[k], Ke, extra, None))
-        # DG p = 0 level: re-discretised operator, lumped-mass transfer from the last CG level
-        dg0 = UniformDgAggHierarchy(n, p=0, pAgg=0, ratios=(), CDir=self.CDir, xin=xin, xout=xout, bc=self.bc,
-                                    func=func, elem_range=elem_range)
-        self.dg0 = dg0
-        self.L.append(self._dg0_cg(self.ps[-1], self.refs[-1]))
-        self.A.append(dg0.stiffness_csc(0))
+            tasks.append(lambda k=k, Ke=Ke, extra=extra: self.A.__setitem__(k, self._assemble(self.ps[k], Ke, extra, None)))
+
+        def dg0_level():
+            # DG p = 0 level: re-discretised operator, lumped-mass transfer from the last CG level
+            self.dg0 = UniformDgAggHierarchy(n, p=0, pAgg=0, ratios=(), CDir=self.CDir, xin=xin, xout=xout, bc=self.bc,
+                                             func=func, elem_range=elem_range, workers=1)
+            self.A[nlev - 1] = self.dg0.stiffness_csc(0)
+
+        tasks.append(dg0_level)
+        tasks.append(lambda: self.L.__setitem__(nlev - 2, self._dg0_cg(self.ps[-1], self.refs[-1])))
+        workers = min(len(tasks), _gen_workers()) if (self.n >= _PAR_MIN_ELEMS or os.environ.get("AGGMG_GEN_FORCE_PARALLEL")) else 1
+        _pool_map(lambda t: t(), tasks, workers)
+
+    def _workers(self):
+        """threads for the element-range fills of one assembly (the assemblies themselves also run side by side)"""
+        if self.n >= _PAR_MIN_ELEMS or os.environ.get("AGGMG_GEN_FORCE_PARALLEL"):
+            return _gen_workers()
+        return 1
 
     def nodes(self, p):
         """(n, p+1) 0-based node numbers per element in local order [left, right, interior...]"""
@@ -718,12 +751,21 @@ class UniformCgDgHierarchy:
         Kref = np.zeros((m, m))
         for l in range(len(ref.gw)):
             Kref += (ref.gw[l] * ref.dphi[l])[:, None] * ref.dphi[l][None, :]
-        K = (1.0 / self.J)[:, None, None] * Kref[None, :, :]
-        xq = self.xc[:, None] + self.h[:, None] / 2.0 * ref.gq[None, :]
-        fq = self.func(xq)
-        fe = np.zeros((n, m))
-        for l in range(len(ref.gw)):
-            fe += (self.J[:, None] * ref.gw[l]) * ref.phi[l][None, :] * fq[:, l][:, None]
+        K = np.empty((n, m, m))
+        fe = np.empty((n, m))
+        workers = self._workers()
+
+        def part(r):
+            a, b = r
+            K[a:b] = (1.0 / self.J[a:b])[:, None, None] * Kref[None, :, :]
+            xq = self.xc[a:b, None] + self.h[a:b, None] / 2.0 * ref.gq[None, :]
+            fq = self.func(xq)
+            t = np.zeros((b - a, m))
+            for l in range(len(ref.gw)):
+                t += (self.J[a:b, None] * ref.gw[l]) * ref.phi[l][None, :] * fq[:, l][:, None]
+            fe[a:b] = t
+
+        _pool_map(part, _ranges(n, 4 * workers if workers > 1 else 1), workers)
         f = np.zeros(N)
         f[1:n + 1] += fe[:, 1]          # element v-1 reaches vertex v before element v does
         f[0:n] += fe[:, 0]
@@ -813,18 +855,26 @@ class UniformCgDgHierarchy:
         # ---- vertex columns: rows v-1, v, v+1, interior of element v-1, interior of element v ----
         rows = np.empty((n + 1, W), dtype=np.int64)
         vals = np.zeros((n + 1, W))
-        rows[:, 0], rows[:, 1], rows[:, 2] = v - 1, v, v + 1
-        vals[1:, 0] = Ke[:, 0, 1]
-        vals[1:, 1] = Ke[:, 1, 1]
-        vals[:-1, 1] += Ke[:, 0, 0]
-        vals[:, 1] += extra
-        vals[:-1, 2] = Ke[:, 1, 0]
-        if q:
-            jj = np.arange(q, dtype=np.int64)
-            rows[:, 3:3 + q] = (n + 1) + (v[:, None] - 1) * q + jj[None, :]
-            rows[:, 3 + q:] = (n + 1) + v[:, None] * q + jj[None, :]
-            vals[1:, 3:3 + q] = Ke[:, 2:, 1]
-            vals[:-1, 3 + q:] = Ke[:, 2:, 0]
+        workers = self._workers()
+        jj = np.arange(q, dtype=np.int64)
+
+        def fill_vertices(r):
+            v0, v1 = r                       # vertices v0 .. v1-1; element v-1 reaches vertex v before element v does
+            vv = v[v0:v1]
+            lo, hi = max(v0, 1), min(v1, n)
+            rows[v0:v1, 0], rows[v0:v1, 1], rows[v0:v1, 2] = vv - 1, vv, vv + 1
+            vals[lo:v1, 0] = Ke[lo - 1:v1 - 1, 0, 1]
+            vals[lo:v1, 1] = Ke[lo - 1:v1 - 1, 1, 1]
+            vals[v0:hi, 1] += Ke[v0:hi, 0, 0]
+            vals[v0:v1, 1] += extra[v0:v1]
+            vals[v0:hi, 2] = Ke[v0:hi, 1, 0]
+            if q:
+                rows[v0:v1, 3:3 + q] = (n + 1) + (vv[:, None] - 1) * q + jj[None, :]
+                rows[v0:v1, 3 + q:] = (n + 1) + vv[:, None] * q + jj[None, :]
+                vals[lo:v1, 3:3 + q] = Ke[lo - 1:v1 - 1, 2:, 1]
+                vals[v0:hi, 3 + q:] = Ke[v0:hi, 2:, 0]
+
+        _pool_map(fill_vertices, _ranges(n + 1, 4 * workers if workers > 1 else 1), workers)
         irregular = {}
 
         def vmask(c):
@@ -852,12 +902,18 @@ class UniformCgDgHierarchy:
         counts = [counts]
         # ---- interior columns (e, j): rows v_e, v_e+1, interior of element e ----
         if q:
-            e = np.arange(n, dtype=np.int64)
             irows = np.empty((n, q, p + 1), dtype=np.int64)
-            irows[:, :, 0] = e[:, None]
-            irows[:, :, 1] = e[:, None] + 1
-            irows[:, :, 2:] = (n + 1) + e[:, None, None] * q + np.arange(q, dtype=np.int64)[None, None, :]
-            ivals = np.ascontiguousarray(Ke[:, :, 2:].transpose(0, 2, 1))
+            ivals = np.empty((n, q, p + 1))
+
+            def fill_interiors(r):
+                e0, e1 = r
+                e = np.arange(e0, e1, dtype=np.int64)
+                irows[e0:e1, :, 0] = e[:, None]
+                irows[e0:e1, :, 1] = e[:, None] + 1
+                irows[e0:e1, :, 2:] = (n + 1) + e[:, None, None] * q + jj[None, None, :]
+                ivals[e0:e1] = Ke[e0:e1, :, 2:].transpose(0, 2, 1)
+
+            _pool_map(fill_interiors, _ranges(n, 4 * workers if workers > 1 else 1), workers)
             irr = {}
             for d in dirs:
                 for el, loc in ((d - 1, 1), (d, 0)):       # elements touching the Dirichlet vertex
@@ -871,7 +927,7 @@ class UniformCgDgHierarchy:
             vparts += v2
         colptr = np.zeros(N + 1, dtype=np.int64)
         np.cumsum(np.concatenate(counts), out=colptr[1:])
-        A = sp.csc_matrix((np.concatenate(vparts), np.concatenate(rparts), colptr), shape=(N, N))
+        A = sp.csc_matrix((_par_concat(vparts, workers), _par_concat(rparts, workers), colptr), shape=(N, N))
         A.has_sorted_indices = True
         return A
 

@@ -165,3 +165,18 @@ def test_range_parallel_generator_is_bitwise_the_serial_one(monkeypatch, workers
             assert np.array_equal(L1.indices, L2.indices) and np.array_equal(L1.data, L2.data)
         assert np.array_equal(U1.rhs(), U2.rhs())
         assert U1.algorithmic_bytes() == U2.algorithmic_bytes()
+
+
+@pytest.mark.parametrize("workers", [2, 5])
+def test_cg_generator_in_threads_is_bitwise_the_serial_one(monkeypatch, workers):
+    """the config-5 generator runs its assemblies side by side and fills their strips element range by element range"""
+    from agglomerationmultigrid1d_amd.uniform import UniformCgDgHierarchy
+    for n, bc in ((300, None), (37, (('dir', 0.2), ('dir', 0.7))), (64, (('neu', 0.1), ('neu', 0.3)))):
+        monkeypatch.delenv("AGGMG_GEN_FORCE_PARALLEL", raising=False)
+        U1 = UniformCgDgHierarchy(n, ps=(4, 2, 1), bc=bc)
+        monkeypatch.setenv("AGGMG_GEN_FORCE_PARALLEL", "1")
+        monkeypatch.setenv("AGGMG_GEN_WORKERS", str(workers))
+        U2 = UniformCgDgHierarchy(n, ps=(4, 2, 1), bc=bc)
+        for a, b in zip(U1.A + U1.L, U2.A + U2.L):
+            assert np.array_equal(a.indptr, b.indptr) and np.array_equal(a.indices, b.indices) and np.array_equal(a.data, b.data)
+        assert np.array_equal(U1.rhs(), U2.rhs())
