@@ -184,6 +184,11 @@ int aggmg_prolong_add_dev(aggmg_ctx* ctx, aggmg_op* L, const double* uc, double*
 /* ---- hierarchy: MeshHierarchy + multigrid_v_cycle ------------------------------------------- */
 /* Coarsest level `u[n] = A_n \\ rhs[n]` (src/solvers.jl:39; UMFPACK re-factorises per cycle in the
  * reference, here the factorisation is done once at aggmg_hier_create). */
+/* Environment variables read when the device solver is planned / launched -- measurement and test knobs, none of
+ * them changes a result beyond round-off: AGGMG_CR_TAIL_ROWS, AGGMG_CR_MAX_Q (smaller tail / chunks: the tests run
+ * the several-stage plan of > 2^24-row systems at small sizes with them), AGGMG_CR_FILL, AGGMG_CR_MINWG,
+ * AGGMG_CR_THREADS (chunk and workgroup size sweeps, tools/exp_coarse_knobs.sh), AGGMG_CR_FUSE_TAIL=1 (boundary
+ * system solved by the last-arriving workgroup of the forward launch: measured 5x slower). */
 #define AGGMG_COARSE_HOST_BANDED 0 /* banded LU with partial pivoting on the host (D2H, solve, H2D) */
 #define AGGMG_COARSE_DEVICE_CR 1   /* block cyclic reduction on the device; error if not applicable */
 #define AGGMG_COARSE_EXTERNAL 3    /* no factorisation: the caller solves the coarsest system between
