@@ -279,10 +279,10 @@ class UniformDgAggHierarchy:
         self.bc = bc or (('neu', -math.sin(xin)), ('dir', math.cos(xout)))
         self.func = func
         self.ref = RefElement(p)
-        if elem_range is None:
+        if not _left_pad:      # (a range of such a build is built in one piece)
             workers = _gen_workers() if workers is None else int(workers)
-            rngs = _ranges(n, 4 * workers if n >= (1 << 22) else workers, tot)
-            if len(rngs) > 1 and (workers > 1) and (n >= _PAR_MIN_ELEMS or os.environ.get("AGGMG_GEN_FORCE_PARALLEL")):
+            rngs = [(a + r0, a + r1) for r0, r1 in _ranges(b - a, 4 * workers if b - a >= (1 << 22) else workers, tot)]
+            if len(rngs) > 1 and (workers > 1) and (b - a >= _PAR_MIN_ELEMS or os.environ.get("AGGMG_GEN_FORCE_PARALLEL")):
                 self._build_by_ranges(rngs, workers, dict(p=p, pAgg=pAgg, ratios=ratios, CDir=self.CDir, xin=xin,
                                                           xout=xout, bc=self.bc, func=func))
                 return
@@ -330,14 +330,14 @@ class UniformDgAggHierarchy:
     def _build_by_ranges(self, rngs, workers, kw):
         """the whole mesh range by range (threads); every worker writes its slice of the stiffness blocks,
         the interpolation rows and the right-hand side (the intermediate G, D, C, M blocks stay range-local)"""
-        n = self.n_global
+        n, a = self.n_global, self.a        # the ranges lie in [a, b): the owned elements of this build
         m = [self.p + 1] + [self.pAgg + 1] * len(self.ratios)
-        ne = [n]
+        ne = [self.nloc]
         for rho in self.ratios:
             ne.append(ne[-1] // rho)
         A = [tuple(np.empty((ne[k], m[k], m[k])) for _ in range(3)) for k in range(len(m))]
         Lb = [np.empty((ne[k], m[k], m[k + 1])) for k in range(len(self.ratios))]
-        rhs = np.empty(n * m[0])
+        rhs = np.empty(self.nloc * m[0])
 
         def work(r):
             q = UniformDgAggHierarchy(n, elem_range=r, _left_pad=True, **kw)
@@ -345,12 +345,12 @@ class UniformDgAggHierarchy:
             for k in range(len(m)):
                 if k > 0:
                     per *= self.ratios[k - 1]
-                sl = slice(r[0] // per, r[1] // per)
+                sl = slice((r[0] - a) // per, (r[1] - a) // per)
                 for i in range(3):
                     A[k][i][sl] = q.levels[k]['A'][i]
                 if k < len(Lb):
                     Lb[k][sl] = q.transfers[k]['Lb']
-            rhs[r[0] * m[0]:r[1] * m[0]] = q._rhs_full
+            rhs[(r[0] - a) * m[0]:(r[1] - a) * m[0]] = q._rhs_full
             return None
 
         _pool_map(work, rngs, workers)
