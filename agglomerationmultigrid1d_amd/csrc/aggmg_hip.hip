@@ -248,6 +248,16 @@ extern "C" int aggmg_blockjacobi_setup(aggmg_ctx* ctx, aggmg_op* A, int64_t m, i
     }
     sm->gs = true;
   }
+  // overlapping element blocks of a CG mesh (cg_smoother :addSchwarz / :hybridSchwarz): the lists are the
+  // element chain -- the sweeps then run in the fused chain kernel (apply_smoother keeps the generic kernel)
+  if (kind != 2 && !sm->btd && m >= 2 && m <= 9 && nb >= 1 && A->m == nb * (m - 1) + 1) {
+    CHECK(cgt_build(ctx, sm.get(), blockinds, m, nb, one_based));
+    if (sm->cgt) CHECK(cgt_attach_schwarz(ctx, sm.get(), kind == 1 ? 2 : 1));
+    if (sm->cgt && !sm->cgt->sw) {  // (not attached: no point-Jacobi chain for a block smoother)
+      sm->cgt.reset();
+      A->cgt.reset();
+    }
+  }
   *out = sm.release();
   return AGGMG_OK;
 }

@@ -47,15 +47,19 @@ int cgt_tile_blocks(int m) {
   return 0;
 }
 
-// sweeps fused into one launch: every sweep costs one block of halo per side
-static int cgt_max_sweeps(int m) { return std::max(1, std::min(8, cgt_tile_blocks(m) / 8)); }
+// sweeps fused into one launch: every sweep costs one block of halo per side (element Schwarz sweeps: two)
+static int cgt_max_sweeps(int m, int sw = 0) {
+  return std::max(1, std::min(8, cgt_tile_blocks(m) / (sw ? 16 : 8)));
+}
 
 template <int M>
-static int cgt_launch_t(aggmg_ctx* ctx, CgtArgs a) {
+static int cgt_launch_t(aggmg_ctx* ctx, CgtArgs a, int sw) {
   using T = CgtTile<M>;
-  // halo: one block per sweep and side; the residual needs one more valid neighbour on both sides,
+  if (a.nsweeps == 0) sw = 0;
+  // halo: one block per sweep and side (element Schwarz: the update of a block reads the residual of its two
+  // neighbours, i.e. the iterate two blocks away); the residual needs one more valid neighbour on both sides,
   // the restriction one more block of residual on the left (chain) or on the right (agglomerating)
-  int hl = a.nsweeps, hr = a.nsweeps;
+  int hl = a.nsweeps * (sw ? 2 : 1), hr = hl;
   if (a.do_residual) {
     hl += 1 + (a.tout.type == kTrChain ? 1 : 0);
     hr += 1 + (a.tout.type == kTrAgg ? 1 : 0);
@@ -70,8 +74,13 @@ static int cgt_launch_t(aggmg_ctx* ctx, CgtArgs a) {
   const int64_t ntiles = (a.lv.ne + owned - 1) / owned;
   if (ntiles == 0) return AGGMG_OK;
   if (ntiles >= ((int64_t)1 << 31)) return fail(ctx, AGGMG_ERR_UNSUPPORTED, "grid too large");
-  const size_t lds = (size_t)2 * (T::TE + 2) * M * sizeof(double);
-  hipLaunchKernelGGL((cgt_fused_kernel<M, T::NS, T::NT>), dim3((unsigned)ntiles), dim3(T::NT), lds, ctx->stream, a);
+  const size_t lds = (size_t)(sw ? 3 : 2) * (T::TE + 2) * M * sizeof(double);
+  if (sw == 1)
+    hipLaunchKernelGGL((cgt_fused_kernel<M, T::NS, T::NT, 1>), dim3((unsigned)ntiles), dim3(T::NT), lds, ctx->stream, a);
+  else if (sw == 2)
+    hipLaunchKernelGGL((cgt_fused_kernel<M, T::NS, T::NT, 2>), dim3((unsigned)ntiles), dim3(T::NT), lds, ctx->stream, a);
+  else
+    hipLaunchKernelGGL((cgt_fused_kernel<M, T::NS, T::NT, 0>), dim3((unsigned)ntiles), dim3(T::NT), lds, ctx->stream, a);
   HIPCHK(hipGetLastError());
   return AGGMG_OK;
 }
@@ -80,7 +89,7 @@ static int cgt_launch(aggmg_ctx* ctx, const CgtDev& g, const CgtArgs& a) {
   switch (g.m) {
 #define CASE(MM) \
   case MM:       \
-    return cgt_launch_t<MM>(ctx, a);
+    return cgt_launch_t<MM>(ctx, a, g.sw);
     CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
 #undef CASE
   }
@@ -90,7 +99,7 @@ static int cgt_launch(aggmg_ctx* ctx, const CgtDev& g, const CgtArgs& a) {
 static CgtArgs cgt_args(const CgtDev& g) {
   CgtArgs a;
   std::memset(&a, 0, sizeof(a));
-  a.lv = CgtLevel{g.dblk, g.subrow, g.supcol, g.ne};
+  a.lv = CgtLevel{g.dblk, g.subrow, g.supcol, g.ne, g.zrows, g.zlast};
   a.perm = g.perm;
   a.affine = g.affine ? 1 : 0;
   return a;
@@ -128,7 +137,7 @@ struct CgtChain {
 static int cgt_run(aggmg_ctx* ctx, const CgtDev& g, const CgtChain& c, double alpha, int nsweeps, const CgtArgs& first,
                    const CgtArgs& last, int kind, int level) {
   // at most smax sweeps per launch (2 * smax + 3 blocks of halo always fit a tile)
-  const int smax = cgt_max_sweeps(g.m);
+  const int smax = cgt_max_sweeps(g.m, g.sw);
   const int nl = std::max(1, (nsweeps + smax - 1) / smax);
   if (nl > 1 && (!c.t0 || (nl > 2 && !c.t1))) return fail(ctx, AGGMG_ERR_UNSUPPORTED, "internal: chain temporaries missing");
   const double* src = c.src;
@@ -185,7 +194,7 @@ int cgt_smooth_ext(aggmg_ctx* ctx, const CgtDev& g, const double* u_in, const do
   c.b_ext = true;
   c.dst = u_out;
   c.dst_ext = true;
-  if (nsweeps > cgt_max_sweeps(g.m)) {
+  if (nsweeps > cgt_max_sweeps(g.m, g.sw)) {
     CHECK(scratch(ctx, 0, g.ne * g.m, &c.t0));
     CHECK(scratch(ctx, 1, g.ne * g.m, &c.t1));
   }
@@ -268,7 +277,7 @@ int cgt_mid(aggmg_ctx* ctx, aggmg_hier* h, const double* cur, double* alt, const
   ch.dst = alt;
   ch.dst_ext = false;
   ch.t0 = l.tmp;
-  if (nsweeps > 2 * cgt_max_sweeps(g.m)) CHECK(scratch(ctx, 0, g.ne * g.m, &ch.t1));
+  if (nsweeps > 2 * cgt_max_sweeps(g.m, g.sw)) CHECK(scratch(ctx, 0, g.ne * g.m, &ch.t1));
   CgtArgs first, last;
   std::memset(&first, 0, sizeof(first));
   std::memset(&last, 0, sizeof(last));

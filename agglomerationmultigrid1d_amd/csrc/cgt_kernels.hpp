@@ -27,6 +27,8 @@ namespace aggmg {
 struct CgtLevel {
   const double *dblk, *subrow, *supcol;
   int64_t ne;  // blocks, the trailing (partial, identity-padded) one included
+  // element Schwarz sweeps (SW != 0): rows of the element inverses, chain-local order (CgtDev::zrows / zlast)
+  const double *zrows, *zlast;
 };
 
 // which vectors of a launch live in the caller's numbering (indexed through perm)
@@ -76,7 +78,14 @@ __device__ __forceinline__ int64_t cgt_tile(const CgtArgs& a) {
   return (int64_t)blockIdx.x + ((int)blockIdx.x >= a.tile_split ? a.tile_skip : 0);
 }
 
-template <int M, int NS, int NT>
+// SW = 0: point-Jacobi sweeps.  SW = 1 / 2: additive / hybrid Schwarz sweeps over the ELEMENTS of the chain
+// (AdditiveSchwarzSmoother, HybridSchwarzSmoother, src/smoother.jl:1-46; cg_smoother :104-134):
+//     u += alpha * [1/count] * sum_e R_e' (A[nodes_e, nodes_e] \ R_e (b - A u))
+// element e = block e plus the first row of block e + 1 (its right vertex); a vertex receives the
+// contribution of the element on its left first, then its own element's (the reference's loop order);
+// count = 2 on interior vertices, 1 elsewhere.  Two LDS phases per sweep (residual, then the element
+// solves on it) and two blocks of halo per sweep and side.
+template <int M, int NS, int NT, int SW = 0>
 __global__ __launch_bounds__(NT) void cgt_fused_kernel(CgtArgs a) {
   // GRP: a block's rows sit in M = 2^k adjacent lanes; lane i keeps entry i of the block's
   // sub-diagonal row and the dot product with the left neighbour is a cross-lane sum
@@ -86,6 +95,7 @@ __global__ __launch_bounds__(NT) void cgt_fused_kernel(CgtArgs a) {
   extern __shared__ double lds[];
   double* buf0 = lds + M;  // index x*M + j, x in [-1, TE]
   double* buf1 = lds + (TE + 2) * M + M;
+  double* rbuf = lds + 2 * (TE + 2) * M + M;  // SW: the residual of the current sweep
 
   const int tid = threadIdx.x;
   const bool active = tid < EPS * M;
@@ -99,8 +109,13 @@ __global__ __launch_bounds__(NT) void cgt_fused_kernel(CgtArgs a) {
     buf0[TE * M + tid] = 0.0;
     buf1[-M + tid] = 0.0;
     buf1[TE * M + tid] = 0.0;
+    if (SW) {
+      rbuf[-M + tid] = 0.0;
+      rbuf[TE * M + tid] = 0.0;
+    }
   }
 
+  double zr[NS][SW ? M + 1 : 1], zl[NS][SW ? M + 1 : 1];  // SW: own row of the element inverse; lane 0: the left element's last row
   double d[NS][M], sup[NS], sr[NS][GRP ? 1 : M], dg[NS], bb[NS], uu[NS];
   int32_t pr[NS];
   bool valid[NS];
@@ -121,7 +136,20 @@ __global__ __launch_bounds__(NT) void cgt_fused_kernel(CgtArgs a) {
     for (int j = 0; j < M; ++j) d[s][j] = 0.0;
 #pragma unroll
     for (int j = 0; j < (GRP ? 1 : M); ++j) sr[s][j] = 0.0;
+#pragma unroll
+    for (int j = 0; j < (SW ? M + 1 : 1); ++j) {
+      zr[s][j] = 0.0;
+      zl[s][j] = 0.0;
+    }
     if (valid[s]) {
+      if (SW && a.nsweeps > 0) {
+#pragma unroll
+        for (int j = 0; j <= M; ++j) zr[s][j] = AGGMG_LD(a.lv.zrows[row * (M + 1) + j]);
+        if (i == 0) {
+#pragma unroll
+          for (int j = 0; j <= M; ++j) zl[s][j] = a.lv.zlast[e * (M + 1) + j];
+        }
+      }
 #pragma unroll
       for (int j = 0; j < M; ++j) d[s][j] = AGGMG_LD(a.lv.dblk[row * M + j]);
 #pragma unroll
@@ -201,16 +229,56 @@ __global__ __launch_bounds__(NT) void cgt_fused_kernel(CgtArgs a) {
   double* cur = buf0;
   double* nxt = buf1;
   for (int sw = 0; sw < a.nsweeps; ++sw) {
+    if (SW) {
+      // phase A: the residual of every row of the tile into LDS
 #pragma unroll
-    for (int s = 0; s < NS; ++s) {
-      const int x = s * EPS + le;
-      if (active) {
-        const double r = bb[s] - row_Au(s, x, cur);
-        const double y = r / dg[s];
-        double un = uu[s] + a.alpha * y;
-        if (!valid[s]) un = 0.0;
-        uu[s] = un;
-        nxt[x * M + i] = un;
+      for (int s = 0; s < NS; ++s) {
+        const int x = s * EPS + le;
+        if (active) {
+          const double r = bb[s] - row_Au(s, x, cur);
+          rbuf[x * M + i] = valid[s] ? r : 0.0;
+        }
+      }
+      __syncthreads();
+      // phase B: row i of  A_e \ r_e  (own element), lane 0 also the last row of the left element's solve
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const int x = s * EPS + le;
+        if (active) {
+          const double* rx = rbuf + x * M;
+          double y = 0.0;
+#pragma unroll
+          for (int j = 0; j < M; ++j) y += zr[s][j] * rx[j];
+          y += zr[s][M] * rx[M];  // the element's right vertex = first row of the next block
+          if (i == 0) {
+            double yl = 0.0;
+#pragma unroll
+            for (int j = 0; j < M; ++j) yl += zl[s][j] * rx[j - M];
+            yl += zl[s][M] * rx[0];
+            y = yl + y;             // element e - 1 reaches the vertex before element e does
+            if (SW == 2) {
+              const int64_t e = e0 + x;
+              if (e > 0 && e < ne - 1) y = y / 2.0;  // mCountingMatrix: two elements share an interior vertex
+            }
+          }
+          double un = uu[s] + a.alpha * y;
+          if (!valid[s]) un = 0.0;
+          uu[s] = un;
+          nxt[x * M + i] = un;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const int x = s * EPS + le;
+        if (active) {
+          const double r = bb[s] - row_Au(s, x, cur);
+          const double y = r / dg[s];
+          double un = uu[s] + a.alpha * y;
+          if (!valid[s]) un = 0.0;
+          uu[s] = un;
+          nxt[x * M + i] = un;
+        }
       }
     }
     __syncthreads();

@@ -97,8 +97,13 @@ struct CgtDev {
   int32_t* perm = nullptr;  // [ne*m] block order -> reference numbering, -1 = padding
   int32_t* inv = nullptr;   // [N]    reference numbering -> block order
   bool affine = false;      // perm is the reference's vertices-first numbering: the kernel computes it
+  // element Schwarz smoothers on the chain (cg_smoother :addSchwarz / :hybridSchwarz): rows of the inverses of
+  // the element blocks A[nodes_e, nodes_e] in chain-local order [block e, first row of block e + 1]
+  int sw = 0;               // 0 point Jacobi, 1 additive Schwarz, 2 hybrid Schwarz
+  double* zrows = nullptr;  // [ne*m][m+1]  row i of element e's inverse at (e*m + i)
+  double* zlast = nullptr;  // [ne][m+1]    its last row (the right vertex) at e + 1: with the block that owns the vertex
   ~CgtDev() {
-    for (void* p : {(void*)dblk, (void*)subrow, (void*)supcol, (void*)perm, (void*)inv})
+    for (void* p : {(void*)dblk, (void*)subrow, (void*)supcol, (void*)perm, (void*)inv, (void*)zrows, (void*)zlast})
       if (p) (void)hipFree(p);
   }
 };
@@ -358,6 +363,7 @@ struct ProfScope {
 // ---------------------------------------------------------------------------------------------
 int cgt_tile_blocks(int m);
 int cgt_build(aggmg_ctx* ctx, aggmg_smoother* sm, const int64_t* elems, int64_t m1, int64_t nel, int one_based);
+int cgt_attach_schwarz(aggmg_ctx* ctx, aggmg_smoother* sm, int sw);
 int cgt_build_transfer(aggmg_ctx* ctx, const aggmg_op* L, const CgtDev& fine, const CgtDev* coarse, int hint_mc,
                        TransferCgt* out, bool* ok);
 // nsweeps sweeps on external (reference-numbered) vectors; u_in may be nullptr (zero), u_out != u_in

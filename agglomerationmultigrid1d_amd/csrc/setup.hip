@@ -745,6 +745,23 @@ int cgt_build(aggmg_ctx* ctx, aggmg_smoother* sm, const int64_t* elems, int64_t 
   return AGGMG_OK;
 }
 
+// Element Schwarz smoothers on a chain (cg_smoother(cgMesh, A, :addSchwarz / :hybridSchwarz), src/smoother.jl:104-134):
+// after cgt_build recognised the element chain, the inverses of the element blocks (already computed for the
+// generic apply, K6) are re-ordered into the rows the fused kernel keeps in registers.  sw: 1 additive, 2 hybrid.
+int cgt_attach_schwarz(aggmg_ctx* ctx, aggmg_smoother* sm, int sw) {
+  if (!sm->cgt || !sm->binv) return AGGMG_OK;
+  CgtDev& g = *sm->cgt;
+  const int M = g.m;
+  const int64_t nel = g.ne - 1;
+  if (sm->m != M + 1 || sm->nb != nel) return AGGMG_OK;
+  CHECK(dalloc(ctx, &g.zrows, g.ne * M * (M + 1), true));
+  CHECK(dalloc(ctx, &g.zlast, g.ne * (M + 1), true));
+  LAUNCH(chain_schwarz_rows_kernel, nel * (M + 1), nel, M, (const double*)sm->binv, g.zrows, g.zlast);
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  g.sw = sw;
+  return AGGMG_OK;
+}
+
 int cgt_build_transfer(aggmg_ctx* ctx, const aggmg_op* L, const CgtDev& f, const CgtDev* coarse, int hint_mc,
                        TransferCgt* out, bool* ok) {
   const int tile_blocks = cgt_tile_blocks(f.m);

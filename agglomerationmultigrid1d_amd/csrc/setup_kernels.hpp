@@ -847,6 +847,22 @@ __global__ __launch_bounds__(kSetupThreads) void chain_perm_kernel(int64_t nel, 
   if (e == nel - 1) perm[nel * m] = (int32_t)(elems[e * m1 + 1] - base);
 }
 
+// rows of the element inverses for the Schwarz sweeps of the chain kernel: binv [nel][M+1][M+1] in the element
+// lists' local order [left vertex, right vertex, interior ...] -> chain-local order [left vertex, interior ..., right
+// vertex]; rows 0 .. M-1 of element e to zrows[(e*M + i)][M+1], its last row to zlast[e + 1][M+1]
+__global__ __launch_bounds__(kSetupThreads) void chain_schwarz_rows_kernel(int64_t nel, int M, const double* __restrict__ binv,
+                                                                           double* __restrict__ zrows, double* __restrict__ zlast) {
+  const int64_t t = (int64_t)blockIdx.x * kSetupThreads + threadIdx.x;
+  const int m1 = M + 1;
+  if (t >= nel * m1) return;
+  const int64_t e = t / m1;
+  const int ci = (int)(t - e * m1);
+  auto ref = [&](int c) { return c == 0 ? 0 : (c == M ? 1 : c + 1); };
+  const double* src = binv + e * m1 * m1 + ref(ci) * m1;
+  double* dst = ci < M ? zrows + (e * M + ci) * m1 : zlast + (e + 1) * m1;
+  for (int cj = 0; cj <= M; ++cj) dst[cj] = src[ref(cj)];
+}
+
 // is the block order the reference's vertices-first numbering itself?  flags[3] raised if not
 __global__ __launch_bounds__(kSetupThreads) void chain_affine_check_kernel(int64_t ne, int m, const int32_t* __restrict__ perm,
                                                                            int* __restrict__ flags) {

@@ -234,6 +234,30 @@ def smoother_bench(mg, ctx, args, alpha):
                                    "frac_of_8TBs": Rc * 100 / dt / 1e9 / HBM_PEAK_GBS}
         del opc, Jc
     out["cg_p4_point_jacobi"] = cg
+    # the element Schwarz smoothers of cg_smoother (src/smoother.jl:104-134) on the same operator: fused chain kernel
+    # (element lists in mesh order) against the generic kernels (same blocks listed in another order: residual pass,
+    # batched block apply with atomics, update).  Algorithmic bytes per sweep: the residual's CSR pass + the element
+    # inverses (8 (p+1)^2 per element) + gather / scatter / update of the vectors
+    sw = {"workload": f"CG n=2^20 p=4 element Schwarz, N={Nc}, {n} overlapping blocks of 5"}
+    Ssw = Rc + 8 * 25 * n + 32 * Nc
+    el = C.element_nodes(0)
+    perm = np.random.default_rng(0).permutation(el.shape[1])
+    for kind, cls in (("additive", mg.AdditiveSchwarzSmoother), ("hybrid", mg.HybridSchwarzSmoother)):
+        for label, lists in (("chain", el), ("generic", np.ascontiguousarray(el[:, perm]))):
+            opc = mg.DeviceOperator(A, _lib.OP_STIFFNESS, ctx)
+            Sw = cls(opc, lists, ctx)
+            assert Sw.structured == (label == "chain")
+            for per_launch in (1, 3):
+                reps = 60 // per_launch
+                fn = sweeps(opc.handle, Sw.handle, per_launch, uc, vc, bc)
+                fn(2)
+                dt = _time_loop(ctx, fn, reps)
+                nsw = reps * per_launch
+                sw[f"{kind}_{label}_sweeps_{per_launch}_per_launch"] = {
+                    "us_per_sweep": 1e6 * dt / nsw, "algorithmic_GBs": Ssw * nsw / dt / 1e9,
+                    "frac_of_8TBs": Ssw * nsw / dt / 1e9 / HBM_PEAK_GBS}
+            del opc, Sw
+    out["cg_p4_element_schwarz"] = sw
     return out
 
 

@@ -180,8 +180,43 @@ def test_chain_level_below_generic_level(oracle, mg):
     reference numbering (hybrid Schwarz on the finest CG level, src/smoother.jl:24-46)"""
     o = oracle
     Ho, b = o.build_cg_hierarchy(48, ps=(4, 2, 1), nDG=1, pDG=0)
-    Ho.mSmoothers[0] = o.cg_smoother(Ho.mMeshes[0], Ho.mStiffness[0], 'hybridSchwarz')
+    S = o.cg_smoother(Ho.mMeshes[0], Ho.mStiffness[0], 'hybridSchwarz')
+    # element blocks listed in another order than the mesh's: the same smoother, but its lists are no element
+    # chain any more, so the level runs the generic kernels
+    order = np.random.default_rng(1).permutation(len(S.mBlocks))
+    S.mBlocks = [S.mBlocks[i] for i in order]
+    S.mBlockInds = S.mBlockInds[:, order]
+    Ho.mSmoothers[0] = S
     check_vcycle(o, mg, Ho, b, it_tol=1e-8, kinds=['generic', 'fused_chain', 'fused_chain', 'coarsest'])
+
+
+@pytest.mark.parametrize("kind", ["addSchwarz", "hybridSchwarz"])
+@pytest.mark.parametrize("n,ps", [(5, (4, 2, 1)), (64, (4, 2, 1)), (700, (4, 2, 1)), (300, (8, 4)), (500, (2, 1)), (90, (3,))])
+def test_schwarz_levels_run_the_chain_kernel(oracle, mg, kind, n, ps):
+    """cg_smoother(mesh, A, :addSchwarz / :hybridSchwarz) (src/smoother.jl:104-134) on every CG level: the overlapping
+    element blocks are the element chain, so the sweeps u += alpha [1/count] sum_e R_e' (A_e \\ R_e (b - A u)) run
+    in the fused chain kernel (two LDS phases per sweep, two blocks of halo), V-cycles against the oracle"""
+    o = oracle
+    Ho, b = o.build_cg_hierarchy(n, ps=ps, nDG=1, pDG=0)
+    for k in range(len(ps)):
+        Ho.mSmoothers[k] = o.cg_smoother(Ho.mMeshes[k], Ho.mStiffness[k], kind)
+    alpha = 0.5 if kind == "addSchwarz" else 1.0       # tests/cg_smoother_test.jl
+    kinds = ['fused_chain'] * len(ps) + ['coarsest']
+    H = check_vcycle(o, mg, Ho, b, alpha=alpha, it_tol=1e-8, kinds=kinds)
+    N = len(b)
+    check_vcycle(o, mg, Ho, o.splitmix_normal(N, 1), x0=o.splitmix_normal(N, 0), alpha=alpha, it_tol=1e-8)
+    check_vcycle(o, mg, Ho, b, nPre=1, nPost=2, alpha=0.4, it_tol=1e-8)
+    check_vcycle(o, mg, Ho, b, nPre=9, nPost=7, alpha=alpha, it_tol=1e-7)     # sweeps chunked over several launches
+    # the multi-cycle entry point: post- and pre-smoothing of consecutive cycles in one launch, bitwise
+    ctx = H.ctx
+    db = ctx.to_device(b)
+    xa, xb = ctx.to_device(np.zeros(N)), ctx.alloc(N)
+    for _ in range(3):
+        H.vcycle_dev(xa, db, xb, 3, 3, alpha)
+        xa, xb = xb, xa
+    out = ctx.alloc(N)
+    H.vcycles_dev(ctx.to_device(np.zeros(N)), db, out, 3, 3, 3, alpha)
+    assert np.array_equal(out.download(), xa.download())
 
 
 def test_multigrid_loop_on_chain_hierarchy(oracle, mg):

@@ -102,19 +102,27 @@ def test_schwarz_smoothers_in_fused_sweeps(oracle, mg):
     """aggmg_smooth with overlapping CG element blocks (additive / hybrid Schwarz, src/smoother.jl
     :1-46): the tests/cg_smoother_test.jl iteration through the device path"""
     o = oracle
-    n = 16
+    for n, p in ((16, 4), (333, 4), (200, 1), (150, 7)):
+        _schwarz_case(o, mg, n, p)
+
+
+def _schwarz_case(o, mg, n, p):
     mesh = o.create_uniform_mesh(n, 0.0, 1.0)
     ue = lambda x: -0.5 * x**2 + x
     bd = o.set_boundary(mesh, 0.0, 1.0, [('dir', ue(0.0)), ('dir', ue(1.0))])
-    cg = o.CgMesh(mesh, 4)
+    cg = o.CgMesh(mesh, p)
     A, b = o.cg_stiffness_and_rhs(cg, mesh, lambda x: 1.0, bd)
     u0 = o.splitmix_normal(A.shape[0], 2)
     for kind, alpha in (('jac', 0.5), ('addSchwarz', 0.5), ('hybridSchwarz', 1.0)):
         So, Sg = o.cg_smoother(cg, A, kind), mg.cg_smoother(cg, A, kind)
+        assert Sg.structured            # the element chain was recognised: fused chain kernel
         ref = u0
         for _ in range(5):
             ref = ref + o.apply_smoother(So, b - o.csc_matvec(A, ref), alpha=alpha)
         assert rel(mg.smooth(Sg.A, Sg, u0, b, alpha, 5), ref) < TOL, kind
+        assert rel(mg.apply_smoother(Sg, b, alpha), o.apply_smoother(So, b, alpha=alpha)) < TOL     # generic apply kernel
+        if n > 16:
+            continue
         xo, ito, reso, _ = o.iterative_smoother_solve(A, So, np.zeros(len(b)), b, maxiter=40, alpha=alpha)
         xg, itg, resg, _ = mg.iterative_smoother_solve(A, Sg, np.zeros(len(b)), b, maxiter=40, alpha=alpha)
         assert itg == ito and rel(xg, xo) < 1e-10 and np.allclose(resg, reso, rtol=1e-8)
