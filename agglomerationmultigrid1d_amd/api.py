@@ -372,7 +372,8 @@ class BlockGaussSeidel(_BlockSmoother):
     """EXTENSION: red-black block Gauss-Seidel on a block-tridiagonal operator (C ABI kind 2 of
     aggmg_blockjacobi_setup).  The reference has no Gauss-Seidel smoother (SURVEY.md D1);
     BASELINE.json names one, so it is offered and checked against the oracle's restatement
-    (BlockGaussSeidelRB), not against the reference.  One sweep: even elements, then odd ones, each
+    (BlockGaussSeidelRB), not against the reference.  Also on the overlapping element blocks of a CG mesh
+    (cg_smoother(mesh, A, 'blockGS'): elements of one colour share no node).  One sweep: even elements, then odd ones, each
     with the newest values; V-cycles post-smooth in the reverse order.  UnsupportedError unless the
     blocks are contiguous and the operator couples an element to its direct neighbours only."""
     _kind = 2
@@ -523,6 +524,8 @@ def cg_smoother(cgMesh, A, smootherType, ctx=None):
         return AdditiveSchwarzSmoother(A, _mesh_block_inds(cgMesh), ctx)
     if smootherType == 'hybridSchwarz':
         return HybridSchwarzSmoother(A, _mesh_block_inds(cgMesh), ctx)
+    if smootherType == 'blockGS':    # extension: red-black ELEMENT Gauss-Seidel on the element chain, see BlockGaussSeidel
+        return BlockGaussSeidel(A, _mesh_block_inds(cgMesh), ctx)
     raise ArgumentError(f"cg_smoother: unknown smoother type {smootherType!r}")
 
 

@@ -239,24 +239,25 @@ extern "C" int aggmg_blockjacobi_setup(aggmg_ctx* ctx, aggmg_op* A, int64_t m, i
   // index lists -> blocks A[inds, inds] -> pivoted LU -> inverses, and the fused block-tridiagonal form where
   // the lists are contiguous and the operator fits (hybrid Schwarz never takes the fused form)
   CHECK(setup_block_smoother(ctx, sm.get(), blockinds, one_based, sm->kind == 1));
-  if (kind == 2) {
-    // two colours order a sweep only when elements couple to their direct neighbours alone
-    if (!sm->btd) {  // reachable with ordinary input; sm's destructor releases what was allocated
-      return fail(ctx, AGGMG_ERR_UNSUPPORTED,
-                  "aggmg_blockjacobi_setup: red-black block Gauss-Seidel needs contiguous blocks and a "
-                  "block-tridiagonal operator");
-    }
-    sm->gs = true;
-  }
   // overlapping element blocks of a CG mesh (cg_smoother :addSchwarz / :hybridSchwarz): the lists are the
-  // element chain -- the sweeps then run in the fused chain kernel (apply_smoother keeps the generic kernel)
-  if (kind != 2 && !sm->btd && m >= 2 && m <= 9 && nb >= 1 && A->m == nb * (m - 1) + 1) {
+  // element chain -- the sweeps then run in the fused chain kernel (apply_smoother keeps the generic kernel);
+  // kind 2 on such lists: red-black ELEMENT Gauss-Seidel (extension), fused chain kernel only
+  if (!sm->btd && m >= 2 && m <= 9 && nb >= 1 && A->m == nb * (m - 1) + 1) {
     CHECK(cgt_build(ctx, sm.get(), blockinds, m, nb, one_based));
-    if (sm->cgt) CHECK(cgt_attach_schwarz(ctx, sm.get(), kind == 1 ? 2 : 1));
+    if (sm->cgt) CHECK(cgt_attach_schwarz(ctx, sm.get(), kind == 2 ? 3 : (kind == 1 ? 2 : 1)));
     if (sm->cgt && !sm->cgt->sw) {  // (not attached: no point-Jacobi chain for a block smoother)
       sm->cgt.reset();
       A->cgt.reset();
     }
+  }
+  if (kind == 2) {
+    // two colours order a sweep only when elements couple to their direct neighbours alone
+    if (!sm->btd && !sm->cgt) {  // reachable with ordinary input; sm's destructor releases what was allocated
+      return fail(ctx, AGGMG_ERR_UNSUPPORTED,
+                  "aggmg_blockjacobi_setup: red-black block Gauss-Seidel needs contiguous blocks and a "
+                  "block-tridiagonal operator, or the element chain of a CG mesh");
+    }
+    sm->gs = true;
   }
   *out = sm.release();
   return AGGMG_OK;
@@ -1350,7 +1351,7 @@ extern "C" int aggmg_vcycles_dev(aggmg_ctx* ctx, aggmg_hier* h, const double* x0
   Level& l0 = h->lv[0];
   const bool fusable = n >= 2 && l0.S && l0.S->btd && l0.S->A == l0.A && l0.tb && (l0.tb->ld || h->restriction == AGGMG_RESTRICT_EXPLICIT) &&
                        btd_fits(*l0.S, nPre + nPost, 1) && !l0.S->gs;
-  if (n >= 2 && l0.cgt_fused && ncycles > 1) {
+  if (n >= 2 && l0.cgt_fused && ncycles > 1 && l0.S->cgt->sw != 3) {
     // CG chain fine level: the same cross-cycle fusion with the chain kernel
     h->last_coarse_ms = 0.0;
     auto rest = [&]() -> int {  // levels 1.. of one cycle (their right-hand side is in place)

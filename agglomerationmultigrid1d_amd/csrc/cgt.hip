@@ -48,8 +48,9 @@ int cgt_tile_blocks(int m) {
 }
 
 // sweeps fused into one launch: every sweep costs one block of halo per side (element Schwarz sweeps: two)
+static int cgt_halo_per_sweep(int sw) { return sw == 3 ? 4 : (sw ? 2 : 1); }
 static int cgt_max_sweeps(int m, int sw = 0) {
-  return std::max(1, std::min(8, cgt_tile_blocks(m) / (sw ? 16 : 8)));
+  return std::max(1, std::min(8, cgt_tile_blocks(m) / (8 * cgt_halo_per_sweep(sw))));
 }
 
 template <int M>
@@ -59,7 +60,9 @@ static int cgt_launch_t(aggmg_ctx* ctx, CgtArgs a, int sw) {
   // halo: one block per sweep and side (element Schwarz: the update of a block reads the residual of its two
   // neighbours, i.e. the iterate two blocks away); the residual needs one more valid neighbour on both sides,
   // the restriction one more block of residual on the left (chain) or on the right (agglomerating)
-  int hl = a.nsweeps * (sw ? 2 : 1), hr = hl;
+  // (red-black element Gauss-Seidel: two such half-sweeps per sweep)
+  int hl = a.nsweeps * cgt_halo_per_sweep(sw), hr = hl;
+  if (sw == 3 && a.gs == 0) a.gs = 1;
   if (a.do_residual) {
     hl += 1 + (a.tout.type == kTrChain ? 1 : 0);
     hr += 1 + (a.tout.type == kTrAgg ? 1 : 0);
@@ -79,6 +82,8 @@ static int cgt_launch_t(aggmg_ctx* ctx, CgtArgs a, int sw) {
     hipLaunchKernelGGL((cgt_fused_kernel<M, T::NS, T::NT, 1>), dim3((unsigned)ntiles), dim3(T::NT), lds, ctx->stream, a);
   else if (sw == 2)
     hipLaunchKernelGGL((cgt_fused_kernel<M, T::NS, T::NT, 2>), dim3((unsigned)ntiles), dim3(T::NT), lds, ctx->stream, a);
+  else if (sw == 3)
+    hipLaunchKernelGGL((cgt_fused_kernel<M, T::NS, T::NT, 3>), dim3((unsigned)ntiles), dim3(T::NT), lds, ctx->stream, a);
   else
     hipLaunchKernelGGL((cgt_fused_kernel<M, T::NS, T::NT, 0>), dim3((unsigned)ntiles), dim3(T::NT), lds, ctx->stream, a);
   HIPCHK(hipGetLastError());
@@ -132,6 +137,7 @@ struct CgtChain {
   double* dst = nullptr;
   bool dst_ext = false;
   double *t0 = nullptr, *t1 = nullptr;  // block-ordered temporaries (needed when the sweeps do not fit one launch)
+  int gs = 0;  // red-black element Gauss-Seidel: colour order of every sweep (1 forward, 2 reverse)
 };
 
 static int cgt_run(aggmg_ctx* ctx, const CgtDev& g, const CgtChain& c, double alpha, int nsweeps, const CgtArgs& first,
@@ -146,6 +152,7 @@ static int cgt_run(aggmg_ctx* ctx, const CgtDev& g, const CgtChain& c, double al
   for (int q = 0; q < nl; ++q) {
     CgtArgs a = cgt_args(g);
     a.alpha = alpha;
+    a.gs = c.gs;
     a.nsweeps = std::min(left, smax);
     left -= a.nsweeps;
     a.u_in = src;
@@ -226,6 +233,7 @@ int cgt_down(aggmg_ctx* ctx, aggmg_hier* h, int k, const double* uin, const doub
   ch.dst = l.u[0];
   ch.t0 = l.u[1];
   ch.t1 = l.tmp;
+  ch.gs = 1;  // pre-smoothing: even elements, then odd ones
   CgtArgs none, last;
   std::memset(&none, 0, sizeof(none));
   std::memset(&last, 0, sizeof(last));
@@ -252,6 +260,7 @@ int cgt_up(aggmg_ctx* ctx, aggmg_hier* h, int k, const double* rhs, int nPost, d
   // launch 0 consumes the source and writes tmp; launch 1 may then overwrite the source, and so on
   ch.t0 = l.tmp;
   ch.t1 = const_cast<double*>(ch.src);
+  ch.gs = 2;  // post-smoothing in the reverse colour order: the cycle stays symmetric
   CgtArgs first, none;
   std::memset(&first, 0, sizeof(first));
   std::memset(&none, 0, sizeof(none));

@@ -72,6 +72,7 @@ struct CgtArgs {
   int owned, halo_left;
   int tile_split;
   int64_t tile_skip;
+  int gs;  // SW == 3: colour order of a sweep, 1 = even elements then odd ones, 2 = the reverse (post-smoothing)
 };
 
 __device__ __forceinline__ int64_t cgt_tile(const CgtArgs& a) {
@@ -85,6 +86,10 @@ __device__ __forceinline__ int64_t cgt_tile(const CgtArgs& a) {
 // contribution of the element on its left first, then its own element's (the reference's loop order);
 // count = 2 on interior vertices, 1 elsewhere.  Two LDS phases per sweep (residual, then the element
 // solves on it) and two blocks of halo per sweep and side.
+// SW = 3 (EXTENSION, no reference counterpart -- SURVEY D1; BASELINE.json names a block-GS smoother for the
+// CG-fine hierarchy of config 5): red-black element Gauss-Seidel.  A sweep is two half-sweeps, one per element
+// colour (elements of one colour share no node): r = b - A u, then u[nodes_e] += alpha (A_e \ r[nodes_e]) for
+// every element of the colour; a.gs gives the colour order.  Four blocks of halo per sweep and side.
 template <int M, int NS, int NT, int SW = 0>
 __global__ __launch_bounds__(NT) void cgt_fused_kernel(CgtArgs a) {
   // GRP: a block's rows sit in M = 2^k adjacent lanes; lane i keeps entry i of the block's
@@ -228,8 +233,9 @@ __global__ __launch_bounds__(NT) void cgt_fused_kernel(CgtArgs a) {
   // ---- sweeps: u <- u + alpha * ((b - A u) / diag)   (LDS ping-pong) ------------------------------
   double* cur = buf0;
   double* nxt = buf1;
-  for (int sw = 0; sw < a.nsweeps; ++sw) {
+  for (int sw = 0; sw < (SW == 3 ? 2 * a.nsweeps : a.nsweeps); ++sw) {
     if (SW) {
+      const int colour = (SW == 3) ? ((a.gs == 2) ? 1 - (sw & 1) : (sw & 1)) : 0;
       // phase A: the residual of every row of the tile into LDS
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
@@ -246,18 +252,20 @@ __global__ __launch_bounds__(NT) void cgt_fused_kernel(CgtArgs a) {
         const int x = s * EPS + le;
         if (active) {
           const double* rx = rbuf + x * M;
+          const int64_t e = e0 + x;
           double y = 0.0;
 #pragma unroll
           for (int j = 0; j < M; ++j) y += zr[s][j] * rx[j];
           y += zr[s][M] * rx[M];  // the element's right vertex = first row of the next block
+          if (SW == 3 && ((e & 1) != colour)) y = 0.0;  // not this element's half-sweep
           if (i == 0) {
             double yl = 0.0;
 #pragma unroll
             for (int j = 0; j < M; ++j) yl += zl[s][j] * rx[j - M];
             yl += zl[s][M] * rx[0];
+            if (SW == 3 && (((e - 1) & 1) != colour)) yl = 0.0;
             y = yl + y;             // element e - 1 reaches the vertex before element e does
             if (SW == 2) {
-              const int64_t e = e0 + x;
               if (e > 0 && e < ne - 1) y = y / 2.0;  // mCountingMatrix: two elements share an interior vertex
             }
           }

@@ -115,10 +115,13 @@ def test_cycle_is_symmetric_and_contracts_faster_than_block_jacobi(oracle, mg):
 
 
 def test_unsupported_operators_are_refused(oracle, mg):
-    """two colours need contiguous blocks and element-to-neighbour coupling only"""
+    """two colours need contiguous blocks and element-to-neighbour coupling only -- or the element chain of a CG
+    mesh (tests/test_gpu_chain.py); overlapping blocks that are no such chain are refused"""
     o = oracle
     Hc, _ = o.build_cg_hierarchy(16, ps=(2, 1), nDG=1)
     A, cgm = Hc.mStiffness[0], Hc.mMeshes[0]
     _, inds = o._element_blocks(cgm, A)          # overlapping vertex-sharing element blocks
+    assert mg.BlockGaussSeidel(mg.DeviceOperator(A), inds).structured      # in mesh order: the chain form
+    shuffled = inds[:, np.random.default_rng(0).permutation(inds.shape[1])]
     with pytest.raises(mg.UnsupportedError):
-        mg.BlockGaussSeidel(mg.DeviceOperator(A), inds)
+        mg.BlockGaussSeidel(mg.DeviceOperator(A), shuffled)

@@ -254,3 +254,40 @@ def test_vcycles_loop_fuses_across_cycles_bitwise(oracle, mg):
         out = ctx.alloc(N)
         H.vcycles_dev(ctx.to_device(x0), db, out, ncyc, nPre, nPost, 0.6)
         assert np.array_equal(out.download(), ref), (nPre, nPost, ncyc)
+
+
+@pytest.mark.parametrize("n,ps", [(6, (4, 2, 1)), (64, (4, 2, 1)), (700, (4, 2, 1)), (301, (8, 4)), (500, (1,))])
+def test_red_black_element_gauss_seidel_on_cg_levels(oracle, mg, n, ps):
+    """EXTENSION (the reference has no Gauss-Seidel smoother; BASELINE.json names a block-GS smoother for the
+    CG-fine hierarchy of config 5): red-black ELEMENT Gauss-Seidel on every CG level -- even elements, then odd ones,
+    post-smoothing in the reverse order -- in the fused chain kernel, against the oracle's own restatement
+    (BlockGaussSeidelRB on the element blocks): no reference parity claim"""
+    o = oracle
+    Ho, b = o.build_cg_hierarchy(n, ps=ps, nDG=1, pDG=0)
+    for k in range(len(ps)):
+        Ho.mSmoothers[k] = o.BlockGaussSeidelRB(*o._element_blocks(Ho.mMeshes[k], Ho.mStiffness[k]))
+    kinds = ['fused_chain'] * len(ps) + ['coarsest']
+    H = check_vcycle(o, mg, Ho, b, alpha=1.0, it_tol=1e-8, kinds=kinds)
+    N = len(b)
+    check_vcycle(o, mg, Ho, o.splitmix_normal(N, 1), x0=o.splitmix_normal(N, 0), alpha=0.8, it_tol=1e-8)
+    check_vcycle(o, mg, Ho, b, nPre=1, nPost=2, alpha=1.0, it_tol=1e-8)
+    check_vcycle(o, mg, Ho, b, nPre=5, nPost=4, alpha=1.0, it_tol=1e-7)       # several launches per smoothing step
+    # stand-alone sweeps and the smoother factory
+    A, cg = Ho.mStiffness[0], Ho.mMeshes[0]
+    Sg = mg.cg_smoother(cg, A, 'blockGS')
+    assert Sg.structured
+    u = o.splitmix_normal(N, 4)
+    ref = u
+    for _ in range(3):
+        ref = Ho.mSmoothers[0].sweep(A, ref, b, 0.9)
+    assert rel(mg.smooth(Sg.A, Sg, u, b, 0.9, 3), ref) < TOL
+    # the multi-cycle entry point equals separate cycles (no cross-cycle fusion for this smoother)
+    ctx = H.ctx
+    db = ctx.to_device(b)
+    xa, xb = ctx.to_device(np.zeros(N)), ctx.alloc(N)
+    for _ in range(3):
+        H.vcycle_dev(xa, db, xb, 2, 2, 1.0)
+        xa, xb = xb, xa
+    out = ctx.alloc(N)
+    H.vcycles_dev(ctx.to_device(np.zeros(N)), db, out, 3, 2, 2, 1.0)
+    assert np.array_equal(out.download(), xa.download())
