@@ -1030,13 +1030,20 @@ class UniformCgDgHierarchy:
         return out
 
 
-def build_device_cg_hierarchy(U, ctx=None, keep_host=False, chain=True):
-    """UniformCgDgHierarchy -> product MeshHierarchy (CG levels :jac, src/mesh_heirarchy.jl:51,58)"""
+def build_device_cg_hierarchy(U, ctx=None, keep_host=False, chain=True, smoother="jac"):
+    """UniformCgDgHierarchy -> product MeshHierarchy (CG levels :jac, src/mesh_heirarchy.jl:51,58; smoother =
+    'addSchwarz' / 'hybridSchwarz': cg_smoother's element Schwarz smoothers; 'blockGS': the labelled red-black element
+    Gauss-Seidel extension)"""
     from . import _lib
-    from .api import DeviceOperator, JacobiSmoother, MeshHierarchy
+    from .api import (AdditiveSchwarzSmoother, BlockGaussSeidel, DeviceOperator, HybridSchwarzSmoother, JacobiSmoother,
+                      MeshHierarchy)
     ops = [DeviceOperator(A, _lib.OP_STIFFNESS, ctx) for A in U.A]
     # cg_smoother(cgMesh, A, :jac) with the mesh's element node lists (chain form, fused kernel);
     # chain=False is the operators-only route through the generic CSR kernels
-    sms = [JacobiSmoother(ops[k], ctx, U.element_nodes(k) if chain else None) for k in range(U.nlevels - 1)]
+    if smoother == "jac":
+        sms = [JacobiSmoother(ops[k], ctx, U.element_nodes(k) if chain else None) for k in range(U.nlevels - 1)]
+    else:
+        cls = {"addSchwarz": AdditiveSchwarzSmoother, "hybridSchwarz": HybridSchwarzSmoother, "blockGS": BlockGaussSeidel}[smoother]
+        sms = [cls(ops[k], U.element_nodes(k), ctx) for k in range(U.nlevels - 1)]
     Ls = [DeviceOperator(L, _lib.OP_TRANSFER, ctx) for L in U.L]
     return MeshHierarchy(None, ops, sms, Ls, ctx=ctx, keep_host=keep_host)
