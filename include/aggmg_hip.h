@@ -103,8 +103,14 @@ int aggmg_op_release_host(aggmg_ctx* ctx, aggmg_op* op);
  *           (SURVEY.md D1): one sweep = for colour in (even elements, odd elements):
  *           u_e += alpha B_e^{-1} (b - A u)_e on that colour with the newest u.  V-cycles pre-smooth
  *           in this order and post-smooth in the reverse one.  Needs contiguous blocks and a block-
- *           tridiagonal operator (AGGMG_ERR_UNSUPPORTED otherwise); aggmg_smoother_apply on such a
- *           smoother applies its block-diagonal part like kind 0. */
+ *           tridiagonal operator, or the element lists of a CG mesh (below): elements of one colour share
+ *           no node (AGGMG_ERR_UNSUPPORTED otherwise); aggmg_smoother_apply on such a smoother applies
+ *           its block-diagonal part like kind 0.
+ * When blockinds are the element node lists of a CG mesh in mesh order ((p+1) x n, consecutive elements
+ * sharing exactly one node, local order [left vertex, right vertex, interior nodes], 2 <= p+1 <= 9) the
+ * SWEEPS with the smoother (aggmg_smooth*, V-cycles) run in the fused chain kernel -- the residual of a
+ * tile into LDS, then every row its row of A_e \ r_e from the element inverse kept in registers;
+ * aggmg_smoother_apply keeps the generic batched-block kernel.  Same results to round-off. */
 int aggmg_blockjacobi_setup(aggmg_ctx* ctx, aggmg_op* A, int64_t m, int64_t nb,
                             const int64_t* blockinds, int one_based, int kind,
                             aggmg_smoother** out);
