@@ -25,38 +25,58 @@
 #ifndef AGGMG_CGT_NS4
 #define AGGMG_CGT_NS4 1
 #endif
-template <int M>
+// K: 0 point Jacobi, 1 element Schwarz, 2 red-black element Gauss-Seidel.  The Gauss-Seidel sweeps cost four blocks
+// of halo each: two slabs per thread there (config-5 hierarchy at 2^24: 6.8 instead of 8.9 ms per V(3,3) cycle); the
+// Schwarz sweeps (two blocks of halo) are faster with one (31 vs 34 us per sweep at 2^20 elements, p = 4)
+#ifndef AGGMG_CGT_NS_GS
+#define AGGMG_CGT_NS_GS 2
+#endif
+template <int M, int K = 0>
 struct CgtTile {
   static constexpr int NT = kThreads;
-  static constexpr int NS = (M == 1) ? AGGMG_CGT_NS1 : (M == 2) ? AGGMG_CGT_NS2 : (M <= 4) ? AGGMG_CGT_NS4 : 3;
+  static constexpr int NS0 = (M == 1) ? AGGMG_CGT_NS1 : (M == 2) ? AGGMG_CGT_NS2 : (M <= 4) ? AGGMG_CGT_NS4 : 3;
+  static constexpr int NS = (K == 2) ? (NS0 < AGGMG_CGT_NS_GS ? AGGMG_CGT_NS_GS : NS0) : NS0;
   static constexpr int EPS = NT / M;
   static constexpr int TE = EPS * NS;
 };
 
-int cgt_tile_blocks(int m) {
+template <int SW>
+static int cgt_tile_blocks_t(int m) {
   switch (m) {
-    case 1: return CgtTile<1>::TE;
-    case 2: return CgtTile<2>::TE;
-    case 3: return CgtTile<3>::TE;
-    case 4: return CgtTile<4>::TE;
-    case 5: return CgtTile<5>::TE;
-    case 6: return CgtTile<6>::TE;
-    case 7: return CgtTile<7>::TE;
-    case 8: return CgtTile<8>::TE;
+    case 1: return CgtTile<1, SW>::TE;
+    case 2: return CgtTile<2, SW>::TE;
+    case 3: return CgtTile<3, SW>::TE;
+    case 4: return CgtTile<4, SW>::TE;
+    case 5: return CgtTile<5, SW>::TE;
+    case 6: return CgtTile<6, SW>::TE;
+    case 7: return CgtTile<7, SW>::TE;
+    case 8: return CgtTile<8, SW>::TE;
   }
   return 0;
 }
+int cgt_tile_blocks(int m) { return cgt_tile_blocks_t<0>(m); }
 
-// sweeps fused into one launch: every sweep costs one block of halo per side (element Schwarz sweeps: two)
+// sweeps fused into one launch: every sweep costs one block of halo per side (element Schwarz sweeps: two,
+// red-black element Gauss-Seidel: four)
 static int cgt_halo_per_sweep(int sw) { return sw == 3 ? 4 : (sw ? 2 : 1); }
 static int cgt_max_sweeps(int m, int sw = 0) {
-  return std::max(1, std::min(8, cgt_tile_blocks(m) / (8 * cgt_halo_per_sweep(sw))));
+  const int te = sw == 3 ? cgt_tile_blocks_t<2>(m) : cgt_tile_blocks_t<0>(m);
+  return std::max(1, std::min(8, te / (8 * cgt_halo_per_sweep(sw))));
 }
+
+template <int M, int K>
+static int cgt_launch_tt(aggmg_ctx* ctx, CgtArgs a, int sw);
 
 template <int M>
 static int cgt_launch_t(aggmg_ctx* ctx, CgtArgs a, int sw) {
-  using T = CgtTile<M>;
   if (a.nsweeps == 0) sw = 0;
+  if (sw == 3) return cgt_launch_tt<M, 2>(ctx, a, sw);
+  return sw ? cgt_launch_tt<M, 1>(ctx, a, sw) : cgt_launch_tt<M, 0>(ctx, a, sw);
+}
+
+template <int M, int K>
+static int cgt_launch_tt(aggmg_ctx* ctx, CgtArgs a, int sw) {
+  using T = CgtTile<M, K>;
   // halo: one block per sweep and side (element Schwarz: the update of a block reads the residual of its two
   // neighbours, i.e. the iterate two blocks away); the residual needs one more valid neighbour on both sides,
   // the restriction one more block of residual on the left (chain) or on the right (agglomerating)
@@ -78,14 +98,16 @@ static int cgt_launch_t(aggmg_ctx* ctx, CgtArgs a, int sw) {
   if (ntiles == 0) return AGGMG_OK;
   if (ntiles >= ((int64_t)1 << 31)) return fail(ctx, AGGMG_ERR_UNSUPPORTED, "grid too large");
   const size_t lds = (size_t)(sw ? 3 : 2) * (T::TE + 2) * M * sizeof(double);
-  if (sw == 1)
-    hipLaunchKernelGGL((cgt_fused_kernel<M, T::NS, T::NT, 1>), dim3((unsigned)ntiles), dim3(T::NT), lds, ctx->stream, a);
-  else if (sw == 2)
-    hipLaunchKernelGGL((cgt_fused_kernel<M, T::NS, T::NT, 2>), dim3((unsigned)ntiles), dim3(T::NT), lds, ctx->stream, a);
-  else if (sw == 3)
+  if constexpr (K == 2) {
     hipLaunchKernelGGL((cgt_fused_kernel<M, T::NS, T::NT, 3>), dim3((unsigned)ntiles), dim3(T::NT), lds, ctx->stream, a);
-  else
+  } else if constexpr (K == 1) {
+    if (sw == 1)
+      hipLaunchKernelGGL((cgt_fused_kernel<M, T::NS, T::NT, 1>), dim3((unsigned)ntiles), dim3(T::NT), lds, ctx->stream, a);
+    else
+      hipLaunchKernelGGL((cgt_fused_kernel<M, T::NS, T::NT, 2>), dim3((unsigned)ntiles), dim3(T::NT), lds, ctx->stream, a);
+  } else {
     hipLaunchKernelGGL((cgt_fused_kernel<M, T::NS, T::NT, 0>), dim3((unsigned)ntiles), dim3(T::NT), lds, ctx->stream, a);
+  }
   HIPCHK(hipGetLastError());
   return AGGMG_OK;
 }
