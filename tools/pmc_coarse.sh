@@ -3,7 +3,9 @@
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 rm -rf $R/gpurun_out/pmc_coarse
-for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD" "SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE" "SQ_INSTS_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES"; do
+SETS=${AGGMG_PMC_SETS:-"SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD|SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE|SQ_INSTS_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES"}
+IFS="|" read -ra ALL <<< "$SETS"
+for set in "${ALL[@]}"; do
   tag=$(echo $set | tr ' ' '_' | cut -c1-40)
   rocprofv3 --pmc $set --output-format csv -d $R/gpurun_out/pmc_coarse/$tag -o run -- python3 $R/tools/exp_coarse.py --cold --cases "${1:-20:2}" --steps 6 > $R/gpurun_out/pmc_coarse_$tag.log 2>&1 || echo "set failed: $set"
 done
