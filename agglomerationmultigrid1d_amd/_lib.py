@@ -92,6 +92,7 @@ SYMBOLS = {
     "aggmg_op_transpose": (c_int, [_P, _P, c_int, POINTER(_P)]),
     "aggmg_op_download_csc": (c_int, [_P, _P, POINTER(c_int32), POINTER(c_int32), _PD]),
     "aggmg_smoother_download_blocks": (c_int, [_P, _P, _PD]),
+    "aggmg_debug_scan_counts": (c_int, [_P, POINTER(c_int32), c_int64, POINTER(c_int64)]),
     "aggmg_blockjacobi_setup": (c_int, [_P, _P, c_int64, c_int64, POINTER(c_int64), c_int, c_int,
                                         POINTER(_P)]),
     "aggmg_blockdiag_setup": (c_int, [_P, c_int64, c_int64, _PD, c_int, POINTER(_P)]),
@@ -126,6 +127,7 @@ SYMBOLS = {
     "aggmg_coarse_chunk_backward_dev": (c_int, [_P, _P, _P, c_int64, c_int64, _P, _P]),
     "aggmg_hier_level_kind": (c_int, [_P, _P, c_int, POINTER(c_int)]),
     "aggmg_hier_coarse_info": (c_int, [_P, _P, POINTER(c_int), POINTER(c_int), POINTER(c_double)]),
+    "aggmg_hier_coarse_probe": (c_int, [_P, _P, POINTER(c_double)]),
     "aggmg_hier_last_coarse_ms": (c_int, [_P, _P, POINTER(c_double)]),
     "aggmg_copy_segments_dev": (c_int, [_P, c_int, POINTER(_P), POINTER(_P), POINTER(c_int64), POINTER(c_int64),
                                         POINTER(c_int64), POINTER(c_int64)]),
@@ -133,6 +135,7 @@ SYMBOLS = {
                                   POINTER(c_int64), POINTER(c_int64), POINTER(c_int32), POINTER(c_int32), POINTER(_P)]),
     "aggmg_dist_free": (c_int, [_P, _P]),
     "aggmg_rccl_unique_id": (c_int, [_P, _P, c_int]),
+    "aggmg_rccl_available": (c_int, [c_char_p, c_int]),
     "aggmg_dist_init_rccl": (c_int, [_P, _P, _P, c_int, POINTER(c_int)]),
     "aggmg_dist_set_allgather": (c_int, [_P, _P, _P, _P]),
     "aggmg_dist_set_loopback": (c_int, [_P, _P]),

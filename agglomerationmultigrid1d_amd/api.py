@@ -783,11 +783,15 @@ class MeshHierarchy:
         return r.value, s_.value, n.value
 
     def coarse_info(self):
-        """-> dict(on_device, block_size, cond_est) of the coarsest direct solver"""
+        """-> dict(on_device, block_size, cond_est, probe_backward_error) of the coarsest direct solver;
+        probe_backward_error: ||d - A x|| / ||d|| of the probe solve that aggmg_hier_create accepts (< 1e-10) or rejects the
+        device factorisation on (-1: none attempted)"""
         a, b, c = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_double(0.0)
         self.ctx.check(self.ctx.lib.aggmg_hier_coarse_info(self.ctx.handle, self.handle, ctypes.byref(a),
                                                            ctypes.byref(b), ctypes.byref(c)))
-        return dict(on_device=bool(a.value), block_size=b.value, cond_est=c.value)
+        e = ctypes.c_double(0.0)
+        self.ctx.check(self.ctx.lib.aggmg_hier_coarse_probe(self.ctx.handle, self.handle, ctypes.byref(e)))
+        return dict(on_device=bool(a.value), block_size=b.value, cond_est=c.value, probe_backward_error=e.value)
 
     def last_coarse_ms(self):
         ms = ctypes.c_double(0.0)

@@ -1144,6 +1144,26 @@ extern "C" int aggmg_hier_create(aggmg_ctx* ctx, int nlevels, aggmg_op* const* s
       int hint = 0;
       if (nlevels >= 2 && h->lv[nlevels - 2].tb) hint = h->lv[nlevels - 2].tb->mc;
       CHECK(setup_cr(ctx, Ac, hint, &h->cr));
+      if (h->cr.valid) {
+        // The cyclic reduction pivots inside the m x m blocks only (the reference's UMFPACK pivots across the whole
+        // matrix, src/solvers.jl:39): accept the factorisation on evidence, not on the per-block condition monitor
+        // alone -- solve one probe system and keep it only if the backward error is at round-off level.
+        Level& lc = h->lv[nlevels - 1];
+        const int64_t Nc = lc.N;
+        double nd = 0.0, nr = 0.0;
+        CHECK(setup_probe_vector(ctx, Nc, lc.u[1]));
+        HIPCHK(hipMemsetAsync(lc.rhs, 0, (size_t)Nc * sizeof(double), ctx->stream));
+        CHECK(setup_csc_scatter(ctx, Ac, lc.u[1], 1.0, lc.rhs));                  // d = A w
+        CHECK(cr_solve(ctx, h->cr, lc.rhs, lc.u[0], nlevels - 1));                // x = CR(d)
+        HIPCHK(hipMemcpyAsync(lc.tmp, lc.rhs, (size_t)Nc * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+        CHECK(setup_csc_scatter(ctx, Ac, lc.u[0], -1.0, lc.tmp));                 // r = d - A x
+        CHECK(aggmg_norm2_dev(ctx, lc.rhs, Nc, &nd));
+        CHECK(aggmg_norm2_dev(ctx, lc.tmp, Nc, &nr));
+        h->cr_probe_backward_error = nd > 0.0 ? nr / nd : 0.0;
+        for (double* p : {lc.u[0], lc.u[1], lc.rhs, lc.tmp}) HIPCHK(hipMemsetAsync(p, 0, (size_t)lc.Nalloc * sizeof(double), ctx->stream));
+        const double tol = 1e-10;
+        if (!(h->cr_probe_backward_error < tol)) cr_discard(&h->cr);              // NaN included
+      }
       if (!h->cr.valid && coarse_mode == AGGMG_COARSE_DEVICE_CR)
         return fail(ctx, AGGMG_ERR_UNSUPPORTED,
                     "aggmg_hier_create: coarsest operator is not block-tridiagonal with well-conditioned pivot "
@@ -1542,6 +1562,12 @@ extern "C" int aggmg_hier_level_kind(aggmg_ctx* ctx, const aggmg_hier* h, int le
     *kind = AGGMG_LEVEL_FUSED_CHAIN;
   else if (l.S && l.S->btd && l.S->A == l.A && l.tb)
     *kind = AGGMG_LEVEL_FUSED_BTD;
+  return AGGMG_OK;
+}
+
+extern "C" int aggmg_hier_coarse_probe(aggmg_ctx* ctx, const aggmg_hier* h, double* backward_error) {
+  if (!ctx || !h || !backward_error) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_hier_coarse_probe: NULL argument");
+  *backward_error = h->cr_probe_backward_error;
   return AGGMG_OK;
 }
 

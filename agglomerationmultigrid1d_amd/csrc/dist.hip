@@ -37,14 +37,19 @@ RcclApi* rccl_api(std::string* err) {
   static std::string why;
   if (!tried) {
     tried = true;
-    // the copy already in the process (torch's) if there is one, the ROCm one otherwise
-    for (const char* name : {"librccl.so.1", "librccl.so"}) {
+    // the copy already in the process (torch's) if there is one, the ROCm one otherwise; AGGMG_RCCL_LIB names
+    // another file (tests use it to take the "not loadable" route)
+    const char* forced = getenv("AGGMG_RCCL_LIB");
+    std::string last;
+    for (const char* name : {forced ? forced : "librccl.so.1", forced ? forced : "librccl.so"}) {
       api.lib = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
       if (!api.lib) api.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
       if (api.lib) break;
+      const char* e = dlerror();   // read ONCE: the call clears the message
+      last = e ? e : (std::string(name) + " not found");
     }
     if (!api.lib) {
-      why = std::string("RCCL not loadable: ") + (dlerror() ? dlerror() : "librccl.so.1 not found");
+      why = std::string("RCCL not loadable: ") + last;
     } else {
       auto sym = [&](const char* n) -> void* {
         void* p = dlsym(api.lib, n);
@@ -386,6 +391,17 @@ extern "C" int aggmg_dist_set_loopback(aggmg_ctx* ctx, aggmg_dist* d) {
   if (!ctx || !d) return AGGMG_ERR_ARGUMENT;
   d->backend = 3;
   return AGGMG_OK;
+}
+
+extern "C" int aggmg_rccl_available(char* why_out, int nbytes) {
+  std::string why;
+  RcclApi* a = rccl_api(&why);
+  if (why_out && nbytes > 0) {
+    const size_t n = std::min<size_t>(why.size(), (size_t)nbytes - 1);
+    std::memcpy(why_out, why.data(), n);
+    why_out[n] = 0;
+  }
+  return a ? AGGMG_OK : AGGMG_ERR_UNSUPPORTED;
 }
 
 extern "C" int aggmg_rccl_unique_id(aggmg_ctx* ctx, void* id_out, int nbytes) {

@@ -254,6 +254,7 @@ struct aggmg_hier {
   int restriction = 0;  // AGGMG_RESTRICT_EXPLICIT (default) / AGGMG_RESTRICT_PRECONDITIONED
   std::vector<double> h_coarse;
   double last_coarse_ms = 0.0;
+  double cr_probe_backward_error = -1.0;  // ||d - A CR(d)|| / ||d|| of the set-up probe (-1: no device factorisation tried)
   // owns every device allocation of its levels: an early return of aggmg_hier_create releases them
   ~aggmg_hier() {
     for (auto& l : lv)
@@ -390,3 +391,6 @@ int setup_block_smoother(aggmg_ctx* ctx, aggmg_smoother* sm, const int64_t* bloc
 int setup_transfer_btd(aggmg_ctx* ctx, const aggmg_op* L, const BtdDev* Abtd, int mf, int64_t nef, int hint_mc,
                        TransferBtd* out, bool* ok);
 int setup_cr(aggmg_ctx* ctx, const aggmg_op* Ac, int hint_m, CrDev* cr);
+void cr_discard(CrDev* cr);                                                  // frees the factors, valid = false
+int setup_probe_vector(aggmg_ctx* ctx, int64_t n, double* w);                // hash-random entries in [-1, 1)
+int setup_csc_scatter(aggmg_ctx* ctx, const aggmg_op* A, const double* x, double sign, double* y);  // y += sign A x

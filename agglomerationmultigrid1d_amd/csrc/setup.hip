@@ -501,6 +501,43 @@ static void cr_release(CrDev* c) {
   *c = CrDev();
 }
 
+void cr_discard(CrDev* c) { cr_release(c); }
+
+// probe vector of the factorisation check: entries in [-1, 1) from a hash of the index (no structure a
+// tridiagonal stencil could annihilate)
+__global__ __launch_bounds__(kSetupThreads) void probe_vector_kernel(int64_t n, double* __restrict__ w) {
+  const int64_t i = (int64_t)blockIdx.x * kSetupThreads + threadIdx.x;
+  if (i >= n) return;
+  uint64_t z = (uint64_t)i * 0x9E3779B97F4A7C15ull + 0xD1B54A32D192ED03ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  w[i] = (double)(int64_t)(z >> 11) * (1.0 / 4503599627370496.0) - 1.0;
+}
+
+// y += sign * A x from the uploaded CSC arrays (column scatter, fp64 atomics): set-up checks only
+__global__ __launch_bounds__(kSetupThreads) void csc_scatter_kernel(int64_t ncols, const int32_t* __restrict__ cp,
+                                                                    const int32_t* __restrict__ rv,
+                                                                    const double* __restrict__ vv,
+                                                                    const double* __restrict__ x, double sign,
+                                                                    double* __restrict__ y) {
+  const int64_t j = (int64_t)blockIdx.x * kSetupThreads + threadIdx.x;
+  if (j >= ncols) return;
+  const double xj = sign * x[j];
+  for (int32_t p = cp[j]; p < cp[j + 1]; ++p) atomicAdd(&y[rv[p]], vv[p] * xj);
+}
+
+int setup_probe_vector(aggmg_ctx* ctx, int64_t n, double* w) {
+  LAUNCH(probe_vector_kernel, n, n, w);
+  return AGGMG_OK;
+}
+
+int setup_csc_scatter(aggmg_ctx* ctx, const aggmg_op* A, const double* x, double sign, double* y) {
+  LAUNCH(csc_scatter_kernel, A->n, A->n, (const int32_t*)A->csc.rowptr, (const int32_t*)A->csc.colind,
+         (const double*)A->csc.vals, x, sign, y);
+  return AGGMG_OK;
+}
+
 // Sets cr->valid when the operator is block-tridiagonal for some block size m <= 8 and every pivot block is
 // comfortably invertible; leaves it false otherwise (the caller then keeps the host banded solver).
 int setup_cr(aggmg_ctx* ctx, const aggmg_op* Ac, int hint_m, CrDev* cr) {

@@ -169,17 +169,34 @@ struct Tmp {
   }
 };
 
-// exclusive scan of counts[0..n) into colptr[0..n] (colptr[n] = total), total read back
-int scan_counts(aggmg_ctx* ctx, int32_t* counts_np1, int32_t* colptr, int64_t n, int64_t* total) {
+// int32 counts widened on the fly: the total of a product can pass 2^31 long before any single count does
+struct WidenCount {
+  __host__ __device__ int64_t operator()(int32_t v) const { return (int64_t)v; }
+};
+
+// exclusive scan of counts[0..n) into colptr[0..n] (colptr[n] = total).  The total is formed in 64 bits FIRST:
+// an int32 scan of a result with >= 2^31 entries wraps, and the fill kernels would then write through wrapped
+// offsets.  Returns AGGMG_ERR_UNSUPPORTED (nothing scanned) when the total does not fit int32 indices.
+int scan_counts(aggmg_ctx* ctx, int32_t* counts_np1, int32_t* colptr, int64_t n, int64_t* total, const char* who) {
+  hipcub::TransformInputIterator<int64_t, WidenCount, const int32_t*> wide(counts_np1, WidenCount());
+  Tmp sum;
+  HIPCHK(hipMalloc(&sum.p, sizeof(int64_t)));
+  size_t rbytes = 0;
+  HIPCHK(hipcub::DeviceReduce::Sum(nullptr, rbytes, wide, (int64_t*)sum.p, (int)n, ctx->stream));
+  Tmp rt;
+  HIPCHK(hipMalloc(&rt.p, std::max<size_t>(rbytes, 8)));
+  HIPCHK(hipcub::DeviceReduce::Sum(rt.p, rbytes, wide, (int64_t*)sum.p, (int)n, ctx->stream));
+  int64_t tot = 0;
+  HIPCHK(hipMemcpyAsync(&tot, sum.p, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  *total = tot;
+  if (tot >= ((int64_t)1 << 31))
+    return fail(ctx, AGGMG_ERR_UNSUPPORTED, std::string(who) + ": result has " + std::to_string(tot) + " >= 2^31 entries (int32 device indices)");
   size_t bytes = 0;
   HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, counts_np1, colptr, (int)(n + 1), ctx->stream));
   Tmp t;
   HIPCHK(hipMalloc(&t.p, std::max<size_t>(bytes, 8)));
   HIPCHK(hipcub::DeviceScan::ExclusiveSum(t.p, bytes, counts_np1, colptr, (int)(n + 1), ctx->stream));
-  int32_t tot = 0;
-  HIPCHK(hipMemcpyAsync(&tot, colptr + n, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
-  *total = tot;
   return AGGMG_OK;
 }
 
@@ -231,8 +248,7 @@ extern "C" int aggmg_bd_sp_apply(aggmg_ctx* ctx, aggmg_smoother* bd, aggmg_op* S
                              (const int32_t*)S->csc.rowptr, (const int32_t*)S->csc.colind, counts);
   HIPCHK(hipGetLastError());
   int64_t nnz = 0;
-  CHECK(scan_counts(ctx, counts, op->csc.rowptr, nc, &nnz));
-  if (nnz >= ((int64_t)1 << 31)) return fail(ctx, AGGMG_ERR_UNSUPPORTED, "aggmg_bd_sp_apply: result has >= 2^31 entries");
+  CHECK(scan_counts(ctx, counts, op->csc.rowptr, nc, &nnz, "aggmg_bd_sp_apply"));
   CHECK(alloc_entries(ctx, op.get(), nnz));
   if (nc) hipLaunchKernelGGL(bdsp_fill_kernel, dim3(grid_for(nc)), dim3(kSetupThreads), 0, ctx->stream, nc, m,
                              (const double*)bd->binv, (const int32_t*)S->csc.rowptr, (const int32_t*)S->csc.colind,
@@ -268,11 +284,11 @@ extern "C" int aggmg_sp_matmul(aggmg_ctx* ctx, aggmg_op* A, aggmg_op* B, int kin
   int herr = 0;
   HIPCHK(hipMemcpyAsync(&herr, err, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   int64_t nnz = 0;
-  CHECK(scan_counts(ctx, counts, op->csc.rowptr, nc, &nnz));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
   if (herr)
     return fail(ctx, AGGMG_ERR_UNSUPPORTED, "aggmg_sp_matmul: a result column has more than " + std::to_string(kColCap) +
                                                 " rows (the device product is meant for finite-element matrices with short columns)");
-  if (nnz >= ((int64_t)1 << 31)) return fail(ctx, AGGMG_ERR_UNSUPPORTED, "aggmg_sp_matmul: result has >= 2^31 entries");
+  CHECK(scan_counts(ctx, counts, op->csc.rowptr, nc, &nnz, "aggmg_sp_matmul"));
   CHECK(alloc_entries(ctx, op.get(), nnz));
   if (nc) hipLaunchKernelGGL((spmm_kernel<true>), dim3(grid_for(nc)), dim3(kSetupThreads), 0, ctx->stream, nc, acp, arv, av, bcp, brv,
                              bv, counts, (const int32_t*)op->csc.rowptr, op->csc.colind, op->csc.vals, err);
@@ -300,7 +316,7 @@ extern "C" int aggmg_sp_sub(aggmg_ctx* ctx, aggmg_op* A, aggmg_op* B, int kind, 
                              bv, counts, (const int32_t*)nullptr, (int32_t*)nullptr, (double*)nullptr);
   HIPCHK(hipGetLastError());
   int64_t nnz = 0;
-  CHECK(scan_counts(ctx, counts, op->csc.rowptr, nc, &nnz));
+  CHECK(scan_counts(ctx, counts, op->csc.rowptr, nc, &nnz, "aggmg_sp_sub"));
   CHECK(alloc_entries(ctx, op.get(), nnz));
   if (nc) hipLaunchKernelGGL((spsub_kernel<true>), dim3(grid_for(nc)), dim3(kSetupThreads), 0, ctx->stream, nc, acp, arv, av, bcp, brv,
                              bv, counts, (const int32_t*)op->csc.rowptr, op->csc.colind, op->csc.vals);
@@ -308,6 +324,19 @@ extern "C" int aggmg_sp_sub(aggmg_ctx* ctx, aggmg_op* A, aggmg_op* B, int kind, 
   HIPCHK(hipStreamSynchronize(ctx->stream));
   *out = op.release();
   return AGGMG_OK;
+}
+
+// Test aid: the count -> column-pointer scan of the set-up products on caller-supplied counts (host array), so that
+// the 2^31 guard can be exercised without building a 2^31-entry product.
+extern "C" int aggmg_debug_scan_counts(aggmg_ctx* ctx, const int32_t* counts_host, int64_t n, int64_t* total) {
+  if (!ctx || !counts_host || !total || n < 0 || n >= ((int64_t)1 << 31) - 1) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_debug_scan_counts: bad argument");
+  HIPCHK(hipSetDevice(ctx->device));
+  Tmp c, p;
+  HIPCHK(hipMalloc(&c.p, (size_t)(n + 1) * sizeof(int32_t)));
+  HIPCHK(hipMalloc(&p.p, (size_t)(n + 1) * sizeof(int32_t)));
+  HIPCHK(hipMemsetAsync(c.p, 0, (size_t)(n + 1) * sizeof(int32_t), ctx->stream));
+  if (n) HIPCHK(hipMemcpyAsync(c.p, counts_host, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+  return scan_counts(ctx, (int32_t*)c.p, (int32_t*)p.p, n, total, "aggmg_debug_scan_counts");
 }
 
 // the transposed operator as an operator of its own (L' of L'*X*L): its CSC arrays are the row-gather CSR of

@@ -377,6 +377,27 @@ def cg_bench(mg, ctx, args, nPre, nPost, alpha):
             "setup_s": t_gen + t_lib, "setup_generator_s": t_gen, "setup_library_s": t_lib}
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: run `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py <same arguments>` as a child
+    process.  The parent stays off the GPU (no HIP call, no package import) so nothing is exec'ed
+    from an initialised process; stdout of the child (rank 0's one JSON line) is relayed."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # dmabuf IPC: RCCL across processes needs it on this pool
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // args.gpus)))
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    sys.stdout.write(proc.stdout)
+    sys.stdout.flush()
+    raise SystemExit(proc.returncode)
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -384,9 +405,14 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     nPre = nPost = 3
     alpha = 2.0 / 3.0
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # bare `python bench.py --gpus N`: start the ranks ourselves, one process per GPU, as a CHILD
+        # torch.distributed.run (this process has not touched HIP and never will; no exec), relay rank 0's
+        # JSON line and exit with the child's code
+        return self_launch(args)
     if world != args.gpus:
-        if not (world == 1 and args.gpus == 1):
-            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run "
+                         f"--nproc-per-node {args.gpus}")
     import agglomerationmultigrid1d_amd as mg
     from agglomerationmultigrid1d_amd.uniform import UniformDgAggHierarchy, build_device_hierarchy
 

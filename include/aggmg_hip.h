@@ -168,6 +168,10 @@ int aggmg_op_transpose(aggmg_ctx* ctx, aggmg_op* A, int kind, aggmg_op** out);
  * factorize = 0 object): read-back for the parity tests of the set-up products. */
 int aggmg_op_download_csc(aggmg_ctx* ctx, const aggmg_op* op, int32_t* colptr, int32_t* rowval, double* nzval);
 int aggmg_smoother_download_blocks(aggmg_ctx* ctx, const aggmg_smoother* sm, double* out);
+/* Test aid for the size guard of the products above: runs their count -> column-pointer scan on n caller-supplied
+ * int32 counts (host array).  The total is formed in 64 bits before anything is scanned or allocated; a result of
+ * 2^31 or more entries is refused with AGGMG_ERR_UNSUPPORTED (int32 device indices), *total still set. */
+int aggmg_debug_scan_counts(aggmg_ctx* ctx, const int32_t* counts_host, int64_t n, int64_t* total);
 
 /* ---- fused hot-path operations -------------------------------------------------------------- */
 /* nsweeps x  `u += apply_smoother(S, b - A*u; alpha)`   src/solvers.jl:32-35,43-46, :199 */
@@ -284,6 +288,13 @@ int aggmg_hier_level_kind(aggmg_ctx* ctx, const aggmg_hier* h, int level, int* k
  * largest pivot-block condition estimate met while factoring (0 for the host solver). */
 int aggmg_hier_coarse_info(aggmg_ctx* ctx, const aggmg_hier* h, int* on_device, int* block_size,
                            double* cond_est);
+/* The cyclic reduction pivots inside its m x m blocks only, the reference's `A_n \ rhs_n` (UMFPACK,
+ * src/solvers.jl:39) across the whole matrix.  aggmg_hier_create therefore accepts a device factorisation on
+ * evidence: it solves one probe system d = A w (w hash-random) and keeps the factorisation only when
+ * ||d - A x|| / ||d|| < 1e-10; otherwise AGGMG_COARSE_AUTO falls back to the host banded LU with partial
+ * pivoting (AGGMG_COARSE_DEVICE_CR: AGGMG_ERR_UNSUPPORTED).  backward_error receives the probe's figure
+ * (-1 when no device factorisation was attempted). */
+int aggmg_hier_coarse_probe(aggmg_ctx* ctx, const aggmg_hier* h, double* backward_error);
 /* Milliseconds the last aggmg_vcycle* call spent in the coarsest direct solve (host path:
  * D2H + solve + H2D, measured with the host clock). */
 int aggmg_hier_last_coarse_ms(aggmg_ctx* ctx, const aggmg_hier* h, double* ms);
@@ -325,6 +336,11 @@ int aggmg_dist_free(aggmg_ctx* ctx, aggmg_dist* d);
 #define AGGMG_RCCL_ID_BYTES 128
 typedef int (*aggmg_allgather_fn)(void* user, const double* send_dev, double* recv_dev, int64_t count, void* hip_stream);
 int aggmg_rccl_unique_id(aggmg_ctx* ctx, void* id_out, int nbytes);
+/* Whether RCCL can be loaded in this process (no context, no device needed): AGGMG_OK, or AGGMG_ERR_UNSUPPORTED
+ * with the loader's message copied into why (NUL-terminated, at most nbytes; may be NULL) -- the same outcome
+ * aggmg_rccl_unique_id / aggmg_dist_init_rccl report, so that all ranks can agree on a fallback before the first
+ * collective.  The environment variable AGGMG_RCCL_LIB names another library file to load (tests). */
+int aggmg_rccl_available(char* why, int nbytes);
 int aggmg_dist_init_rccl(aggmg_ctx* ctx, aggmg_dist* d, const void* id, int nbytes, int* nranks_out);
 int aggmg_dist_set_allgather(aggmg_ctx* ctx, aggmg_dist* d, aggmg_allgather_fn fn, void* user);
 int aggmg_dist_set_loopback(aggmg_ctx* ctx, aggmg_dist* d);

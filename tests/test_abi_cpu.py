@@ -70,3 +70,62 @@ def test_header_is_plain_c(tmp_path):
                    'fn table(fn* p) {\n' + body + "\n    return p[0];\n}\n")
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
                            "-c", str(src), "-o", str(tmp_path / "abi_check.o")])
+
+
+def test_bench_bare_multi_gpu_form_starts_its_own_ranks(monkeypatch):
+    """`python bench.py --gpus N` with no launcher in the environment must start torch.distributed.run itself as
+    a child process (never exec, never initialise HIP in the parent) and pass its own arguments through."""
+    import subprocess
+    import sys
+    import bench
+    seen = {}
+
+    class Done:
+        returncode = 0
+        stdout = '{"n_gpus": 4}\n'
+
+    def fake_run(cmd, **kw):
+        seen["cmd"], seen["kw"] = cmd, kw
+        return Done()
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"])
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 0
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"] and cmd[-7].endswith("bench.py")
+    assert seen["kw"]["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    # under a launcher (WORLD_SIZE set) a mismatch is still an error, not a second launch
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert "WORLD_SIZE=2" in str(e.value.code)
+
+
+def test_rccl_not_loadable_is_reported_not_crashed(tmp_path):
+    """ADVICE r2: the 'RCCL not loadable' route used to read dlerror() twice (second read NULL -> std::string + NULL).
+    Forced here with AGGMG_RCCL_LIB naming a file that is not there, in a fresh process (the loader result is cached):
+    AGGMG_ERR_UNSUPPORTED and the loader's message, no crash."""
+    import subprocess
+    import sys
+    code = (
+        "import ctypes, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "from agglomerationmultigrid1d_amd import _lib\n"
+        "lib = _lib.load()\n"
+        "buf = ctypes.create_string_buffer(512)\n"
+        "st = lib.aggmg_rccl_available(buf, 512)\n"
+        "print(st, buf.value.decode())\n" % ROOT)
+    env = dict(os.environ, AGGMG_RCCL_LIB=str(tmp_path / "no_such_librccl.so"))
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    st, _, msg = out.stdout.strip().partition(" ")
+    from agglomerationmultigrid1d_amd import _lib
+    assert int(st) == _lib.ERR_UNSUPPORTED
+    assert "RCCL not loadable" in msg and "no_such_librccl.so" in msg

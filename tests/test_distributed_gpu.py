@@ -352,19 +352,26 @@ def test_rccl_backend_smoke_single_rank():
     assert same and m == 3.25 and backend == "nccl"
 
 
-@pytest.mark.parametrize("dist_config", [4, 5])
-def test_bench_two_ranks_under_torch_distributed_run(dist_config, tmp_path):
-    """bench.py --gpus 2 as the driver launches it (python -m torch.distributed.run, one process per rank), with both
+@pytest.mark.parametrize("dist_config,launcher", [(4, "torchrun"), (5, "torchrun"), (4, "bare")])
+def test_bench_two_ranks_under_torch_distributed_run(dist_config, launcher, tmp_path):
+    """bench.py --gpus 2 as the driver launches it (python -m torch.distributed.run, one process per rank) and in the
+    bare form `python bench.py --gpus 2` (bench.py starts the ranks itself as a child process), with both
     ranks sharing this box's GPU over gloo: the N > 1 path end to end -- rank-local generators, library set-up,
     partitioned cycles, max-over-ranks timing, ONE JSON line from rank 0"""
     import json
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, AGGMG_DIST_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
     port = 29600 + dist_config
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--log2-elems", "16", "--cg-log2-elems", "16", "--dist-config", str(dist_config)]
+    tail = [os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+            "--log2-elems", "16", "--cg-log2-elems", "16", "--dist-config", str(dist_config)]
+    if launcher == "bare":
+        cmd = [sys.executable] + tail
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+               "127.0.0.1", "--master-port", str(port)] + tail
     out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]

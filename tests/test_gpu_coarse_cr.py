@@ -163,3 +163,31 @@ def test_cr_several_stages(mg, monkeypatch, nb, m, tail_rows, max_q):
                                                       xq.ptr, out.ptr.value + 8 * cuts[r] * m))
     assert np.array_equal(out.download(), x)
     H.free()
+
+
+def test_probe_rejects_factorisation_that_needs_pivoting_across_blocks(mg):
+    """cyclic reduction pivots inside its blocks only.  tridiag(1, eps, 1) with n even is well conditioned
+    (cond ~ n), its 1 x 1 pivot blocks have condition number 1 -- the per-block monitor sees nothing -- and the
+    elimination divides by eps: element growth 1/eps.  The probe solve of aggmg_hier_create measures the backward
+    error, rejects the device factorisation (AUTO: host banded LU with partial pivoting, as accurate as the
+    reference's UMFPACK; DEVICE_CR forced: UnsupportedError), and the solve stays at round-off."""
+    from agglomerationmultigrid1d_amd import _lib
+    n = 4096 + 512
+    eps = 1e-9
+    A = sp.diags([np.ones(n - 1), np.full(n, eps), np.ones(n - 1)], [-1, 0, 1], format="csc")
+    rng = np.random.default_rng(11)
+    b = rng.standard_normal(n)
+    ctx, H = one_level(mg, A, mode=_lib.COARSE_AUTO)
+    info = H.coarse_info()
+    assert not info["on_device"] and info["probe_backward_error"] > 1e-10
+    bd, xd, z = ctx.to_device(b), ctx.alloc(n), ctx.to_device(np.zeros(n))
+    H.vcycle_dev(z, bd, xd, 0, 0, 1.0)
+    x = xd.download()
+    assert np.linalg.norm(A @ x - b) <= 1e-12 * np.linalg.norm(b)
+    with pytest.raises(mg.UnsupportedError):
+        one_level(mg, A, mode=_lib.COARSE_DEVICE_CR)
+    # a well-scaled system of the same shape passes the probe with a backward error at round-off level
+    A2 = sp.diags([np.ones(n - 1), np.full(n, 4.0), np.ones(n - 1)], [-1, 0, 1], format="csc")
+    _, H2 = one_level(mg, A2, mode=_lib.COARSE_AUTO)
+    info2 = H2.coarse_info()
+    assert info2["on_device"] and 0.0 <= info2["probe_backward_error"] < 1e-14

@@ -173,6 +173,31 @@ def test_sparse_products_and_transpose(oracle, mg):
         dG.matmul(sp.identity(7, format='csc'))
 
 
+def test_product_size_guard_is_taken_in_64_bits(mg):
+    """the entry total of a set-up product is formed in 64 bits before the int32 scan: counts that add up
+    to 2^31 or more are refused (UnsupportedError), they do not wrap into a small or negative total"""
+    import ctypes
+    ctx = mg.default_context()
+    lib = ctx.lib
+
+    def scan(counts):
+        c = np.ascontiguousarray(counts, dtype=np.int32)
+        tot = ctypes.c_int64(-1)
+        st = lib.aggmg_debug_scan_counts(ctx.handle, c.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), len(c), ctypes.byref(tot))
+        return st, tot.value
+
+    st, tot = scan([3, 0, 5, 7])
+    assert st == 0 and tot == 15
+    st, tot = scan([2 ** 30] * 3 + [17])                       # int32 arithmetic: 3 * 2^30 + 17 wraps to -1073741807
+    assert tot == 3 * 2 ** 30 + 17
+    with pytest.raises(mg.UnsupportedError):
+        ctx.check(st)
+    st, tot = scan([2 ** 30, 2 ** 30 - 1])                     # 2^31 - 1 entries still fit
+    assert st == 0 and tot == 2 ** 31 - 1
+    st, tot = scan([2 ** 30, 2 ** 30])
+    assert tot == 2 ** 31 and st != 0
+
+
 @pytest.mark.parametrize("n,p,pAgg,nAgg,first", [(32, 3, 1, 3, 4), (48, 2, 0, 2, 2), (64, 1, 1, 3, 4)])
 def test_dg_constructor_recurrences_on_device(oracle, mg, n, p, pAgg, nAgg, first):
     """MeshHierarchy.from_dg_operators: Galerkin products, A = C - D (M_LU \\ G) and the block smoothers of
