@@ -30,6 +30,9 @@ LEVEL_GENERIC, LEVEL_FUSED_BTD, LEVEL_FUSED_CHAIN, LEVEL_COARSEST = 0, 1, 2, 3
 RCCL_ID_BYTES = 128
 DIST_X0_GHOSTS_VALID, DIST_OVERLAP_NEXT, DIST_GRAPH = 1, 2, 4
 ALLGATHER_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p, c_void_p, c_int64, c_void_p)
+# aggmg_sendrecv_fn(user, nops, peer[], is_send[], dev_ptr[], count[], hip_stream)
+SENDRECV_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_void_p), POINTER(c_int64),
+                               c_void_p)
 LEVEL_KIND_NAMES = ["generic", "fused_btd", "fused_chain", "coarsest"]
 
 
@@ -139,6 +142,8 @@ SYMBOLS = {
     "aggmg_dist_init_rccl": (c_int, [_P, _P, _P, c_int, POINTER(c_int)]),
     "aggmg_dist_set_allgather": (c_int, [_P, _P, _P, _P]),
     "aggmg_dist_set_loopback": (c_int, [_P, _P]),
+    "aggmg_dist_set_sendrecv": (c_int, [_P, _P, _P]),
+    "aggmg_dist_set_neighbor_layout": (c_int, [_P, _P, c_int] + [c_int, POINTER(c_int64), POINTER(c_int64)] * 4),
     "aggmg_dist_set_exchange_layout": (c_int, [_P, _P, c_int, c_int64, c_int] + [POINTER(c_int64)] * 3 + [c_int] +
                                        [POINTER(c_int64)] * 3 + [c_int] + [POINTER(c_int64)] * 3),
     "aggmg_dist_allgather_dev": (c_int, [_P, _P, _P, _P, c_int64]),

@@ -931,10 +931,13 @@ static CrStageArgs cr_make_args(const CrDev& cr, const CrStage& S, bool tail) {
 // Stages s0.. and the tail for the right-hand side d (+ db) of stage s0's input system into x:
 // forward launches stage by stage (the last one goes on to solve the tail system in its
 // last-arriving workgroup), then the back substitutions in reverse.
+// dstride: doubles between consecutive blocks of d / db (0 = M; 2 M: the chunk-interleaved boundary rows of an
+// element-partitioned run, gathered in place)
 template <int M>
-static int cr_solve_from(aggmg_ctx* ctx, CrDev& cr, int s0, const double* d, const double* db, double* x) {
+static int cr_solve_from(aggmg_ctx* ctx, CrDev& cr, int s0, const double* d, const double* db, double* x, int dstride = 0) {
   const int ns = (int)cr.st.size();
-  const CrStageArgs T = cr_make_args(cr, cr.tail, true);
+  CrStageArgs T = cr_make_args(cr, cr.tail, true);
+  if (s0 >= ns) T.dstride = dstride;
   const size_t tail_lds = (size_t)cr.tail.lds_total * sizeof(double);
   static const bool fuse_tail = [] {
     const char* e = std::getenv("AGGMG_CR_FUSE_TAIL");
@@ -948,7 +951,8 @@ static int cr_solve_from(aggmg_ctx* ctx, CrDev& cr, int s0, const double* d, con
   const double *din = d, *dinb = db;
   for (int s = s0; s < ns; ++s) {
     const CrStage& S = cr.st[s];
-    const CrStageArgs A = cr_make_args(cr, S, false);
+    CrStageArgs A = cr_make_args(cr, S, false);
+    if (s == s0) A.dstride = dstride;
     const unsigned grid = (unsigned)std::max<int64_t>(S.n_out, 1);
     const size_t lds = (size_t)S.lds_total * sizeof(double);
     if (s == ns - 1 && fuse_tail) {
@@ -966,7 +970,8 @@ static int cr_solve_from(aggmg_ctx* ctx, CrDev& cr, int s0, const double* d, con
   }
   for (int s = ns - 1; s >= s0; --s) {
     const CrStage& S = cr.st[s];
-    const CrStageArgs A = cr_make_args(cr, S, false);
+    CrStageArgs A = cr_make_args(cr, S, false);
+    if (s == s0) A.dstride = dstride;
     const unsigned grid = (unsigned)std::max<int64_t>(S.n_out, 1);
     const double* ds = s == s0 ? d : cr.st[s - 1].partR;
     const double* dsb = s == s0 ? db : cr.st[s - 1].partL;
@@ -1003,11 +1008,12 @@ static int cr_solve_t(aggmg_ctx* ctx, CrDev& cr, const double* rhs, double* out)
 // is gathered and solved redundantly: later stages + tail) ---------------------------------------
 template <int M>
 static int cr_phase_t(aggmg_ctx* ctx, CrDev& cr, int phase, const double* d_owned, int64_t blk_lo, int64_t blk_hi,
-                      double* partR, double* partL, const double* xq, double* x_owned) {
+                      double* partR, double* partL, const double* xq, double* x_owned, int pstride) {
   if (phase == 1)  // boundary system
-    return cr_solve_from<M>(ctx, cr, 1, partR, partL, const_cast<double*>(xq));
+    return cr_solve_from<M>(ctx, cr, 1, partR, partL, const_cast<double*>(xq), pstride);
   const CrStage& S = cr.st[0];
   CrStageArgs A = cr_make_args(cr, S, false);
+  A.ostride = pstride;
   const int q = S.q;
   A.c0 = blk_lo >> q;
   const int64_t c1 = (blk_hi + ((int64_t)1 << q) - 1) >> q;
@@ -1029,12 +1035,12 @@ static int cr_phase_t(aggmg_ctx* ctx, CrDev& cr, int phase, const double* d_owne
 }
 
 static int cr_phase(aggmg_ctx* ctx, CrDev& cr, int phase, const double* d_owned, int64_t blk_lo, int64_t blk_hi,
-                    double* partR, double* partL, const double* xq, double* x_owned) {
+                    double* partR, double* partL, const double* xq, double* x_owned, int pstride = 0) {
   ProfScope ps(ctx, AGGMG_KIND_COARSE, 0);
   switch (cr.m) {
 #define CASE(MM) \
   case MM:       \
-    return cr_phase_t<MM>(ctx, cr, phase, d_owned, blk_lo, blk_hi, partR, partL, xq, x_owned);
+    return cr_phase_t<MM>(ctx, cr, phase, d_owned, blk_lo, blk_hi, partR, partL, xq, x_owned, pstride);
     CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
 #undef CASE
   }
@@ -1617,6 +1623,21 @@ extern "C" int aggmg_coarse_boundary_solve_dev(aggmg_ctx* ctx, aggmg_hier* h, co
   CHECK(coarse_phase_check(ctx, h, 0, 0));
   if (!partR || !partL || !xq) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_coarse_boundary_solve_dev: NULL");
   return cr_phase(ctx, h->cr, 1, nullptr, 0, 0, const_cast<double*>(partR), const_cast<double*>(partL), xq, nullptr);
+}
+
+// Element-partitioned driver (dist.hip): the chunk kernels write their boundary rows chunk-interleaved into Z --
+// chunk c: Z[c][0..m) = its right-hand terms, Z[c][m..2m) = the terms for chunk c + 1's left end -- so that a rank's
+// chunks are ONE contiguous slice and the all-gather of the boundary system runs in place, with no pack or unpack
+// launch; the boundary solve reads Z as it lies (block stride 2 m).  Z points one pad block (2 m zeros) into its
+// allocation: the left-end terms of chunk 0 do not exist.
+int coarse_chunk_forward_interleaved(aggmg_ctx* ctx, aggmg_hier* h, const double* rhs_owned, int64_t blk_lo, int64_t blk_hi,
+                                     double* Z) {
+  return cr_phase(ctx, h->cr, 0, rhs_owned, blk_lo, blk_hi, Z, Z - h->cr.m, nullptr, nullptr, 2 * h->cr.m);
+}
+
+int coarse_boundary_solve_interleaved(aggmg_ctx* ctx, aggmg_hier* h, const double* Z, double* xq) {
+  return cr_phase(ctx, h->cr, 1, nullptr, 0, 0, const_cast<double*>(Z), const_cast<double*>(Z) - h->cr.m, xq, nullptr,
+                  2 * h->cr.m);
 }
 
 extern "C" int aggmg_coarse_chunk_backward_dev(aggmg_ctx* ctx, aggmg_hier* h, const double* rhs_owned,

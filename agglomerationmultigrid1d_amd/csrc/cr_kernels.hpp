@@ -72,6 +72,8 @@ struct CrStageArgs {
   double* stack;  // [n_chunks][stack_stride]: summed inputs of steps 1 .. nsteps-1, or null
   int stack_stride;
   int tail;       // one chunk = the whole system, n_out == 1: the last block is solved with lu_last
+  int dstride;    // doubles between consecutive blocks of the step-0 input vectors d0 / d0b (0: M, contiguous)
+  int ostride;    // same for the boundary rows a forward stage writes (partR / partL); 2 M = interleaved per chunk
   const double* lu_last;
   const int32_t* perm_last;
 };
@@ -282,7 +284,8 @@ __device__ __forceinline__ void cr_loc_load(const CrStageArgs& A, int s, const C
   tshared = thi <= g.n_in - 1;
   if (!tshared) thi = g.n_in - 1;
   if (s == 0) {
-    if (tshared) {  // a full sub-chunk: NB * M contiguous doubles, 16-byte aligned
+    const int ds = A.dstride ? A.dstride : M;
+    if (tshared && ds == M) {  // a full sub-chunk: NB * M contiguous doubles, 16-byte aligned
       const double2* p = reinterpret_cast<const double2*>(d0 + tlo * M);
       if (d0b) {
         const double2* pb = reinterpret_cast<const double2*>(d0b + tlo * M);
@@ -308,19 +311,20 @@ __device__ __forceinline__ void cr_loc_load(const CrStageArgs& A, int s, const C
       for (int k = 0; k <= NB; ++k) {
         const int64_t gk = tlo + k <= thi ? tlo + k : thi;
 #pragma unroll
-        for (int e = 0; e < M; ++e) v[k * M + e] = d0[gk * M + e];
+        for (int e = 0; e < M; ++e) v[k * M + e] = d0[gk * ds + e];
       }
       if (d0b) {
 #pragma unroll
         for (int k = 0; k <= NB; ++k) {
           const int64_t gk = tlo + k <= thi ? tlo + k : thi;
 #pragma unroll
-          for (int e = 0; e < M; ++e) v[k * M + e] += d0b[gk * M + e];
+          for (int e = 0; e < M; ++e) v[k * M + e] += d0b[gk * ds + e];
         }
       }
 #pragma unroll
       for (int k = 0; k <= NB; ++k) {
-        const bool ok = tlo + k <= thi;
+        // (a shared right boundary belongs to the next sub-chunk -- strided inputs bring full sub-chunks here)
+        const bool ok = tlo + k <= thi && !(tshared && k == NB);
 #pragma unroll
         for (int e = 0; e < M; ++e) v[k * M + e] = ok ? v[k * M + e] : 0.0;
       }
@@ -518,8 +522,9 @@ __global__ __launch_bounds__(kCrThreads) CR_WAVES_ATTR void cr_stage_forward_ker
   {
     const double* R = sh + A.lds_off[A.nsteps];  // level q: blocks c, c + 1
     if (threadIdx.x < M) {
-      partR[c * M + threadIdx.x] = R[threadIdx.x];
-      if (c + 1 <= A.n_out - 1) partL[(c + 1) * M + threadIdx.x] = R[2 * M + M + threadIdx.x];
+      const int os = A.ostride ? A.ostride : M;
+      partR[c * os + threadIdx.x] = R[threadIdx.x];
+      if (c + 1 <= A.n_out - 1) partL[(c + 1) * os + threadIdx.x] = R[2 * M + M + threadIdx.x];
     }
   }
   // the summed inputs of the later steps are kept for the back substitution (a few hundred values

@@ -11,9 +11,20 @@
 //      solves it and back-substitutes its own chunks, then the coarse ghost blocks are all-gathered
 //      (small coarsest levels: all-gather of the owned right-hand side + replicated solve),
 // and nothing else: block-Jacobi sweeps are recomputed in the ghost layers.
-// Collectives: RCCL (ncclAllGather, loaded with dlopen so that libaggmg_hip.so carries no link-time
-// dependency on it and shares the copy torch has already loaded), or a caller-supplied function
-// (tests drive the same C++ schedule over gloo), or a device-local loop-back (rehearsals).
+// Collectives: RCCL (loaded with dlopen so that libaggmg_hip.so carries no link-time dependency on it and
+// shares the copy torch has already loaded), or caller-supplied functions (tests drive the same C++ schedule
+// over gloo), or a device-local loop-back (rehearsals).
+//
+// What travels how (round 3: fewer dependent launches per cycle -- every launch of a rank's 1/8 share costs
+// about as much in dispatch as in work):
+//   * interface elements -> the neighbours' ghost elements: ONE grouped ncclSend / ncclRecv per exchange, straight
+//     between the owned interface and the ghost region of the vectors themselves (no pack, no all-gather of
+//     every rank's interface to every rank, no unpack).  AGGMG_DIST_P2P=0 brings back pack -> ncclAllGather ->
+//     unpack (the form BASELINE.json's north_star words; SURVEY.md 8e names the grouped send/recv as its
+//     equivalent).
+//   * the chunk-boundary system of the coarsest solve: ncclAllGather IN PLACE -- the chunk kernels write
+//     their boundary rows chunk-interleaved, so a rank's chunks are one contiguous slice of the buffer the
+//     boundary solve reads as it lies (aggmg_hip.hip, coarse_*_interleaved).
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
@@ -28,6 +39,10 @@ struct RcclApi {
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
   ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 
@@ -61,6 +76,10 @@ RcclApi* rccl_api(std::string* err) {
       api.CommDestroy = (decltype(api.CommDestroy))sym("ncclCommDestroy");
       api.CommCount = (decltype(api.CommCount))sym("ncclCommCount");
       api.AllGather = (decltype(api.AllGather))sym("ncclAllGather");
+      api.Send = (decltype(api.Send))sym("ncclSend");
+      api.Recv = (decltype(api.Recv))sym("ncclRecv");
+      api.GroupStart = (decltype(api.GroupStart))sym("ncclGroupStart");
+      api.GroupEnd = (decltype(api.GroupEnd))sym("ncclGroupEnd");
       api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
     }
   }
@@ -106,6 +125,16 @@ struct ExLayout {
   int64_t count = 0;
   std::vector<ExSeg> send, left, right;
 };
+// the same exchange as neighbour messages: slices [off, off + len) of the local level vector that go to / are
+// filled from the left and the right neighbour; rank r's to_right matches rank r + 1's from_left slice by slice
+// (equal lengths, same order), to_left matches rank r - 1's from_right
+struct NbSeg {
+  int64_t off, len;
+};
+struct NbLayout {
+  bool set = false;
+  std::vector<NbSeg> to_left, to_right, from_left, from_right;
+};
 
 struct aggmg_dist {
   aggmg_hier* H = nullptr;   // local hierarchy, AGGMG_COARSE_EXTERNAL
@@ -115,20 +144,24 @@ struct aggmg_dist {
   std::vector<int> m, W;
   DevBuf send[2], recv[2];  // [0]: finest level, [1]: coarsest level ghosts
   ExLayout ex[2];
+  NbLayout nb[2];
+  bool p2p = true;          // neighbour messages where the backend has them (AGGMG_DIST_P2P=0: all-gathers only)
   DevBuf rhs_g, sol_g, zero_g;
   bool chunked = false;
   int q = 0;
   int64_t nq = 0, cnt = 0;
-  DevBuf send2, recv2, partR, partL, xq;
+  DevBuf zbuf, xq;          // chunk-interleaved boundary rows (one pad block in front), boundary solution
   // collectives
   int backend = 0;  // 0 none, 1 callback, 2 RCCL, 3 loop-back
   aggmg_allgather_fn fn = nullptr;
+  aggmg_sendrecv_fn fn_p2p = nullptr;
   void* user = nullptr;
   ncclComm_t comm = nullptr;
   // interface exchange of the next cycle's x0 under the fine-level ascent
   hipStream_t side = nullptr;
   hipEvent_t ev_main = nullptr, ev_ends = nullptr, ev_side = nullptr;
   const double* pending = nullptr;
+  bool pending_in_place = false;
   int64_t exchanges = 0;
   // hipGraph replay of whole cycles, keyed by the argument tuple (AGGMG_DIST_GRAPH)
   struct GraphKey {
@@ -164,7 +197,7 @@ struct aggmg_dist {
 static int dist_allgather(aggmg_ctx* ctx, aggmg_dist* d, const double* send, double* recv, int64_t count) {
   d->exchanges += 1;
   if (d->world == 1 && d->backend != 2) {
-    HIPCHK(hipMemcpyAsync(recv, send, count * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    if (recv != send) HIPCHK(hipMemcpyAsync(recv, send, count * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
     return AGGMG_OK;
   }
   switch (d->backend) {
@@ -241,9 +274,95 @@ static int unpack_ghosts(aggmg_ctx* ctx, aggmg_dist* d, double* x, int level, co
   return AGGMG_OK;
 }
 
+static NbLayout contiguous_neighbors(const aggmg_dist* d, int level) {
+  NbLayout L;
+  const int64_t m = d->m[level], wm = (int64_t)d->W[level] * m;
+  const int64_t gl = d->own_lo[level] - d->loc_lo[level], gr = d->loc_hi[level] - d->own_hi[level];
+  const int64_t o0 = gl * m;
+  const int64_t o1 = o0 + (d->own_hi[level] - d->own_lo[level]) * m;
+  L.set = true;
+  if (wm > 0) {
+    L.to_left = {NbSeg{o0, wm}};
+    L.to_right = {NbSeg{o1 - wm, wm}};
+    if (gl) L.from_left = {NbSeg{0, gl * m}};
+    if (gr) L.from_right = {NbSeg{o1, gr * m}};
+  }
+  return L;
+}
+
+static bool use_p2p(const aggmg_dist* d, int slot) {
+  if (!d->p2p || !d->nb[slot].set) return false;
+  return d->backend == 2 || d->backend == 3 || (d->backend == 1 && d->fn_p2p);
+}
+
+// interface slices of x -> the neighbours' ghost slices of THEIR x, theirs -> mine; in place, one launch
+static int neighbor_exchange(aggmg_ctx* ctx, aggmg_dist* d, double* x, int slot) {
+  const NbLayout& L = d->nb[slot];
+  const int r = d->rank;
+  const bool hasL = r > 0, hasR = r + 1 < d->world;
+  d->exchanges += 1;
+  switch (d->backend) {
+    case 2: {
+      RcclApi* a = rccl_api(nullptr);
+      ncclResult_t st = a->GroupStart();
+      auto post = [&](const std::vector<NbSeg>& out, const std::vector<NbSeg>& in, int peer) {
+        for (const NbSeg& g : out)
+          if (st == ncclSuccess && g.len > 0) st = a->Send(x + g.off, (size_t)g.len, ncclDouble, peer, d->comm, ctx->stream);
+        for (const NbSeg& g : in)
+          if (st == ncclSuccess && g.len > 0) st = a->Recv(x + g.off, (size_t)g.len, ncclDouble, peer, d->comm, ctx->stream);
+      };
+      if (hasL) post(L.to_left, L.from_left, r - 1);
+      if (hasR) post(L.to_right, L.from_right, r + 1);
+      const ncclResult_t en = a->GroupEnd();
+      if (st == ncclSuccess) st = en;
+      if (st != ncclSuccess) return fail(ctx, AGGMG_ERR_HIP, std::string("ncclSend / ncclRecv: ") + a->GetErrorString(st));
+      return AGGMG_OK;
+    }
+    case 1: {
+      std::vector<int> peer, is_send;
+      std::vector<double*> ptr;
+      std::vector<int64_t> cnt;
+      auto post = [&](const std::vector<NbSeg>& out, const std::vector<NbSeg>& in, int pr) {
+        for (const NbSeg& g : out)
+          if (g.len > 0) peer.push_back(pr), is_send.push_back(1), ptr.push_back(x + g.off), cnt.push_back(g.len);
+        for (const NbSeg& g : in)
+          if (g.len > 0) peer.push_back(pr), is_send.push_back(0), ptr.push_back(x + g.off), cnt.push_back(g.len);
+      };
+      if (hasL) post(L.to_left, L.from_left, r - 1);
+      if (hasR) post(L.to_right, L.from_right, r + 1);
+      if (peer.empty()) return AGGMG_OK;
+      const int st = d->fn_p2p(d->user, (int)peer.size(), peer.data(), is_send.data(), ptr.data(), cnt.data(), (void*)ctx->stream);
+      if (st != 0) return fail(ctx, AGGMG_ERR_HIP, "aggmg_dist: the send/recv callback reported failure " + std::to_string(st));
+      return AGGMG_OK;
+    }
+    case 3: {
+      // rehearsal: this rank's own interface stands in for the neighbours' (same bytes, one launch like the
+      // grouped RCCL call it replaces)
+      const double* src[4];
+      double* dst[4];
+      int64_t rows[4], cols[4], ld[4];
+      int n = 0;
+      auto pair = [&](const std::vector<NbSeg>& out, const std::vector<NbSeg>& in) {
+        for (size_t i = 0; i < in.size() && i < out.size() && n < 4; ++i) {
+          if (in[i].len <= 0) continue;
+          src[n] = x + out[i].off, dst[n] = x + in[i].off;
+          rows[n] = 1, cols[n] = std::min(in[i].len, out[i].len), ld[n] = cols[n];
+          ++n;
+        }
+      };
+      if (hasL) pair(L.to_right, L.from_left);    // what a left neighbour like this rank would send
+      if (hasR) pair(L.to_left, L.from_right);
+      if (n) CHECK(copy2(ctx, n, src, dst, rows, cols, ld, ld));
+      return AGGMG_OK;
+    }
+  }
+  return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_dist: no collective backend set (aggmg_dist_init_rccl / aggmg_dist_set_allgather)");
+}
+
 static int exchange_ghosts(aggmg_ctx* ctx, aggmg_dist* d, double* x, int level) {
   const int slot = level == 0 ? 0 : 1;
   if (d->world == 1 || d->ex[slot].count == 0) return AGGMG_OK;
+  if (use_p2p(d, slot)) return neighbor_exchange(ctx, d, x, slot);
   CHECK(pack_interface(ctx, d, x, level, d->send[slot].p));
   CHECK(dist_allgather(ctx, d, d->send[slot].p, d->recv[slot].p, d->ex[slot].count));
   return unpack_ghosts(ctx, d, x, level, d->recv[slot].p);
@@ -290,8 +409,13 @@ extern "C" int aggmg_dist_create(aggmg_ctx* ctx, aggmg_hier* local, aggmg_hier* 
   for (int s = 0; s < 2; ++s) {
     const int lev = s == 0 ? 0 : nc;
     d->ex[s] = contiguous_layout(d.get(), lev);
+    d->nb[s] = contiguous_neighbors(d.get(), lev);
     CHECK(d->send[s].alloc(ctx, d->ex[s].count));
     CHECK(d->recv[s].alloc(ctx, d->ex[s].count * world));
+  }
+  {
+    const char* e = getenv("AGGMG_DIST_P2P");
+    d->p2p = !(e && e[0] == '0');
   }
   const int64_t Ng = ne[nc] * m[nc];
   CHECK(d->rhs_g.alloc(ctx, Ng));
@@ -303,17 +427,22 @@ extern "C" int aggmg_dist_create(aggmg_ctx* ctx, aggmg_hier* local, aggmg_hier* 
     int64_t nq = 0, nblk = 0;
     CHECK(aggmg_coarse_plan(ctx, coarse_global, &q, &nq, &mblk, &nblk));
     const int64_t own_blk = own_hi[nc] - own_lo[nc];
-    // every rank must own the same number of whole chunks (the all-gather has equal counts)
-    if (q > 0 && mblk == m[nc] && nblk == ne[nc] && own_blk % ((int64_t)1 << q) == 0 && own_blk >= ((int64_t)1 << q) &&
-        own_blk * world == ne[nc]) {
+    // every rank must own the same number of whole chunks, rank r the r-th run of them: the in-place all-gather
+    // has equal counts and puts rank r's slice at r * count.  The decision must come out the same on every rank
+    // (mismatched collective counts hang): it depends only on the replicated operator's plan and on a partition
+    // that is even and in rank order -- anything else takes the gather-and-replicate route on ALL ranks, or is
+    // refused here when this rank alone breaks the pattern.
+    const bool plan_ok = q > 0 && mblk == m[nc] && nblk == ne[nc];
+    const bool even = own_blk * world == ne[nc];
+    const bool aligned = own_blk % ((int64_t)1 << std::max(q, 0)) == 0 && own_blk >= ((int64_t)1 << std::max(q, 0));
+    if (even && own_lo[nc] != (int64_t)rank * own_blk)
+      return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_dist_create: coarsest-level ranges must follow the rank order (own_lo = rank * blocks per rank)");
+    if (plan_ok && even && aligned) {
       d->chunked = true;
       d->q = q;
       d->nq = nq;
       d->cnt = (own_blk >> q) * mblk;
-      CHECK(d->send2.alloc(ctx, 2 * d->cnt));
-      CHECK(d->recv2.alloc(ctx, 2 * d->cnt * world));
-      CHECK(d->partR.alloc(ctx, (nq + 1) * mblk));
-      CHECK(d->partL.alloc(ctx, (nq + 1) * mblk));
+      CHECK(d->zbuf.alloc(ctx, (nq + 2) * 2 * mblk));   // zeroed: the pad block in front stays zero
       CHECK(d->xq.alloc(ctx, (nq + 1) * mblk));
     }
   }
@@ -364,6 +493,7 @@ extern "C" int aggmg_dist_set_exchange_layout(aggmg_ctx* ctx, aggmg_dist* d, int
     return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_dist_set_exchange_layout: a slice leaves the vector or the exchange buffer");
   HIPCHK(hipStreamSynchronize(ctx->stream));
   d->ex[slot] = L;
+  d->nb[slot] = NbLayout();   // the contiguous default no longer describes this level: aggmg_dist_set_neighbor_layout
   d->send[slot].~DevBuf();
   new (&d->send[slot]) DevBuf();
   d->recv[slot].~DevBuf();
@@ -376,6 +506,45 @@ extern "C" int aggmg_dist_set_exchange_layout(aggmg_ctx* ctx, aggmg_dist* d, int
       g.exec = nullptr;
       g.seen = 0;
     }
+  return AGGMG_OK;
+}
+
+extern "C" int aggmg_dist_set_neighbor_layout(aggmg_ctx* ctx, aggmg_dist* d, int level, int nto_left, const int64_t* to_left_off,
+                                              const int64_t* to_left_len, int nto_right, const int64_t* to_right_off,
+                                              const int64_t* to_right_len, int nfrom_left, const int64_t* from_left_off,
+                                              const int64_t* from_left_len, int nfrom_right, const int64_t* from_right_off,
+                                              const int64_t* from_right_len) {
+  if (!ctx || !d) return AGGMG_ERR_ARGUMENT;
+  if (level != 0 && level != d->nl - 1)
+    return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_dist_set_neighbor_layout: only the finest and the coarsest level exchange ghosts");
+  const int64_t N = d->H->lv[level].N;
+  NbLayout L;
+  auto fill = [&](std::vector<NbSeg>& v, int n, const int64_t* off, const int64_t* len) -> bool {
+    if (n < 0 || n > 2 || (n && (!off || !len))) return false;
+    for (int i = 0; i < n; ++i) {
+      if (off[i] < 0 || len[i] < 0 || off[i] + len[i] > N) return false;
+      v.push_back(NbSeg{off[i], len[i]});
+    }
+    return true;
+  };
+  if (!fill(L.to_left, nto_left, to_left_off, to_left_len) || !fill(L.to_right, nto_right, to_right_off, to_right_len) ||
+      !fill(L.from_left, nfrom_left, from_left_off, from_left_len) || !fill(L.from_right, nfrom_right, from_right_off, from_right_len))
+    return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_dist_set_neighbor_layout: at most two slices per direction, inside the level vector");
+  L.set = true;
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  d->nb[level == 0 ? 0 : 1] = L;
+  for (auto& g : d->graphs)
+    if (g.exec) {
+      (void)hipGraphExecDestroy(g.exec);
+      g.exec = nullptr;
+      g.seen = 0;
+    }
+  return AGGMG_OK;
+}
+
+extern "C" int aggmg_dist_set_sendrecv(aggmg_ctx* ctx, aggmg_dist* d, aggmg_sendrecv_fn fn) {
+  if (!ctx || !d) return AGGMG_ERR_ARGUMENT;
+  d->fn_p2p = fn;
   return AGGMG_OK;
 }
 
@@ -476,7 +645,7 @@ static int dist_vcycle_eager(aggmg_ctx* ctx, aggmg_dist* d, double* x0, const do
     // the exchange issued under the previous cycle's ascent (already joined to the main stream): use
     // it if it was for this x0
     if (d->pending == x0) {
-      CHECK(unpack_ghosts(ctx, d, x0, 0, d->recv[0].p));
+      if (!d->pending_in_place) CHECK(unpack_ghosts(ctx, d, x0, 0, d->recv[0].p));   // (neighbour messages landed in the ghosts)
       ghosts_valid = true;
     }
     d->pending = nullptr;
@@ -492,18 +661,13 @@ static int dist_vcycle_eager(aggmg_ctx* ctx, aggmg_dist* d, double* x0, const do
     const int64_t blo = d->own_lo[nc], bhi = d->own_hi[nc];
     const int64_t clo = blo >> d->q;
     const int64_t cnt = d->cnt;
-    const int P = d->world;
-    // the chunk kernels write their boundary rows at GLOBAL positions partR[c*mc ..], partL[(c+1)*mc ..]:
-    // shifted base pointers make this rank's slices land in the send buffer directly (no pack launch)
-    CHECK(aggmg_coarse_chunk_forward_dev(ctx, d->Hc, own, blo, bhi, d->send2.p - clo * mc, d->send2.p + cnt - (clo + 1) * mc));
-    CHECK(dist_allgather(ctx, d, d->send2.p, d->recv2.p, 2 * cnt));
-    {  // rank r's slices go to their global positions: partR[r*cnt ..], partL[mc + r*cnt ..]
-      const double* src[2] = {d->recv2.p, d->recv2.p + cnt};
-      double* dst[2] = {d->partR.p, d->partL.p + mc};
-      const int64_t rows[2] = {P, P}, cols[2] = {cnt, cnt}, sld[2] = {2 * cnt, 2 * cnt}, dld[2] = {cnt, cnt};
-      CHECK(copy2(ctx, 2, src, dst, rows, cols, sld, dld));
-    }
-    CHECK(aggmg_coarse_boundary_solve_dev(ctx, d->Hc, d->partR.p, d->partL.p, d->xq.p));
+    // the chunk kernels write their boundary rows chunk-interleaved at GLOBAL chunk positions of Z (one pad block
+    // in front): this rank's chunks are the contiguous slice Z[clo .. clo + chunks), 2 cnt doubles, and the
+    // all-gather runs in place -- no pack, no unpack, the boundary solve reads Z as it lies
+    double* Z = d->zbuf.p + 2 * mc;
+    CHECK(coarse_chunk_forward_interleaved(ctx, d->Hc, own, blo, bhi, Z));
+    CHECK(dist_allgather(ctx, d, Z + clo * 2 * mc, Z, 2 * cnt));
+    CHECK(coarse_boundary_solve_interleaved(ctx, d->Hc, Z, d->xq.p));
     CHECK(aggmg_coarse_chunk_backward_dev(ctx, d->Hc, own, blo, bhi, d->xq.p, sol_c + gl * mc));
     CHECK(exchange_ghosts(ctx, d, sol_c, nc));
   } else {
@@ -525,15 +689,19 @@ static int dist_vcycle_eager(aggmg_ctx* ctx, aggmg_dist* d, double* x0, const do
       HIPCHK(hipStreamWaitEvent(d->side, d->ev_main, 0));
       ctx->stream = d->side;
       st = aggmg_vcycle_up_split_dev(ctx, H, b, nPost, alpha, x_out, head, tail, 1);
+      const bool in_place = use_p2p(d, 0);
       if (st == AGGMG_OK) {
         (void)hipEventRecord(d->ev_ends, d->side);
-        st = pack_interface(ctx, d, x_out, 0, d->send[0].p);
+        // neighbour messages go from x_out's interface elements straight into the neighbours' ghost elements of
+        // THEIR x_out (the middle tiles on the main stream write neither)
+        st = in_place ? neighbor_exchange(ctx, d, x_out, 0) : pack_interface(ctx, d, x_out, 0, d->send[0].p);
       }
-      if (st == AGGMG_OK) st = dist_allgather(ctx, d, d->send[0].p, d->recv[0].p, d->ex[0].count);
+      if (st == AGGMG_OK && !in_place) st = dist_allgather(ctx, d, d->send[0].p, d->recv[0].p, d->ex[0].count);
       (void)hipEventRecord(d->ev_side, d->side);
       ctx->stream = main;
       CHECK(st);
       d->pending = x_out;
+      d->pending_in_place = in_place;
       CHECK(aggmg_vcycle_up_split_dev(ctx, H, b, nPost, alpha, x_out, head, tail, 2));  // the middle, main stream
       HIPCHK(hipStreamWaitEvent(main, d->ev_side, 0));  // join: x_out whole and the gathered interface ready
       return AGGMG_OK;
@@ -570,6 +738,7 @@ extern "C" int aggmg_dist_vcycle_dev(aggmg_ctx* ctx, aggmg_dist* d, double* x0, 
     d->exchanges += g->exchanges;
     d->graph_replays += 1;
     d->pending = (flags & AGGMG_DIST_OVERLAP_NEXT) && d->world > 1 && d->W[0] > 0 ? x_out : nullptr;
+    d->pending_in_place = use_p2p(d, 0);
     return AGGMG_OK;
   }
   if (g->seen++ == 0) return dist_vcycle_eager(ctx, d, x0, b, x_out, nPre, nPost, alpha, flags);

@@ -391,6 +391,9 @@ int setup_block_smoother(aggmg_ctx* ctx, aggmg_smoother* sm, const int64_t* bloc
 int setup_transfer_btd(aggmg_ctx* ctx, const aggmg_op* L, const BtdDev* Abtd, int mf, int64_t nef, int hint_mc,
                        TransferBtd* out, bool* ok);
 int setup_cr(aggmg_ctx* ctx, const aggmg_op* Ac, int hint_m, CrDev* cr);
+// chunk-interleaved boundary rows of the element-partitioned coarsest solve (aggmg_hip.hip; used by dist.hip)
+int coarse_chunk_forward_interleaved(aggmg_ctx* ctx, aggmg_hier* h, const double* rhs_owned, int64_t blk_lo, int64_t blk_hi, double* Z);
+int coarse_boundary_solve_interleaved(aggmg_ctx* ctx, aggmg_hier* h, const double* Z, double* xq);
 void cr_discard(CrDev* cr);                                                  // frees the factors, valid = false
 int setup_probe_vector(aggmg_ctx* ctx, int64_t n, double* w);                // hash-random entries in [-1, 1)
 int setup_csc_scatter(aggmg_ctx* ctx, const aggmg_op* A, const double* x, double sign, double* y);  // y += sign A x

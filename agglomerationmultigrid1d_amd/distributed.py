@@ -142,18 +142,32 @@ class CgRankLayout:
     owns the vertices [own_lo, own_hi) (the last rank also the final vertex) and the interior nodes of its
     elements.  `exchange_layout(level)` describes the interface slices for aggmg_dist_set_exchange_layout."""
 
-    def __init__(self, n, ps, world, rank, nPre=3, nPost=3):
+    # elements by which one sweep moves information: point-Jacobi one (a row couples the two elements of a vertex);
+    # the element Schwarz smoothers two (src/smoother.jl:1-46: the residual of a node, then the element solves that
+    # mix it over the element); the red-black element Gauss-Seidel extension four (two half-sweeps, each a residual
+    # and an element solve, the second reading the first one's new values)
+    SWEEP_REACH = {"jac": 1, "addSchwarz": 2, "hybridSchwarz": 2, "blockGS": 4}
+
+    def __init__(self, n, ps, world, rank, nPre=3, nPost=3, smoother="jac"):
         if n % world:
             raise ValueError("element count must be divisible by world_size")
+        if smoother not in self.SWEEP_REACH:
+            raise ValueError(f"unknown CG smoother {smoother!r}")
         self.world, self.rank = world, rank
         self.ps = tuple(ps)
+        self.smoother = smoother
         nl = len(ps) + 1
         self.ratios = (1,) * (nl - 1)
         self.m = list(ps) + [1]
-        w = len(ps) * (nPre + nPost + 4)
+        w = len(ps) * (self.SWEEP_REACH[smoother] * (nPre + nPost) + 4)
+        per = n // world
+        if smoother == "blockGS" and world > 1:
+            # the two colours are the parity of the LOCAL element index: every local range starts on an even element
+            w += w % 2
+            if per % 2:
+                raise ValueError("element Gauss-Seidel: every rank must own an even number of elements")
         self.W = [w] * nl
         self.nPre, self.nPost = nPre, nPost
-        per = n // world
         if per < w + 1:
             raise ValueError(f"each rank must own more than {w} elements")
         lo, hi = rank * per, (rank + 1) * per
@@ -209,6 +223,20 @@ class CgRankLayout:
         left = [(o_lv, 0, W), (o_li, I0, W * q)] if gl else []                       # left ghosts <- neighbour's last part
         right = [(o_fv, gl + nown, W + 1), (o_fi, I0 + (gl + nown) * q, W * q)] if gr else []
         return count, [s_ for s_ in send if s_[2] > 0], [s_ for s_ in left if s_[2] > 0], [s_ for s_ in right if s_[2] > 0]
+
+
+    def neighbor_layout(self, k):
+        """-> (to_left, to_right, from_left, from_right), each a list of (offset, len) slices of the local level-k
+        vector (aggmg_dist_set_neighbor_layout): the same interface as exchange_layout, as neighbour messages --
+        vertex slice, then interior slice, in both directions"""
+        if k >= len(self.ps):
+            return None
+        count, send, left, right = self.exchange_layout(k)
+        by_dst = {s_[1]: s_ for s_ in send}            # pack offset -> (x offset, pack offset, len)
+        W, q = self.W[k], self.ps[k] - 1
+        o_fv, o_fi, o_lv, o_li = 0, W + 1, W + 1 + W * q, 2 * W + 1 + W * q
+        sl = lambda *offs: [(by_dst[o][0], by_dst[o][2]) for o in offs if o in by_dst]
+        return (sl(o_fv, o_fi), sl(o_lv, o_li), [(d, n) for (_, d, n) in left], [(d, n) for (_, d, n) in right])
 
 
 # ------------------------------------------------------------------------------------------
@@ -465,6 +493,12 @@ class NativeDistributedVCycle:
                 ctx.check(ctx.lib.aggmg_dist_set_exchange_layout(
                     ctx.handle, h, k, int(count), len(send), arr(send, 0), arr(send, 1), arr(send, 2),
                     len(left), arr(left, 0), arr(left, 1), arr(left, 2), len(right), arr(right, 0), arr(right, 1), arr(right, 2)))
+                nbl = L.neighbor_layout(k) if hasattr(L, "neighbor_layout") else None
+                if nbl is not None:      # the same interface as neighbour messages (one grouped send/recv, no pack / unpack)
+                    a = []
+                    for segs in nbl:
+                        a += [len(segs), arr(segs, 0), arr(segs, 1)]
+                    ctx.check(ctx.lib.aggmg_dist_set_neighbor_layout(ctx.handle, h, k, *a))
         if collectives in ("rccl", "loopback"):
             # nothing of the cycle goes through torch any more: run on the library's own (capturable,
             # non-blocking) stream instead of torch's current one; torch-side initialisation of the
@@ -474,8 +508,10 @@ class NativeDistributedVCycle:
         if collectives == "rccl":
             self._init_rccl()
         elif collectives == "torch":
-            self._cb = _lib.ALLGATHER_FN(self._torch_allgather)     # keep the callback object alive
+            self._cb = _lib.ALLGATHER_FN(self._torch_allgather)     # keep the callback objects alive
             ctx.check(ctx.lib.aggmg_dist_set_allgather(ctx.handle, h, ctypes.cast(self._cb, ctypes.c_void_p), None))
+            self._cb2 = _lib.SENDRECV_FN(self._torch_sendrecv)
+            ctx.check(ctx.lib.aggmg_dist_set_sendrecv(ctx.handle, h, ctypes.cast(self._cb2, ctypes.c_void_p)))
         elif collectives == "loopback":
             ctx.check(ctx.lib.aggmg_dist_set_loopback(ctx.handle, h))
         else:
@@ -530,6 +566,45 @@ class NativeDistributedVCycle:
                     c.dist.all_gather_into_tensor(ro, si)
             return 0
         except Exception:       # an exception must not unwind through the C frames
+            import traceback
+            traceback.print_exc()
+            return 1
+
+    def _torch_sendrecv(self, user, nops, peer, is_send, ptr, count, stream):
+        """aggmg_sendrecv_fn over torch.distributed point-to-point operations (gloo: host-staged; nccl: device
+        tensors on the library's stream, one batch)"""
+        try:
+            import torch
+            c = self.c
+            ops = [(int(peer[i]), bool(is_send[i]), int(ptr[i]), int(count[i])) for i in range(int(nops))]
+            if c.staged or c.dist.get_backend() != "nccl":
+                ctx = self.ctx
+                bufs, reqs = [], []
+                tags = {}
+                for pr, snd, p_, n in ops:
+                    t = torch.empty(n, dtype=torch.float64)
+                    if snd:
+                        ctx.check(ctx.lib.aggmg_memcpy_d2h(ctx.handle, t.numpy().ctypes.data, ctypes.c_void_p(p_), n * 8))
+                    tag = tags.get((pr, snd), 0)          # messages of one pair and direction match in order
+                    tags[(pr, snd)] = tag + 1
+                    reqs.append(c.dist.isend(t, pr, tag=tag) if snd else c.dist.irecv(t, pr, tag=tag))
+                    bufs.append(t)
+                for r_ in reqs:
+                    r_.wait()
+                for (pr, snd, p_, n), t in zip(ops, bufs):
+                    if not snd:
+                        ctx.check(ctx.lib.aggmg_memcpy_h2d(ctx.handle, ctypes.c_void_p(p_), t.numpy().ctypes.data, n * 8))
+            else:
+                ext = torch.cuda.ExternalStream(int(stream or 0), device=self.e.dev)
+                with torch.cuda.stream(ext):
+                    p2p = []
+                    for pr, snd, p_, n in ops:
+                        t = torch.as_tensor(_DevView(p_, n), device=self.e.dev)
+                        p2p.append(c.dist.P2POp(c.dist.isend if snd else c.dist.irecv, t, pr))
+                    for r_ in c.dist.batch_isend_irecv(p2p):
+                        r_.wait()
+            return 0
+        except Exception:
             import traceback
             traceback.print_exc()
             return 1
@@ -799,19 +874,29 @@ def build_local_uniform(n, p, pAgg, ratios, layout, ctx, comm, smoother="blockJa
     return HipEngine(H, Hc, ctx), U
 
 
-def build_local_cg(n, ps, layout, ctx, comm):
+def build_local_cg(n, ps, layout, ctx, comm, smoother=None):
     """Local operators of this rank for the CG p-chain + DG p=0 model hierarchy (config 5 shape), uploaded
     through the CSC boundary with the sub-mesh's element lists (chain kernels), plus the global coarsest
-    (DG p=0) operator assembled from every rank's owned rows.  -> (HipEngine, U_local)"""
+    (DG p=0) operator assembled from every rank's owned rows.  smoother: cg_smoother's kinds 'jac' (default: the
+    layout's), 'addSchwarz', 'hybridSchwarz' (src/smoother.jl:88-139) or the 'blockGS' extension -- the layout must
+    have been sized for it (CgRankLayout(..., smoother=)).  -> (HipEngine, U_local)"""
     import torch
     from . import _lib
-    from .api import DeviceOperator, JacobiSmoother, MeshHierarchy
+    from .api import (AdditiveSchwarzSmoother, BlockGaussSeidel, DeviceOperator, HybridSchwarzSmoother, JacobiSmoother,
+                      MeshHierarchy)
     from .uniform import UniformCgDgHierarchy, block_tridiag_to_csc, _csc
+    smoother = smoother or getattr(layout, "smoother", "jac")
+    if CgRankLayout.SWEEP_REACH[smoother] > CgRankLayout.SWEEP_REACH[getattr(layout, "smoother", "jac")]:
+        raise ValueError(f"the layout's ghost layers were sized for {layout.smoother!r} sweeps, not {smoother!r}")
     lo, hi = layout.loc[0]
     U = UniformCgDgHierarchy(n, ps=ps, elem_range=(lo, hi))
     nl = U.nlevels
     ops = [DeviceOperator(A, _lib.OP_STIFFNESS, ctx) for A in U.A]
-    sms = [JacobiSmoother(ops[k], ctx, U.element_nodes(k)) for k in range(nl - 1)]
+    if smoother == "jac":
+        sms = [JacobiSmoother(ops[k], ctx, U.element_nodes(k)) for k in range(nl - 1)]
+    else:
+        cls = {"addSchwarz": AdditiveSchwarzSmoother, "hybridSchwarz": HybridSchwarzSmoother, "blockGS": BlockGaussSeidel}[smoother]
+        sms = [cls(ops[k], U.element_nodes(k), ctx) for k in range(nl - 1)]
     Ls = [DeviceOperator(L, _lib.OP_TRANSFER, ctx) for L in U.L]
     H = MeshHierarchy(None, ops, sms, Ls, ctx=ctx, keep_host=False, coarse_mode=_lib.COARSE_EXTERNAL)
     # global coarsest operator: the owned rows of the local DG p=0 operator of every rank
@@ -854,8 +939,11 @@ def bench_main(args, rank, world, local_rank, nPre, nPost, alpha):
     n = 2 ** (args.cg_log2_elems if cfg5 else args.log2_elems)
     ratios = (4, 2, 2)
     t_setup = time.perf_counter()
+    cg_sm = getattr(args, "dist_smoother", "jac")
     if cfg5:      # CG p = 4, 2, 1 -> DG p = 0 (BASELINE config 5 shape), chain kernels on every rank's sub-mesh
-        layout = CgRankLayout(n, (4, 2, 1), world, rank, nPre, nPost)
+        if cg_sm == "blockGS":
+            alpha = 1.0          # as the single-GPU block_gs_extension leg
+        layout = CgRankLayout(n, (4, 2, 1), world, rank, nPre, nPost, smoother=cg_sm)
         engine, U = build_local_cg(n, (4, 2, 1), layout, ctx, comm)
     else:
         layout = RankLayout(n, ratios, [args.p + 1, 2, 2, 2], world, rank, nPre, nPost)
@@ -943,7 +1031,9 @@ def bench_main(args, rank, world, local_rank, nPre, nPost, alpha):
             "unit": "DoF-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": (f"config 5 shape: CG n=2^{args.cg_log2_elems} p=4 -> 2 -> 1 -> DG p=0, point-Jacobi, V(3,3), "
+            "config": {"workload": (f"config 5 shape: CG n=2^{args.cg_log2_elems} p=4 -> 2 -> 1 -> DG p=0, "
+                                    + {"jac": "point-Jacobi", "addSchwarz": "additive element Schwarz", "hybridSchwarz": "hybrid element Schwarz",
+                                       "blockGS": "red-black element Gauss-Seidel (EXTENSION, alpha = 1)"}[cg_sm] + ", V(3,3), "
                                     f"partitioned by contiguous element range over {world} GPUs" if cfg5 else
                                     f"config 4: config 3 hierarchy (DG p={args.p} n=2^{args.log2_elems} -> AggDG 4:1 -> "
                                     f"2:1 -> 2:1, V(3,3)) partitioned by contiguous element range over {world} GPUs"),

@@ -61,6 +61,9 @@ def parse():
     ap.add_argument("--dist-config", type=int, default=4, choices=(4, 5),
                     help="N > 1 only: 4 = the config-3 DG hierarchy partitioned (default, the north-star scaling series), "
                          "5 = the CG p=4,2,1 -> DG p=0 hierarchy partitioned (2^cg-log2-elems elements)")
+    ap.add_argument("--dist-smoother", default="jac", choices=("jac", "addSchwarz", "hybridSchwarz", "blockGS"),
+                    help="N > 1, --dist-config 5 only: the CG levels' smoother (cg_smoother's kinds; blockGS = the labelled "
+                         "red-black element Gauss-Seidel extension BASELINE config 5 names)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-smoother-bench", action="store_true")
     return ap.parse_args()

@@ -343,6 +343,27 @@ int aggmg_rccl_unique_id(aggmg_ctx* ctx, void* id_out, int nbytes);
 int aggmg_rccl_available(char* why, int nbytes);
 int aggmg_dist_init_rccl(aggmg_ctx* ctx, aggmg_dist* d, const void* id, int nbytes, int* nranks_out);
 int aggmg_dist_set_allgather(aggmg_ctx* ctx, aggmg_dist* d, aggmg_allgather_fn fn, void* user);
+/* Neighbour messages.  An interface exchange moves a rank's first / last owned elements into the ghost elements of
+ * its left / right neighbour; as grouped ncclSend / ncclRecv between the vectors themselves that is ONE launch
+ * with no pack, all-gather or unpack around it (SURVEY.md 8e names it as the equivalent of the interface
+ * all-gather).  RCCL and the loop-back do so by default; a caller-supplied collective backend does when it also
+ * supplies aggmg_dist_set_sendrecv: fn posts nops operations -- is_send[i] ? send count[i] doubles at dev_ptr[i]
+ * to rank peer[i] : receive them from it -- ordered on hip_stream, messages between one pair of ranks matched in
+ * order, returns 0 on success (`user` is the pointer given to aggmg_dist_set_allgather).  The environment variable
+ * AGGMG_DIST_P2P=0 keeps every exchange on pack -> all-gather -> unpack.
+ * aggmg_dist_set_neighbor_layout: the slices [off, off + len) of a local level-`level` vector (finest or
+ * coarsest) that go to / are filled from the left and right neighbour, at most two per direction; rank r's
+ * to_right must match rank r + 1's from_left slice by slice, to_left rank r - 1's from_right.  Levels with
+ * element-contiguous DoFs have it by default; a level given an explicit aggmg_dist_set_exchange_layout loses the
+ * default and exchanges by all-gather until this is called. */
+typedef int (*aggmg_sendrecv_fn)(void* user, int nops, const int* peer, const int* is_send, double* const* dev_ptr,
+                                 const int64_t* count, void* hip_stream);
+int aggmg_dist_set_sendrecv(aggmg_ctx* ctx, aggmg_dist* d, aggmg_sendrecv_fn fn);
+int aggmg_dist_set_neighbor_layout(aggmg_ctx* ctx, aggmg_dist* d, int level, int nto_left, const int64_t* to_left_off,
+                                   const int64_t* to_left_len, int nto_right, const int64_t* to_right_off,
+                                   const int64_t* to_right_len, int nfrom_left, const int64_t* from_left_off,
+                                   const int64_t* from_left_len, int nfrom_right, const int64_t* from_right_off,
+                                   const int64_t* from_right_len);
 int aggmg_dist_set_loopback(aggmg_ctx* ctx, aggmg_dist* d);
 /* Interface layout of a level whose DoFs are not contiguous per element (a CG level in the reference's
  * vertices-first numbering, src/cg_mesh.jl:37-45,59-65: the interface is a slice of the vertex part plus
