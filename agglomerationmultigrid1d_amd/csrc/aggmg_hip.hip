@@ -907,34 +907,6 @@ static int cr_stage_threads() {
   return t;
 }
 
-// launch shape of a stage kernel: with the LDS image every wave of the workgroup owns CrImg<M>::kBytes behind the
-// step vectors (block size 2: two waves per workgroup fill the CU's 160 KiB; block size 1: four)
-template <int M>
-static void cr_stage_shape(const CrStage& S, bool img, unsigned* threads, size_t* lds) {
-  *threads = (unsigned)cr_stage_threads();
-  *lds = (size_t)S.lds_total * sizeof(double);
-  if constexpr (M <= 2) {
-    if (img) {
-      *threads = std::min<unsigned>(*threads, M == 2 ? 128u : 256u);
-      *lds = ((*lds + 1023) & ~(size_t)1023) + (size_t)(*threads / 64) * CrImg<M>::kBytes;
-    }
-  }
-}
-
-// more than 64 KiB of dynamic LDS has to be allowed per kernel, once
-template <typename K>
-static int cr_allow_lds(aggmg_ctx* ctx, K kernel, size_t lds) {
-  if (lds <= 64 * 1024) return AGGMG_OK;
-  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  return AGGMG_OK;
-}
-
-// bit 0: forward launches, bit 1: backward launches take the LDS-image path (AGGMG_CR_IMG_MASK: measurement / debugging)
-static int cr_img_mask() {
-  static const int m = cr_env_int("AGGMG_CR_IMG_MASK", 3) & 3;
-  return m;
-}
-
 static CrStageArgs cr_make_args(const CrDev& cr, const CrStage& S, bool tail) {
   CrStageArgs A;
   std::memset(&A, 0, sizeof(A));
@@ -950,9 +922,6 @@ static CrStageArgs cr_make_args(const CrDev& cr, const CrStage& S, bool tail) {
   A.n_out = S.n_out;
   A.stack = S.stack;
   A.stack_stride = S.stack_stride;
-  A.stack0 = S.stack0;
-  A.stack0_stride = S.stack0_stride;
-  A.img = 0;   // set by the launcher that sized the LDS for it
   A.tail = tail ? 1 : 0;
   A.lu_last = cr.lu_last;
   A.perm_last = cr.perm_last;
@@ -985,17 +954,12 @@ static int cr_solve_from(aggmg_ctx* ctx, CrDev& cr, int s0, const double* d, con
     CrStageArgs A = cr_make_args(cr, S, false);
     if (s == s0) A.dstride = dstride;
     const unsigned grid = (unsigned)std::max<int64_t>(S.n_out, 1);
-    A.img = (S.stack0 && !dinb && !A.dstride) ? cr_img_mask() : 0;
-    unsigned threads;
-    size_t lds;
-    cr_stage_shape<M>(S, A.img, &threads, &lds);
+    const size_t lds = (size_t)S.lds_total * sizeof(double);
     if (s == ns - 1 && fuse_tail) {
-      CHECK(cr_allow_lds(ctx, cr_stage_forward_kernel<M, true>, std::max(lds, tail_lds)));
-      hipLaunchKernelGGL((cr_stage_forward_kernel<M, true>), dim3(grid), dim3(threads), std::max(lds, tail_lds),
+      hipLaunchKernelGGL((cr_stage_forward_kernel<M, true>), dim3(grid), dim3(cr_stage_threads()), std::max(lds, tail_lds),
                          ctx->stream, A, din, dinb, S.partR, S.partL, T, S.xq, cr.ticket);
     } else {
-      CHECK(cr_allow_lds(ctx, cr_stage_forward_kernel<M, false>, lds));
-      hipLaunchKernelGGL((cr_stage_forward_kernel<M, false>), dim3(grid), dim3(threads), lds, ctx->stream, A, din,
+      hipLaunchKernelGGL((cr_stage_forward_kernel<M, false>), dim3(grid), dim3(cr_stage_threads()), lds, ctx->stream, A, din,
                          dinb, S.partR, S.partL, T, (double*)nullptr, (unsigned int*)nullptr);
       if (s == ns - 1)
         hipLaunchKernelGGL((cr_tail_kernel<M>), dim3(1), dim3(kCrThreads), tail_lds, ctx->stream, T,
@@ -1012,13 +976,8 @@ static int cr_solve_from(aggmg_ctx* ctx, CrDev& cr, int s0, const double* d, con
     const double* ds = s == s0 ? d : cr.st[s - 1].partR;
     const double* dsb = s == s0 ? db : cr.st[s - 1].partL;
     double* xs = s == s0 ? x : cr.st[s - 1].xq;
-    A.img = (S.stack0 && !dsb && !A.dstride) ? cr_img_mask() : 0;
-    unsigned threads;
-    size_t lds;
-    cr_stage_shape<M>(S, A.img, &threads, &lds);
-    CHECK(cr_allow_lds(ctx, cr_stage_backward_kernel<M>, lds));
-    hipLaunchKernelGGL((cr_stage_backward_kernel<M>), dim3(grid), dim3(threads), lds, ctx->stream, A, ds, dsb,
-                       (const double*)S.xq, xs);
+    hipLaunchKernelGGL((cr_stage_backward_kernel<M>), dim3(grid), dim3(cr_stage_threads()), (size_t)S.lds_total * sizeof(double),
+                       ctx->stream, A, ds, dsb, (const double*)S.xq, xs);
   }
   HIPCHK(hipGetLastError());
   return AGGMG_OK;
@@ -1061,19 +1020,14 @@ static int cr_phase_t(aggmg_ctx* ctx, CrDev& cr, int phase, const double* d_owne
   const unsigned grid = (unsigned)std::max<int64_t>(c1 - A.c0, 0);
   if (!grid) return AGGMG_OK;
   const double* d0 = d_owned - blk_lo * M;  // global block indexing; only owned blocks are touched
-  A.img = S.stack0 ? cr_img_mask() : 0;
-  unsigned threads;
-  size_t lds;
-  cr_stage_shape<M>(S, A.img, &threads, &lds);
+  const size_t lds = (size_t)S.lds_total * sizeof(double);
   if (phase == 0) {
     CrStageArgs T;
     std::memset(&T, 0, sizeof(T));
-    CHECK(cr_allow_lds(ctx, cr_stage_forward_kernel<M, false>, lds));
-    hipLaunchKernelGGL((cr_stage_forward_kernel<M, false>), dim3(grid), dim3(threads), lds, ctx->stream, A, d0,
+    hipLaunchKernelGGL((cr_stage_forward_kernel<M, false>), dim3(grid), dim3(cr_stage_threads()), lds, ctx->stream, A, d0,
                        (const double*)nullptr, partR, partL, T, (double*)nullptr, (unsigned int*)nullptr);
   } else {
-    CHECK(cr_allow_lds(ctx, cr_stage_backward_kernel<M>, lds));
-    hipLaunchKernelGGL((cr_stage_backward_kernel<M>), dim3(grid), dim3(threads), lds, ctx->stream, A, d0,
+    hipLaunchKernelGGL((cr_stage_backward_kernel<M>), dim3(grid), dim3(cr_stage_threads()), lds, ctx->stream, A, d0,
                        (const double*)nullptr, xq, x_owned - blk_lo * M);
   }
   HIPCHK(hipGetLastError());

@@ -72,9 +72,6 @@ struct CrStageArgs {
   double* stack;  // [n_chunks][stack_stride]: summed inputs of steps 1 .. nsteps-1, or null
   int stack_stride;
   int tail;       // one chunk = the whole system, n_out == 1: the last block is solved with lu_last
-  int img;        // step 0 through the wave's LDS image where a wave's 64 sub-chunks are interior (M <= 2, see CrImg)
-  double* stack0; // [3 M][stack0_stride]: the odd blocks of sub-levels 1, 2 of every step-0 sub-chunk (forward ->
-  int64_t stack0_stride;  //              backward: no recomputation there), or null
   int dstride;    // doubles between consecutive blocks of the step-0 input vectors d0 / d0b (0: M, contiguous)
   int ostride;    // same for the boundary rows a forward stage writes (partR / partL); 2 M = interleaved per chunk
   const double* lu_last;
@@ -248,269 +245,6 @@ __device__ __forceinline__ void cr_loc_bwd(const CrLevel* lv, int64_t b, double*
   }
 }
 
-
-// ---------------------------------------------------------------------------------------------
-// Step 0 of a stage through LDS (block sizes 1 and 2, three levels per step).
-//
-// A lane that keeps its sub-chunk's ~150 factor values in registers can have only a fraction of their loads
-// in flight: measured (r02) a stage launch issues them in about a dozen dependent batches, one HBM round
-// trip each, with one wave per SIMD to hide them behind -- 2.7 TB/s.  Here a WAVE stages everything its 64
-// sub-chunks need with LDS-DMA loads (global_load_lds_dwordx4: no register destination, so all ~55 KiB are in
-// flight at once), waits once, and the lanes then read their values from LDS when the arithmetic wants them.
-// The DMA writes lane-linear (destination = wave-uniform base + lane * 16), the SOURCE address is per lane:
-// piece k (16 bytes) of every lane's contiguous run goes to region + k * 1024 + lane * 16, so that a lane's reads
-// of one piece hit 64 consecutive 16-byte slots -- conflict-free ds_read_b128 -- while each lane still streams
-// whole cache lines from its own part of the arrays.
-// Used where all 64 sub-chunks of the wave are interior (no clamping, no ragged end); the few others keep the
-// register path above.  Groups of 64 sub-chunks are aligned globally (chunks hold multiples of 64 of them), so
-// which path a sub-chunk takes does not depend on the chunk size or the launch.
-// ---------------------------------------------------------------------------------------------
-// bytes of a region whose lanes each own `bytes` contiguous bytes (8: two lanes share a 16-byte piece; the DMA
-// still writes a full KiB, see cr_glds)
-constexpr int cr_img_reg(int bytes) { return bytes >= 16 ? (bytes / 16) * 1024 : 1024; }
-constexpr int cr_img_nb1(int I) { return 4 >> I; }
-template <int M> constexpr int cr_img_oF(int I) { return I == 0 ? cr_img_reg(8 * M * 8) : cr_img_oF<M>(I - 1) + cr_img_reg(cr_img_nb1(I - 1) * 2 * M * M * 8); }
-// (row 0 of the sub-chunk behind the wave's last one, levels 0 .. 2: one DMA instruction, M^2 pieces per level)
-template <int M> constexpr int cr_img_oFX(int I) { return cr_img_oF<M>(3) + I * 16 * M * M; }
-template <int M> constexpr int cr_img_oU(int I) { return I == 0 ? cr_img_oF<M>(3) + 1024 : cr_img_oU<M>(I - 1) + cr_img_reg(cr_img_nb1(I - 1) * M * M * 8); }
-template <int M> constexpr int cr_img_oP(int I) { return I == 0 ? cr_img_oU<M>(3) : cr_img_oP<M>(I - 1) + (M > 1 ? cr_img_reg(cr_img_nb1(I - 1) * M * 4) : 0); }
-
-template <int M>
-struct CrImg {
-  static_assert(M == 1 || M == 2, "LDS image: block sizes 1 and 2");
-  static constexpr int kRow = 2 * M * M * 8;  // bytes of an (a, c) row of fe / fo
-  static constexpr int kLu = M * M * 8;       // bytes of an lu row
-  static constexpr int kPm = M * 4;           // bytes of a perm row (not staged for M = 1: no permutation)
-  static constexpr int kDb = 8 * M * 8;       // bytes of a sub-chunk's 8 blocks of d
-  static constexpr int nb1(int I) { return cr_img_nb1(I); }
-  static constexpr int oD = 0;                                             // d: 8 blocks per lane
-  static constexpr int oF(int I) { return cr_img_oF<M>(I); }               // fe / fo rows of level I
-  static constexpr int oFX(int I) { return cr_img_oFX<M>(I); }             // row 0 of the sub-chunk after the wave's last
-  static constexpr int oU(int I) { return cr_img_oU<M>(I); }               // lu rows
-  static constexpr int oP(int I) { return cr_img_oP<M>(I); }               // perm rows
-  static constexpr int kBytes = (cr_img_oP<M>(3) + 1023) & ~1023;
-
-  // address of byte `off` of the lane's run in a region of `bytes`-per-lane
-  template <int BYTES>
-  static __device__ __forceinline__ const char* at(const char* region, int lane, int off) {
-    if constexpr (BYTES >= 16)
-      return region + (off >> 4) * 1024 + lane * 16 + (off & 15);
-    else
-      return region + lane * 8 + off;
-  }
-};
-
-// lane's `BYTES` contiguous bytes at gbase + (first + lane) * BYTES -> the region (see CrImg::at).
-// EVERY lane takes part in every DMA instruction: under a partial exec mask the wave's slots came out wrong on
-// gfx950 (measured: the compiler had split the wave around an `if (lane < n)` and issued the wave-wide loads
-// once per part) -- lanes with nothing of their own to fetch repeat another lane's piece.
-template <int BYTES>
-__device__ __forceinline__ void cr_glds(const void* gbase, int64_t first, int lane, char* region) {
-  typedef const __attribute__((address_space(1))) void* gptr_t;
-  typedef __attribute__((address_space(3))) void* lptr_t;
-  if constexpr (BYTES >= 16) {
-    const char* src = static_cast<const char*>(gbase) + (first + lane) * BYTES;
-#pragma unroll
-    for (int k = 0; k < BYTES / 16; ++k)
-      __builtin_amdgcn_global_load_lds((gptr_t)(src + k * 16), (lptr_t)(region + k * 1024), 16, 0, 0);
-  } else {
-    static_assert(BYTES == 8, "runs of 8 bytes or multiples of 16");
-    // lanes 2 l, 2 l + 1 share piece l (first is even: 16-byte aligned source); lanes 32 .. 63 repeat 0 .. 31
-    const char* src = static_cast<const char*>(gbase) + (first + 2 * (lane & 31)) * 8;
-    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)region, 16, 0, 0);
-  }
-}
-
-// row 0 of sub-chunk b0 + 64 at levels 0 .. 2 (row NB1 of lane 63): lane l < 3 M^2 fetches piece l % M^2 of level
-// l / M^2, the others repeat lane 0's
-template <int M, bool FWD>
-__device__ __forceinline__ void cr_stage_extra(const CrLevel* lv, int64_t b0, int lane, char* img) {
-  typedef const __attribute__((address_space(1))) void* gptr_t;
-  typedef __attribute__((address_space(3))) void* lptr_t;
-  using G = CrImg<M>;
-  const int l = lane < 3 * M * M ? lane : 0;
-  const int I = l / (M * M), t = l % (M * M);
-  const double* rows = I == 0 ? (FWD ? lv[0].fe : lv[0].fo) : I == 1 ? (FWD ? lv[1].fe : lv[1].fo) : (FWD ? lv[2].fe : lv[2].fo);
-  const char* src = reinterpret_cast<const char*>(rows) + (b0 + 64) * ((4 >> I) * G::kRow) + t * 16;
-  __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(img + G::oFX(0)), 16, 0, 0);
-}
-
-// the factors of levels 0 .. 2 for the wave's sub-chunks b0 .. b0 + 63 (forward: fe; backward: fo), lu, perm
-template <int M, bool FWD, int I>
-__device__ __forceinline__ void cr_stage_levels(const CrLevel* lv, int64_t b0, int lane, char* img) {
-  if constexpr (I < 3) {
-    using G = CrImg<M>;
-    constexpr int NB1 = G::nb1(I);
-    const CrLevel& L = lv[I];
-    const double* rows = FWD ? L.fe : L.fo;
-    cr_glds<NB1 * G::kRow>(rows, b0, lane, img + G::oF(I));
-    if constexpr (FWD && I == 0) cr_stage_extra<M, FWD>(lv, b0, lane, img);
-    cr_glds<NB1 * G::kLu>(L.lu, b0, lane, img + G::oU(I));
-    if constexpr (M > 1) cr_glds<NB1 * G::kPm>(L.perm, b0, lane, img + G::oP(I));
-    cr_stage_levels<M, FWD, I + 1>(lv, b0, lane, img);
-  }
-}
-
-template <int M, int I>
-__device__ __forceinline__ void cr_img_lu(const char* img, int lane, int jj, double (&f)[M * M], int32_t (&pm)[M]) {
-  using G = CrImg<M>;
-  constexpr int NB1 = G::nb1(I);
-  if constexpr (M == 1) {
-    f[0] = *reinterpret_cast<const double*>(G::template at<NB1 * G::kLu>(img + G::oU(I), lane, jj * G::kLu));
-    pm[0] = 0;
-  } else {
-#pragma unroll
-    for (int t = 0; t < M * M / 2; ++t) {
-      const double2 w = *reinterpret_cast<const double2*>(G::template at<NB1 * G::kLu>(img + G::oU(I), lane, jj * G::kLu + t * 16));
-      f[2 * t] = w.x;
-      f[2 * t + 1] = w.y;
-    }
-    const int2 q = *reinterpret_cast<const int2*>(G::template at<NB1 * G::kPm>(img + G::oP(I), lane, jj * G::kPm));
-    pm[0] = q.x;
-    pm[1] = q.y;
-  }
-}
-
-// (a, c) of row jj of the lane's sub-chunk at level I; row NB1 is row 0 of the next sub-chunk (next lane, or the
-// extra pieces for lane 63)
-template <int M, int I>
-__device__ __forceinline__ void cr_img_row(const char* img, int lane, int jj, double (&ac)[2 * M * M]) {
-  using G = CrImg<M>;
-  constexpr int NB1 = G::nb1(I);
-  const bool next = jj == NB1;
-  const bool extra = next && lane == 63;
-  const char* p = extra ? img + G::oFX(I) : G::template at<NB1 * G::kRow>(img + G::oF(I), next ? lane + 1 : lane, next ? 0 : jj * G::kRow);
-  const int stride = extra ? 16 : 1024;
-#pragma unroll
-  for (int t = 0; t < M * M; ++t) {
-    const double2 w = *reinterpret_cast<const double2*>(p + t * stride);
-    ac[2 * t] = w.x;
-    ac[2 * t + 1] = w.y;
-  }
-}
-
-// y = b \ r with the factors already in registers (the operation order of cr_lu_solve_reg)
-template <int M>
-__device__ __forceinline__ void cr_lu_solve_vals(const double (&f)[M * M], const int32_t (&pm)[M], const double* r, double (&y)[M]) {
-  if constexpr (M == 1) {
-    y[0] = r[0] / f[0];
-  } else {
-    double rv[M];
-#pragma unroll
-    for (int q = 0; q < M; ++q) {
-      rv[q] = r[q];
-      asm("" : "+v"(rv[q]));
-    }
-#pragma unroll
-    for (int k = 0; k < M; ++k) {
-      double v = rv[0];
-#pragma unroll
-      for (int q = 1; q < M; ++q) v = (pm[k] == q) ? rv[q] : v;
-      y[k] = v;
-    }
-#pragma unroll
-    for (int i = 1; i < M; ++i) {
-      double s = y[i];
-#pragma unroll
-      for (int j = 0; j < i; ++j) s -= f[i * M + j] * y[j];
-      y[i] = s;
-    }
-#pragma unroll
-    for (int i = M - 1; i >= 0; --i) {
-      double s = y[i];
-#pragma unroll
-      for (int j = i + 1; j < M; ++j) s -= f[i * M + j] * y[j];
-      y[i] = s / f[i * M + i];
-    }
-  }
-}
-
-// cr_loc_fwd for an interior sub-chunk, factors from the image
-template <int M, int I>
-__device__ __forceinline__ void cr_fwd_img(const char* img, int lane, double* v) {
-  if constexpr (I < 3) {
-    constexpr int NB1 = 1 << (3 - I - 1);
-    double* d = v + CrOff<3, I>::blocks * M;
-    double* dn = v + CrOff<3, I + 1>::blocks * M;
-    double y[NB1][M];
-#pragma unroll
-    for (int jj = 0; jj < NB1; ++jj) {
-      double f[M * M];
-      int32_t pm[M];
-      cr_img_lu<M, I>(img, lane, jj, f, pm);
-      cr_lu_solve_vals<M>(f, pm, d + (2 * jj + 1) * M, y[jj]);
-    }
-#pragma unroll
-    for (int jj = 0; jj <= NB1; ++jj) {
-      double ac[2 * M * M], acc[M];
-      cr_img_row<M, I>(img, lane, jj, ac);
-#pragma unroll
-      for (int e = 0; e < M; ++e) acc[e] = d[(2 * jj) * M + e];
-      if (jj > 0) {
-#pragma unroll
-        for (int i = 0; i < M; ++i)
-#pragma unroll
-          for (int k = 0; k < M; ++k) acc[i] -= ac[i * M + k] * y[jj > 0 ? jj - 1 : 0][k];
-      }
-      if (jj < NB1) {
-#pragma unroll
-        for (int i = 0; i < M; ++i)
-#pragma unroll
-          for (int k = 0; k < M; ++k) acc[i] -= ac[M * M + i * M + k] * y[jj < NB1 ? jj : 0][k];
-      }
-#pragma unroll
-      for (int e = 0; e < M; ++e) dn[jj * M + e] = acc[e];
-    }
-    cr_fwd_img<M, I + 1>(img, lane, v);
-  }
-}
-
-// cr_loc_bwd for an interior sub-chunk (every row has a right neighbour), factors from the image
-template <int M, int I>
-__device__ __forceinline__ void cr_bwd_img(const char* img, int lane, double* v) {
-  if constexpr (I >= 0) {
-    constexpr int NB1 = 1 << (3 - I - 1);
-    double* d = v + CrOff<3, I>::blocks * M;
-    const double* xn = v + CrOff<3, I + 1>::blocks * M;
-#pragma unroll
-    for (int jj = 0; jj < NB1; ++jj) {
-      double ac[2 * M * M], rhs[M], x[M], f[M * M];
-      int32_t pm[M];
-      cr_img_row<M, I>(img, lane, jj, ac);
-      cr_img_lu<M, I>(img, lane, jj, f, pm);
-#pragma unroll
-      for (int i = 0; i < M; ++i) {
-        double s = d[(2 * jj + 1) * M + i];
-#pragma unroll
-        for (int k = 0; k < M; ++k) s -= ac[i * M + k] * xn[jj * M + k];
-#pragma unroll
-        for (int k = 0; k < M; ++k) s -= ac[M * M + i * M + k] * xn[(jj + 1) * M + k];
-        rhs[i] = s;
-      }
-      cr_lu_solve_vals<M>(f, pm, rhs, x);
-#pragma unroll
-      for (int e = 0; e < M; ++e) d[(2 * jj + 1) * M + e] = x[e];
-    }
-#pragma unroll
-    for (int jj = 0; jj <= NB1; ++jj)
-#pragma unroll
-      for (int e = 0; e < M; ++e) d[(2 * jj) * M + e] = xn[jj * M + e];
-    cr_bwd_img<M, I - 1>(img, lane, v);
-  }
-}
-
-// the lane's 8 blocks of d from the image into sub-level 0 of v
-template <int M>
-__device__ __forceinline__ void cr_img_d(const char* img, int lane, double* v) {
-  using G = CrImg<M>;
-#pragma unroll
-  for (int k = 0; k < 8 * M / 2; ++k) {
-    const double2 t = *reinterpret_cast<const double2*>(G::template at<G::kDb>(img + G::oD, lane, k * 16));
-    v[2 * k] = t.x;
-    v[2 * k + 1] = t.y;
-  }
-}
-
 // geometry of step s for chunk c
 struct CrStepGeom {
   int a, a1;            // local levels in / out
@@ -612,26 +346,6 @@ __device__ __forceinline__ void cr_loc_load(const CrStageArgs& A, int s, const C
   }
 }
 
-// one sub-chunk of step s forward, factors from global memory into registers
-template <int M, int QS>
-__device__ __forceinline__ void cr_sub_forward(const CrStageArgs& A, int s, const CrStepGeom& g, int i, bool wg_shared,
-                                               const double* __restrict__ d0, const double* __restrict__ d0b,
-                                               double* sh, double* Rout, double* Lout) {
-  const int64_t b = g.lo_out + i;
-  double v[CrOff<QS, QS + 1>::blocks * M];
-  int64_t thi;
-  bool tshared;
-  cr_loc_load<M, QS>(A, s, g, b, d0, d0b, sh, v, thi, tshared, wg_shared && s > 0 && i == g.nb - 1);
-  cr_loc_fwd<M, QS, 0>(&A.lv[g.a], b, v);
-  const double* top = v + CrOff<QS, QS>::blocks * M;
-#pragma unroll
-  for (int e = 0; e < M; ++e) Rout[i * M + e] = top[e];
-  if (b + 1 <= g.n_out - 1) {
-#pragma unroll
-    for (int e = 0; e < M; ++e) Lout[(i + 1) * M + e] = top[M + e];
-  }
-}
-
 template <int M, int QS>
 __device__ __forceinline__ void cr_step_forward(const CrStageArgs& A, int s, int64_t c, bool wg_shared,
                                                 const double* __restrict__ d0, const double* __restrict__ d0b,
@@ -640,57 +354,19 @@ __device__ __forceinline__ void cr_step_forward(const CrStageArgs& A, int s, int
   const int cnt_out = ((1 << (A.q - g.a1)) + 1) * M;
   double* Rout = sh + A.lds_off[s + 1];
   double* Lout = Rout + cnt_out;
-  for (int i = threadIdx.x; i < g.nb; i += blockDim.x) cr_sub_forward<M, QS>(A, s, g, i, wg_shared, d0, d0b, sh, Rout, Lout);
-}
-
-// whether the 64 sub-chunks b0 .. b0 + 63 of a stage's first step (eight blocks each plus the shared right
-// boundary) are all interior: every row the image stages exists, nothing is clamped
-__device__ __forceinline__ bool cr_group_interior(const CrStageArgs& A, int64_t b0) { return ((b0 + 64) << 3) <= A.lv[0].n - 1; }
-
-// Step 0 forward with the wave's LDS image (img: this wave's CrImg<M>::kBytes): interior groups of 64 sub-chunks
-// stage + compute from LDS and leave the odd blocks of sub-levels 1 and 2 in stack0 for the back substitution;
-// other groups take cr_sub_forward.
-template <int M>
-__device__ __forceinline__ void cr_step0_forward_img(const CrStageArgs& A, int64_t c, bool wg_shared,
-                                                     const double* __restrict__ d0, double* sh, char* img) {
-  constexpr int QS = 3;
-  using G = CrImg<M>;
-  const CrStepGeom g = cr_step_geom<QS>(A, 0, c, wg_shared);
-  const int cnt_out = ((1 << (A.q - g.a1)) + 1) * M;
-  double* Rout = sh + A.lds_off[1];
-  double* Lout = Rout + cnt_out;
-  const int lane = threadIdx.x & 63;
-  for (int base = threadIdx.x & ~63; base < g.nb; base += blockDim.x) {   // (wave-uniform)
-    const int i = base + lane;
-    const int64_t b0 = g.lo_out + base;
-    if (base + 64 <= g.nb && cr_group_interior(A, b0)) {
-      cr_glds<G::kDb>(d0, b0, lane, img + G::oD);
-      cr_stage_levels<M, true, 0>(&A.lv[0], b0, lane, img);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      double v[CrOff<QS, QS + 1>::blocks * M];
-      cr_img_d<M>(img, lane, v);
+  for (int i = threadIdx.x; i < g.nb; i += blockDim.x) {
+    const int64_t b = g.lo_out + i;
+    double v[CrOff<QS, QS + 1>::blocks * M];
+    int64_t thi;
+    bool tshared;
+    cr_loc_load<M, QS>(A, s, g, b, d0, d0b, sh, v, thi, tshared, wg_shared && s > 0 && i == g.nb - 1);
+    cr_loc_fwd<M, QS, 0>(&A.lv[g.a], b, v);
+    const double* top = v + CrOff<QS, QS>::blocks * M;
 #pragma unroll
-      for (int e = 0; e < M; ++e) v[8 * M + e] = 0.0;   // the shared right boundary's value belongs to the next sub-chunk
-      cr_fwd_img<M, 0>(img, lane, v);
-      const double* top = v + CrOff<QS, QS>::blocks * M;
-#pragma unroll
-      for (int e = 0; e < M; ++e) Rout[i * M + e] = top[e];
+    for (int e = 0; e < M; ++e) Rout[i * M + e] = top[e];
+    if (b + 1 <= g.n_out - 1) {
 #pragma unroll
       for (int e = 0; e < M; ++e) Lout[(i + 1) * M + e] = top[M + e];
-      {
-        const double* s1 = v + CrOff<QS, 1>::blocks * M;
-        const double* s2 = v + CrOff<QS, 2>::blocks * M;
-        double* st = A.stack0 + (b0 + lane);
-#pragma unroll
-        for (int e = 0; e < M; ++e) {
-          st[(int64_t)e * A.stack0_stride] = s1[1 * M + e];
-          st[(int64_t)(M + e) * A.stack0_stride] = s1[3 * M + e];
-          st[(int64_t)(2 * M + e) * A.stack0_stride] = s2[1 * M + e];
-        }
-      }
-      asm volatile("" ::: "memory");   // the next pass restages the image: keep its reads above
-    } else if (i < g.nb) {
-      cr_sub_forward<M, QS>(A, 0, g, i, wg_shared, d0, nullptr, sh, Rout, Lout);
     }
   }
 }
@@ -698,113 +374,49 @@ __device__ __forceinline__ void cr_step0_forward_img(const CrStageArgs& A, int64
 // xtop: x of the step's output level, indexed by block - xtop_lo (LDS, or the global boundary
 // solution); xout: x of the step's input level (LDS for s >= 1, the caller's vector for s == 0)
 template <int M, int QS>
-__device__ __forceinline__ void cr_sub_backward(const CrStageArgs& A, int s, const CrStepGeom& g, int i, bool wg_shared,
-                                                const double* __restrict__ d0, const double* __restrict__ d0b,
-                                                const double* xtop, int64_t xtop_lo, double* xout, int64_t xout_lo,
-                                                double* sh) {
-  constexpr int NB = 1 << QS;
-  const int64_t b = g.lo_out + i;
-  double v[CrOff<QS, QS + 1>::blocks * M];
-  int64_t thi;
-  bool tshared;
-  cr_loc_load<M, QS>(A, s, g, b, d0, d0b, sh, v, thi, tshared, wg_shared && s > 0 && i == g.nb - 1);
-  cr_loc_fwd<M, QS, 0>(&A.lv[g.a], b, v);
-  double* top = v + CrOff<QS, QS>::blocks * M;
-  const bool has_right = b + 1 <= g.n_out - 1;
-  const int64_t br = has_right ? b + 1 : b;
-#pragma unroll
-  for (int e = 0; e < M; ++e) {
-    top[e] = xtop[(b - xtop_lo) * M + e];
-    const double xr = xtop[(br - xtop_lo) * M + e];
-    top[M + e] = has_right ? xr : 0.0;
-  }
-  cr_loc_bwd<M, QS, QS - 1>(&A.lv[g.a], b, v);
-  const int64_t tlo = b << QS;
-  double* o = xout + (tlo - xout_lo) * M;
-  if (tshared && s == 0) {
-    double2* o2 = reinterpret_cast<double2*>(o);
-#pragma unroll
-    for (int k = 0; k < NB * M / 2; ++k) o2[k] = make_double2(v[2 * k], v[2 * k + 1]);
-  } else {
-    // own blocks; a shared right boundary is the next sub-chunk's, except that the last sub-chunk of
-    // the workgroup leaves it in LDS for the finer steps
-    const bool write_rb = tshared && s > 0 && i == g.nb - 1;
-#pragma unroll
-    for (int k = 0; k <= NB; ++k) {
-      const bool w = k < NB ? (tlo + k <= thi) : (tshared ? write_rb : (tlo + k <= thi));
-      if (w) {
-#pragma unroll
-        for (int e = 0; e < M; ++e) o[k * M + e] = v[k * M + e];
-      }
-    }
-  }
-}
-
-template <int M, int QS>
 __device__ __forceinline__ void cr_step_backward(const CrStageArgs& A, int s, int64_t c, bool wg_shared,
                                                  const double* __restrict__ d0, const double* __restrict__ d0b,
                                                  const double* xtop, int64_t xtop_lo, double* xout, int64_t xout_lo,
                                                  double* sh) {
+  constexpr int NB = 1 << QS;
   const CrStepGeom g = cr_step_geom<QS>(A, s, c, wg_shared);
-  for (int i = threadIdx.x; i < g.nb; i += blockDim.x)
-    cr_sub_backward<M, QS>(A, s, g, i, wg_shared, d0, d0b, xtop, xtop_lo, xout, xout_lo, sh);
-}
-
-// Step 0 backward with the wave's LDS image: interior groups read d, fo, lu, perm from LDS and the odd blocks of
-// sub-levels 1, 2 from stack0 (written by cr_step0_forward_img: nothing is recomputed, fe is not read again)
-template <int M>
-__device__ __forceinline__ void cr_step0_backward_img(const CrStageArgs& A, int64_t c, bool wg_shared,
-                                                      const double* __restrict__ d0, const double* xtop, int64_t xtop_lo,
-                                                      double* xout, double* sh, char* img) {
-  constexpr int QS = 3;
-  using G = CrImg<M>;
-  const CrStepGeom g = cr_step_geom<QS>(A, 0, c, wg_shared);
-  const int lane = threadIdx.x & 63;
-  for (int base = threadIdx.x & ~63; base < g.nb; base += blockDim.x) {
-    const int i = base + lane;
-    const int64_t b0 = g.lo_out + base;
-    if (base + 64 <= g.nb && cr_group_interior(A, b0)) {
-      const int64_t b = b0 + lane;
-      cr_glds<G::kDb>(d0, b0, lane, img + G::oD);
-      cr_stage_levels<M, false, 0>(&A.lv[0], b0, lane, img);
-      double v[CrOff<QS, QS + 1>::blocks * M];
-      {
-        double* s1 = v + CrOff<QS, 1>::blocks * M;
-        double* s2 = v + CrOff<QS, 2>::blocks * M;
-        const double* st = A.stack0 + b;
+  for (int i = threadIdx.x; i < g.nb; i += blockDim.x) {
+    const int64_t b = g.lo_out + i;
+    double v[CrOff<QS, QS + 1>::blocks * M];
+    int64_t thi;
+    bool tshared;
+    cr_loc_load<M, QS>(A, s, g, b, d0, d0b, sh, v, thi, tshared, wg_shared && s > 0 && i == g.nb - 1);
+    cr_loc_fwd<M, QS, 0>(&A.lv[g.a], b, v);
+    double* top = v + CrOff<QS, QS>::blocks * M;
+    const bool has_right = b + 1 <= g.n_out - 1;
+    const int64_t br = has_right ? b + 1 : b;
 #pragma unroll
-        for (int e = 0; e < M; ++e) {
-          s1[1 * M + e] = st[(int64_t)e * A.stack0_stride];
-          s1[3 * M + e] = st[(int64_t)(M + e) * A.stack0_stride];
-          s2[1 * M + e] = st[(int64_t)(2 * M + e) * A.stack0_stride];
+    for (int e = 0; e < M; ++e) {
+      top[e] = xtop[(b - xtop_lo) * M + e];
+      const double xr = xtop[(br - xtop_lo) * M + e];
+      top[M + e] = has_right ? xr : 0.0;
+    }
+    cr_loc_bwd<M, QS, QS - 1>(&A.lv[g.a], b, v);
+    const int64_t tlo = b << QS;
+    double* o = xout + (tlo - xout_lo) * M;
+    if (tshared && s == 0) {
+      double2* o2 = reinterpret_cast<double2*>(o);
+#pragma unroll
+      for (int k = 0; k < NB * M / 2; ++k) o2[k] = make_double2(v[2 * k], v[2 * k + 1]);
+    } else {
+      // own blocks; a shared right boundary is the next sub-chunk's, except that the last sub-chunk of
+      // the workgroup leaves it in LDS for the finer steps
+      const bool write_rb = tshared && s > 0 && i == g.nb - 1;
+#pragma unroll
+      for (int k = 0; k <= NB; ++k) {
+        const bool w = k < NB ? (tlo + k <= thi) : (tshared ? write_rb : (tlo + k <= thi));
+        if (w) {
+#pragma unroll
+          for (int e = 0; e < M; ++e) o[k * M + e] = v[k * M + e];
         }
       }
-      double* top = v + CrOff<QS, QS>::blocks * M;
-#pragma unroll
-      for (int e = 0; e < M; ++e) {
-        top[e] = xtop[(b - xtop_lo) * M + e];
-        top[M + e] = xtop[(b + 1 - xtop_lo) * M + e];
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      cr_img_d<M>(img, lane, v);
-      cr_bwd_img<M, QS - 1>(img, lane, v);
-      double2* o2 = reinterpret_cast<double2*>(xout + (b << QS) * M);
-#pragma unroll
-      for (int k = 0; k < 8 * M / 2; ++k) o2[k] = make_double2(v[2 * k], v[2 * k + 1]);
-      asm volatile("" ::: "memory");
-    } else if (i < g.nb) {
-      cr_sub_backward<M, QS>(A, 0, g, i, wg_shared, d0, nullptr, xtop, xtop_lo, xout, 0, sh);
     }
   }
-}
-
-// this wave's LDS image: behind the step vectors of the workgroup (host: cr_stage_lds_bytes)
-template <int M>
-__device__ __forceinline__ char* cr_wave_image(const CrStageArgs& A, double* sh) {
-  if constexpr (M <= 2)
-    return reinterpret_cast<char*>(sh) + (((size_t)A.lds_total * sizeof(double) + 1023) & ~(size_t)1023) + (threadIdx.x >> 6) * CrImg<M>::kBytes;
-  else
-    return nullptr;
 }
 
 template <int M>
@@ -814,13 +426,6 @@ __device__ __forceinline__ void cr_forward_steps(const CrStageArgs& A, int64_t c
   constexpr int Q = CrRadix<M>::Q;
   for (int s = 0; s < A.nsteps; ++s) {
     const int qs = A.step_a[s + 1] - A.step_a[s];
-    if constexpr (M <= 2) {
-      if (s == 0 && (A.img & 1) && qs == 3 && !d0b) {   // (A.img: the host sized the LDS for one image per wave)
-        cr_step0_forward_img<M>(A, c, wg_shared, d0, sh, cr_wave_image<M>(A, sh));
-        __syncthreads();
-        continue;
-      }
-    }
     if (qs == 1) {
       cr_step_forward<M, 1>(A, s, c, wg_shared, d0, d0b, sh);
     } else if (qs == 2) {
@@ -847,13 +452,6 @@ __device__ __forceinline__ void cr_backward_steps(const CrStageArgs& A, int64_t 
     const int64_t xtop_lo = top_global ? 0 : (c << (A.q - a1));
     double* xout = s ? sh + A.lds_xoff[s] : x0;
     const int64_t xout_lo = s ? (c << (A.q - a)) : 0;
-    if constexpr (M <= 2) {
-      if (s == 0 && (A.img & 2) && qs == 3 && !d0b) {
-        cr_step0_backward_img<M>(A, c, wg_shared, d0, xtop, xtop_lo, xout, sh, cr_wave_image<M>(A, sh));
-        __syncthreads();
-        continue;
-      }
-    }
     if (qs == 1) {
       cr_step_backward<M, 1>(A, s, c, wg_shared, d0, d0b, xtop, xtop_lo, xout, xout_lo, sh);
     } else if (qs == 2) {

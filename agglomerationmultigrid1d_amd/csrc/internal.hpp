@@ -202,8 +202,6 @@ struct CrStage {
   double *partR = nullptr, *partL = nullptr, *xq = nullptr;  // the stage's boundary system (n_out blocks)
   double* stack = nullptr;      // per chunk: summed inputs of the steps after the first
   int stack_stride = 0;
-  double* stack0 = nullptr;     // [3 m][stack0_stride]: odd blocks of sub-levels 1, 2 of the first step's sub-chunks
-  int64_t stack0_stride = 0;    //   (LDS-image path of cr_kernels.hpp, block sizes 1 and 2)
 };
 
 struct CrDev {

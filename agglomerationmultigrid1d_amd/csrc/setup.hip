@@ -660,13 +660,6 @@ int setup_cr(aggmg_ctx* ctx, const aggmg_op* Ac, int hint_m, CrDev* cr) {
     S.partL = S.partR + nb;  // partL[0] is never written: stays zero
     S.xq = S.partL + nb;
     if (S.stack_stride > 0) CHECK(dz((S.n_out + 1) * (int64_t)S.stack_stride, &S.stack));
-    // first stage, block sizes 1 and 2, chunks of whole 64-sub-chunk groups, a three-level first step: the
-    // LDS-image path of cr_kernels.hpp, which hands the odd blocks of sub-levels 1, 2 from the forward to the
-    // backward launch through stack0
-    if (cr->st.empty() && m <= 2 && S.q >= 9 && S.step_a[1] == 3 && env_int("AGGMG_CR_LDS", 1, 0, 1)) {
-      S.stack0_stride = ((S.n_in >> 3) + 64 + 63) & ~(int64_t)63;
-      CHECK(dz(3 * (int64_t)m * S.stack0_stride, &S.stack0));
-    }
     cr->st.push_back(S);
     l0 += S.q;
   }
