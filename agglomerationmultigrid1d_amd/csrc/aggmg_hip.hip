@@ -343,6 +343,8 @@ template <int MODE>
 static int launch_csr(aggmg_ctx* ctx, const CsrDev& A, const double* x, const double* b, const double* dg,
                       double alpha, double* y) {
   if (A.nrows == 0) return AGGMG_OK;
+  // (single passes stay on the stream kernel also for banded operators: measured on the config-2 matrix, the window
+  // kernel's extra LDS and barrier make one sweep 121 us against 105 us; it pays from two sweeps per launch on)
   if (A.rowblk) {
     hipLaunchKernelGGL((csr_stream_kernel<MODE>), dim3((unsigned)A.nblk), dim3(kThreads), 0, ctx->stream, A.view(),
                        (const int32_t*)A.rowblk, x, b, dg, alpha, y);
@@ -366,6 +368,33 @@ static int launch_csr(aggmg_ctx* ctx, const CsrDev& A, const double* x, const do
       return fail(ctx, AGGMG_ERR_UNSUPPORTED, "bad lanes-per-row");
   }
   HIPCHK(hipGetLastError());
+  return AGGMG_OK;
+}
+
+// n point-Jacobi sweeps u <- u + alpha D^-1 (b - A u) from src into dst (dst != src; tmp: a second vector of the
+// same length, may be clobbered).  Banded operators take up to kBandSweeps sweeps per launch (csr_band_kernel), the
+// others one; the launches ping-pong so that the last one lands in dst.
+static int launch_csr_jacobi_sweeps(aggmg_ctx* ctx, const CsrDev& A, const double* src, const double* b, const double* dg,
+                                    double alpha, int n, double* dst, double* tmp) {
+  if (n <= 0 || A.nrows == 0) return AGGMG_OK;
+  const int per = A.bandblk ? kBandSweeps : 1;
+  const int nl = (n + per - 1) / per;
+  int left = n;
+  for (int l = 0; l < nl; ++l) {
+    // even out the sweeps over the launches (3 + 3 rather than 4 + 2: every launch pays its halo)
+    const int s = (left + (nl - l) - 1) / (nl - l);
+    double* out = ((nl - 1 - l) % 2 == 0) ? dst : tmp;
+    if (out == src) return fail(ctx, AGGMG_ERR_ARGUMENT, "point-Jacobi sweeps: source and destination alias");
+    if (A.bandblk && s > 1) {
+      hipLaunchKernelGGL((csr_band_kernel<kJacobi>), dim3((unsigned)A.nbandblk), dim3(kThreads), 0, ctx->stream, A.view(),
+                         (const int32_t*)A.bandblk, A.bw, s, src, b, dg, alpha, out);
+      HIPCHK(hipGetLastError());
+    } else {
+      CHECK(launch_csr<kJacobi>(ctx, A, src, b, dg, alpha, out));
+    }
+    src = out;
+    left -= s;
+  }
   return AGGMG_OK;
 }
 
@@ -607,6 +636,32 @@ static int generic_sweep(aggmg_ctx* ctx, aggmg_op* A, aggmg_smoother* sm, const 
   return AGGMG_OK;
 }
 
+// nsweeps generic point-Jacobi sweeps from src into dst (dst may be src); `other` is a second vector of the level
+static int generic_jacobi(aggmg_ctx* ctx, aggmg_op* A, aggmg_smoother* sm, const double* src, const double* rhs, double alpha,
+                          int nsweeps, double* dst, double* other) {
+  const int64_t N = A->m;
+  if (nsweeps <= 0) {
+    if (src != dst) HIPCHK(hipMemcpyAsync(dst, src, N * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    return AGGMG_OK;
+  }
+  const int per = A->csr.bandblk ? kBandSweeps : 1;
+  const int nl = (nsweeps + per - 1) / per;
+  // the launches alternate between dst and other and end in dst: the first one writes `other` when their number is
+  // even -- a source that is the first target has to move out of the way
+  double* first = ((nl - 1) % 2 == 0) ? dst : other;
+  if (first == src) {
+    double* spare = first == dst ? other : dst;
+    if (nl == 1) {   // one launch, in place: through the spare vector
+      CHECK(launch_csr_jacobi_sweeps(ctx, A->csr, src, rhs, sm->diag, alpha, nsweeps, spare, dst));
+      HIPCHK(hipMemcpyAsync(dst, spare, N * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+      return AGGMG_OK;
+    }
+    HIPCHK(hipMemcpyAsync(spare, src, N * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    src = spare;
+  }
+  return launch_csr_jacobi_sweeps(ctx, A->csr, src, rhs, sm->diag, alpha, nsweeps, dst, other);
+}
+
 static int check_pair(aggmg_ctx* ctx, aggmg_op* A, aggmg_smoother* sm, const char* who) {
   if (!ctx) return AGGMG_ERR_ARGUMENT;
   if (!A || !sm) return fail(ctx, AGGMG_ERR_ARGUMENT, std::string(who) + ": NULL handle");
@@ -649,21 +704,14 @@ extern "C" int aggmg_smooth_dev(aggmg_ctx* ctx, aggmg_op* A, aggmg_smoother* sm,
     if (src != u_out) HIPCHK(hipMemcpyAsync(u_out, src, N * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
     return AGGMG_OK;
   }
+  if (sm->kind == 0) {   // point Jacobi: several sweeps per launch on banded operators, ping-pong through scratch
+    CHECK(op_ensure_csr(ctx, A));
+    ProfScope ps(ctx, AGGMG_KIND_JACOBI, 0);
+    return generic_jacobi(ctx, A, sm, src, b, alpha, nsweeps, u_out, t);
+  }
   for (int s = 0; s < nsweeps; ++s) {
-    if (sm->kind == 0) {
-      // choose destinations so that the last sweep lands in u_out
-      double* dst = ((nsweeps - 1 - s) % 2 == 0) ? u_out : t;
-      if (dst == src) {  // only possible on the first sweep when src == u_out
-        HIPCHK(hipMemcpyAsync(t, src, N * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
-        src = t;
-        if (dst == t) dst = u_out;  // unreachable, kept for clarity
-      }
-      CHECK(generic_sweep(ctx, A, sm, src, b, alpha, dst, 0));
-      src = dst;
-    } else {
-      CHECK(generic_sweep(ctx, A, sm, src, b, alpha, u_out, 0));
-      src = u_out;
-    }
+    CHECK(generic_sweep(ctx, A, sm, src, b, alpha, u_out, 0));
+    src = u_out;
   }
   return AGGMG_OK;
 }
@@ -1246,19 +1294,15 @@ static int vcycle_down(aggmg_ctx* ctx, aggmg_hier* h, const double* x0, const do
         }
         if (nPre == 0 && src != l.u[0])
           HIPCHK(hipMemcpyAsync(l.u[0], src, l.N * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
-        for (int s = 0; s < nPre; ++s) {
-          double* dst;
-          if (l.S->kind == 0) {
-            dst = ((nPre - 1 - s) % 2 == 0) ? l.u[0] : l.u[1];
-            if (dst == src) {
-              HIPCHK(hipMemcpyAsync(l.u[1], src, l.N * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
-              src = l.u[1];
-            }
-          } else {
-            dst = l.u[0];
+        if (l.S->kind == 0 && nPre > 0) {   // point Jacobi: several sweeps per launch where the operator is banded
+          CHECK(op_ensure_csr(ctx, l.A));
+          ProfScope ps(ctx, AGGMG_KIND_JACOBI, k);
+          CHECK(generic_jacobi(ctx, l.A, l.S, src, rhs, alpha, nPre, l.u[0], l.u[1]));
+        } else {
+          for (int s = 0; s < nPre; ++s) {
+            CHECK(generic_sweep(ctx, l.A, l.S, src, rhs, alpha, l.u[0], k));
+            src = l.u[0];
           }
-          CHECK(generic_sweep(ctx, l.A, l.S, src, rhs, alpha, dst, k));
-          src = dst;
         }
       }
       {
@@ -1320,16 +1364,16 @@ static int vcycle_up(aggmg_ctx* ctx, aggmg_hier* h, const double* b, int nPost, 
         const double* src = l.u[0];
         if (nPost == 0) HIPCHK(hipMemcpyAsync(dst, src, l.N * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
         double* alt = (dst == l.u[1]) ? l.tmp : l.u[1];
-        for (int s = 0; s < nPost; ++s) {
-          double* d2;
-          if (l.S->kind == 0) {
-            d2 = ((nPost - 1 - s) % 2 == 0) ? dst : alt;
-            if (d2 == src) return fail(ctx, AGGMG_ERR_UNSUPPORTED, "internal: ping-pong aliasing");
-          } else {
-            d2 = (s == nPost - 1) ? dst : l.u[0];
+        if (l.S->kind == 0 && nPost > 0) {
+          CHECK(op_ensure_csr(ctx, l.A));
+          ProfScope ps(ctx, AGGMG_KIND_JACOBI, k);
+          CHECK(generic_jacobi(ctx, l.A, l.S, src, rhs, alpha, nPost, dst, alt));
+        } else {
+          for (int s = 0; s < nPost; ++s) {
+            double* d2 = (s == nPost - 1) ? dst : l.u[0];
+            CHECK(generic_sweep(ctx, l.A, l.S, src, rhs, alpha, d2, k));
+            src = d2;
           }
-          CHECK(generic_sweep(ctx, l.A, l.S, src, rhs, alpha, d2, k));
-          src = d2;
         }
       }
     }

@@ -62,6 +62,9 @@ struct CsrDev {
   int lpr = 1;
   int32_t* rowblk = nullptr;  // CSR-stream row blocks (short-row matrices), nblk + 1 entries
   int64_t nblk = 0;
+  int32_t* bandblk = nullptr; // CSR-band row blocks (square, entries within bw of the diagonal), nbandblk + 1 entries
+  int64_t nbandblk = 0;
+  int bw = -1;                // band half-width, -1: not banded / not examined
   CsrView view() const { return CsrView{rowptr, colind, vals, nrows}; }
 };
 
@@ -117,7 +120,7 @@ struct aggmg_op {
   std::shared_ptr<CgtDev> cgt;  // set when a point-Jacobi smoother was given the CG element chain
   ~aggmg_op() {
     for (CsrDev* d : {&csc, &csr})
-      for (void* p : {(void*)d->rowptr, (void*)d->colind, (void*)d->vals, (void*)d->rowblk})
+      for (void* p : {(void*)d->rowptr, (void*)d->colind, (void*)d->vals, (void*)d->rowblk, (void*)d->bandblk})
         if (p) (void)hipFree(p);
   }
 };

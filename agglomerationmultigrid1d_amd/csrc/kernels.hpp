@@ -129,6 +129,87 @@ __global__ __launch_bounds__(kThreads) void csr_stream_kernel(CsrView A, const i
   }
 }
 
+// "CSR-band" variant: the same streaming pattern for square operators whose entries all lie within `bw` of the
+// diagonal (every DG / agglomerated operator of the reference in its own numbering; detected on the device at
+// upload).  A workgroup owns a run of rows plus S * bw rows of halo on either side and
+//   * reads the window of x it needs ONCE, coalesced, into LDS -- the gathers x[col] of csr_stream_kernel fetch the
+//     lines of neighbouring rows several times (measured r02: 13 % more HBM bytes than the model),
+//   * runs S point-Jacobi sweeps on it (temporal blocking, as the fused block-tridiagonal kernel does: sweep s
+//     updates the rows within (S - 1 - s) * bw of the block, so that after S sweeps the block's own rows are exact):
+//     the operator's entries come from HBM once per launch and from the caches for the later sweeps.
+// Products are summed per row in ascending column order (SparseArrays' CSC scatter order), so S sweeps in one
+// launch give bit for bit what S launches give.  Row blocks (bandblk) are cut on the host so that the entries of a
+// block and its halo rows fit `prod` and its window fits kBandWin.
+constexpr int kBandSweeps = 4;   // most sweeps per launch (halo sized for it)
+constexpr int kBandMaxBw = 32;   // widest band the window kernel takes
+constexpr int kBandWin = 4 * kThreads + 2 * kBandSweeps * kBandMaxBw;
+template <int MODE>
+__global__ __launch_bounds__(kThreads) void csr_band_kernel(CsrView A, const int32_t* __restrict__ bandblk, int bw, int S,
+                                                            const double* __restrict__ x, const double* __restrict__ b,
+                                                            const double* __restrict__ dg, double alpha,
+                                                            double* __restrict__ y) {
+  __shared__ double prod[kStreamNnz];
+  __shared__ double xw[2][kBandWin];
+  const int tid = threadIdx.x;
+  const int N = (int)A.nrows;
+  const int r0 = bandblk[blockIdx.x], r1 = bandblk[blockIdx.x + 1];
+  const int w0 = max(0, r0 - S * bw), w1 = min(N, r1 + S * bw);
+  for (int w = w0 + tid; w < w1; w += kThreads) xw[0][w - w0] = x[w];
+  __syncthreads();
+  int cur = 0;
+  for (int s = 0; s < S; ++s) {
+    const int h = (S - 1 - s) * bw;
+    const int ra = max(0, r0 - h), rb = min(N, r1 + h);
+    const int pa = A.rowptr[ra], nn = A.rowptr[rb] - pa;
+    const double* xa = xw[cur];
+    int p = tid;
+    for (; p + 3 * kThreads < nn; p += 4 * kThreads) {
+      const int c0 = A.colind[pa + p], c1 = A.colind[pa + p + kThreads], c2 = A.colind[pa + p + 2 * kThreads],
+                c3 = A.colind[pa + p + 3 * kThreads];
+      const double v0 = A.vals[pa + p], v1 = A.vals[pa + p + kThreads], v2 = A.vals[pa + p + 2 * kThreads],
+                   v3 = A.vals[pa + p + 3 * kThreads];
+      prod[p] = v0 * xa[c0 - w0];
+      prod[p + kThreads] = v1 * xa[c1 - w0];
+      prod[p + 2 * kThreads] = v2 * xa[c2 - w0];
+      prod[p + 3 * kThreads] = v3 * xa[c3 - w0];
+    }
+    for (; p < nn; p += kThreads) prod[p] = A.vals[pa + p] * xa[A.colind[pa + p] - w0];
+    __syncthreads();
+    const bool last = s == S - 1;
+    for (int r = ra + tid; r < rb; r += kThreads) {
+      const int q0 = A.rowptr[r] - pa, q1 = A.rowptr[r + 1] - pa;
+      double acc = 0.0;
+      for (int q = q0; q < q1; ++q) acc += prod[q];
+      if (MODE == kJacobi) {
+        const double res = b[r] - acc;
+        const double yy = res / dg[r];
+        const double v = xa[r - w0] + alpha * yy;
+        if (last) y[r] = v;                 // (the last sweep's range is the block itself)
+        else xw[cur ^ 1][r - w0] = v;
+      } else {
+        if (MODE == kSpmvSet) y[r] = acc;
+        if (MODE == kSpmvAdd) y[r] += acc;
+        if (MODE == kResidual) y[r] = b[r] - acc;
+      }
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+}
+
+// largest |row - col| over the stored entries of a square CSR (atomicMax into *out)
+static __global__ __launch_bounds__(kThreads) void csr_bandwidth_kernel(CsrView A, int* __restrict__ out) {
+  const int64_t row = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  int m = 0;
+  if (row < A.nrows) {
+    const int p0 = A.rowptr[row], p1 = A.rowptr[row + 1];
+    if (p1 > p0) m = max((int)row - A.colind[p0], A.colind[p1 - 1] - (int)row);   // columns ascend within a row
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off, 64));
+  if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(out, m);
+}
+
 // y[inds] (+)= Binv_blk * r[inds]   -- generic block apply (arbitrary, possibly overlapping,
 // index lists: BlockJacobi / AdditiveSchwarz / HybridSchwarz, src/smoother.jl:6-18,30-46,69-81).
 // One thread per (block, local row).  ATOMIC for overlapping blocks (y pre-zeroed).

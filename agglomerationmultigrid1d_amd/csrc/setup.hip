@@ -130,6 +130,47 @@ int setup_stream_blocks(aggmg_ctx* ctx, CsrDev* d) {
   }
   d->nblk = (int64_t)blk.size() - 1;
   CHECK(dev_upload(ctx, blk, &d->rowblk));
+  // square and banded: row blocks for csr_band_kernel (x window in LDS, several point-Jacobi sweeps per launch) --
+  // a block's rows plus (kBandSweeps - 1) * bw halo rows hold at most kStreamNnz entries, its window fits kBandWin
+  static const bool band_on = [] {
+    const char* e = std::getenv("AGGMG_CSR_BAND");
+    return !(e && e[0] == '0');
+  }();
+  if (band_on && d->nrows == d->ncols && nrows > 1) {
+    Flags f;
+    CHECK(f.init(ctx, 1));
+    LAUNCH(csr_bandwidth_kernel, nrows, d->view(), f.d);
+    int bwv = 0;
+    CHECK(f.read(ctx, &bwv));
+    if (bwv <= kBandMaxBw) {
+      const int bw = std::max(bwv, 1);
+      const int64_t H = (int64_t)(kBandSweeps - 1) * bw;
+      std::vector<int32_t> bb;
+      bb.push_back(0);
+      bool ok = true;
+      r = 0;
+      while (r < nrows && ok) {
+        const int64_t lo = std::max<int64_t>(0, r - H);
+        auto fits = [&](int64_t e) {
+          const int64_t hi = std::min(nrows, e + H);
+          return rowptr[hi] - rowptr[lo] <= kStreamNnz && (e - r) + 2 * (int64_t)kBandSweeps * bw <= kBandWin;
+        };
+        int64_t e = r + 1;
+        if (!fits(e)) {
+          ok = false;   // (rows too long for the halo to fit: keep the stream kernel)
+          break;
+        }
+        while (e < nrows && e - r < 4 * kThreads && fits(e + 1)) ++e;
+        bb.push_back((int32_t)e);
+        r = e;
+      }
+      if (ok) {
+        d->bw = bw;
+        d->nbandblk = (int64_t)bb.size() - 1;
+        CHECK(dev_upload(ctx, bb, &d->bandblk));
+      }
+    }
+  }
   return AGGMG_OK;
 }
 

@@ -198,11 +198,17 @@ def smoother_bench(mg, ctx, args, alpha):
     op2 = mg.DeviceOperator(U.stiffness_csc(0), _lib.OP_STIFFNESS, ctx)
     J = mg.JacobiSmoother(op2, ctx)
     Sj_bytes = 12 * nnzA + 4 * (N + 1) + 8 * N + 24 * N
-    fn = sweeps(op2.handle, J.handle, 1, u, v, b)
-    fn(2)
-    dt = _time_loop(ctx, fn, 100)
-    out["generic_csr_point_jacobi"] = {"us_per_sweep": 1e6 * dt / 100, "algorithmic_GBs": Sj_bytes * 100 / dt / 1e9,
-                                       "frac_of_8TBs": Sj_bytes * 100 / dt / 1e9 / HBM_PEAK_GBS}
+    # (the DG operator is banded: the generic path keeps the x window of a row block in LDS and runs up to four
+    # sweeps per launch -- csr_band_kernel; AGGMG_CSR_BAND=0 falls back to one csr_stream_kernel launch per sweep)
+    for per_launch, key in ((1, "generic_csr_point_jacobi"), (3, "generic_csr_point_jacobi_3_per_launch"),
+                            (4, "generic_csr_point_jacobi_4_per_launch")):
+        reps = 96 // per_launch
+        fn = sweeps(op2.handle, J.handle, per_launch, u, v, b)
+        fn(2)
+        dt = _time_loop(ctx, fn, reps)
+        nsw = reps * per_launch
+        out[key] = {"us_per_sweep": 1e6 * dt / nsw, "algorithmic_GBs": Sj_bytes * nsw / dt / 1e9,
+                    "frac_of_8TBs": Sj_bytes * nsw / dt / 1e9 / HBM_PEAK_GBS}
     fn = resid(op2.handle, u, b, r)
     fn(1)
     dt = _time_loop(ctx, fn, 100)

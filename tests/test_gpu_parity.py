@@ -168,6 +168,37 @@ def test_generic_point_jacobi_sweeps(oracle, mg):
                        oracle_sweeps(o, A, So, u0, bb, 2.0 / 3.0, ns)) < TOL
 
 
+@pytest.mark.parametrize("n,p", [(7, 3), (64, 3), (700, 3), (2000, 1), (1500, 4), (333, 7)])
+def test_banded_generic_point_jacobi_many_sweeps_per_launch(oracle, mg, n, p):
+    """dg_smoother(mesh, A, :jac) (src/smoother.jl:146-151) on DG operators through the GENERIC kernels: the operator is
+    banded, so csr_band_kernel keeps the x window of a row block in LDS and runs up to four sweeps per launch
+    (temporal blocking with halo rows) -- 1 .. 9 sweeps (one launch, several launches, uneven splits; several row
+    blocks with halos at n = 700 .. 2000; tiny systems whose halo is the whole matrix), in place and out of place,
+    against the oracle's sweeps; the residual and y = A x take the window kernel too"""
+    o = oracle
+    mesh = o.create_uniform_mesh(n, 0.0, 1.0)
+    bd = o.set_boundary(mesh, 0.0, 1.0, [('neu', 0.0), ('dir', 1.0)])
+    dg = o.DgMesh(mesh, p)
+    G, D, C = o.dg_flux_operators(dg, mesh, bd, 1000.0 * n)
+    A = o.dg_stiffness(dg, G, D, C)
+    So = o.dg_smoother(dg, A, 'jac')
+    Sg = mg.JacobiSmoother(A)                      # no element lists: generic CSR kernels
+    assert not Sg.structured
+    N = A.shape[0]
+    u0, bb = rand_vec(o, N, 16), rand_vec(o, N, 17)
+    for ns in (1, 2, 3, 4, 5, 6, 7, 9):
+        ref = oracle_sweeps(o, A, So, u0, bb, 2.0 / 3.0, ns)
+        assert rel(mg.smooth(Sg.A, Sg, u0, bb, 2.0 / 3.0, ns), ref) < TOL, ns
+    ctx = Sg.A.ctx
+    bd_ = ctx.to_device(bb)
+    for ns in (1, 3, 8):                           # in place on the device
+        x = ctx.to_device(u0)
+        ctx.check(ctx.lib.aggmg_smooth_dev(ctx.handle, Sg.A.handle, Sg.handle, x.ptr, bd_.ptr, 2.0 / 3.0, ns, x.ptr))
+        assert rel(x.download(), oracle_sweeps(o, A, So, u0, bb, 2.0 / 3.0, ns)) < TOL, ns
+    r = mg.residual(Sg.A, u0, bb)
+    assert rel(r, bb - o.csc_matvec(A, u0)) < TOL
+
+
 def test_iterative_smoother_solve_matches(oracle, mg):
     """tests/dg_smoother_test.jl call pattern through the product API: same iteration count,
     same iterate."""
