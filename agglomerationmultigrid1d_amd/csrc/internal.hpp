@@ -52,6 +52,14 @@ struct aggmg_ctx {
   int64_t solv_len[5] = {0, 0, 0, 0, 0};
   double* solv_part = nullptr;
   double* solv_sc = nullptr;
+  // host <-> device staging of the host-pointer entry points (aggmg_vcycle): per worker thread a stream and two
+  // pinned chunks (HostStager in aggmg_hip.hip); allocated on first use
+  struct StageLane {
+    hipStream_t stream = nullptr;
+    void* pin[2] = {nullptr, nullptr};
+    hipEvent_t ev[2] = {nullptr, nullptr};
+  };
+  std::vector<StageLane> stage;
 };
 
 struct CsrDev {
@@ -254,6 +262,7 @@ struct aggmg_hier {
   BandedLU coarse;
   CrDev cr;
   double* cyc[2] = {nullptr, nullptr};  // iterate ping-pong for multi-cycle calls (lazy)
+  double* io[3] = {nullptr, nullptr, nullptr};  // x0, b, x_out of the host-pointer entry aggmg_vcycle (lazy)
   int restriction = 0;  // AGGMG_RESTRICT_EXPLICIT (default) / AGGMG_RESTRICT_PRECONDITIONED
   std::vector<double> h_coarse;
   double last_coarse_ms = 0.0;
@@ -266,6 +275,8 @@ struct aggmg_hier {
     for (void* p : cr.owned)
       if (p) (void)hipFree(p);
     for (double* p : cyc)
+      if (p) (void)hipFree(p);
+    for (double* p : io)
       if (p) (void)hipFree(p);
   }
 };

@@ -431,9 +431,10 @@ def main():
 
     ctx = mg.Context(local_rank)
 
-    def run_size(E, steps, warmup, profile):
+    def run_size(E, steps, warmup, profile, host_entry=False):
         """build the hierarchy at 2^E fine elements, run `steps` timed V-cycles and the same count
-        through the multi-cycle entry point"""
+        through the multi-cycle entry point; host_entry: also time the host-pointer entry point
+        (aggmg_vcycle: x0, b in and x out over PCIe on every call) -- the PCIe-inclusive rate"""
         n = 2 ** E
         t0 = time.perf_counter()
         U = UniformDgAggHierarchy(n, p=args.p, pAgg=1, ratios=(4, 2, 2))
@@ -501,10 +502,28 @@ def main():
                                  "final_residual": resp[-1]}
         except Exception as e:  # reported, never fatal for the bench line
             outer["error"] = repr(e)
+        pcie = None
+        if host_entry:
+            try:
+                xh = mg.multigrid_v_cycle(H, np.zeros(N), b_host)         # (first call: staging buffers, device vectors)
+                th = []
+                for _ in range(5):
+                    t2 = time.perf_counter()
+                    xh = mg.multigrid_v_cycle(H, xh, b_host)
+                    th.append(time.perf_counter() - t2)
+                tm = statistics.median(th)
+                pcie = {"value": N * (nPre + nPost) / tm, "unit": "DoF-updates/s", "ms_per_call": 1e3 * tm,
+                        "host_bytes_per_call": 3 * 8 * N, "effective_GBs": 3 * 8 * N / tm / 1e9,
+                        "note": "multigrid_v_cycle(H, x0, b) on host arrays (aggmg_vcycle): x0, b copied in and a NEW result "
+                                "array copied out on every call, pageable memory staged through pinned chunks by 4 "
+                                "threads; median of 5 calls.  Never the reported `value`: callers that loop keep the "
+                                "vectors on the device (aggmg_vcycle_dev / aggmg_multigrid_dev)"}
+            except Exception as e:
+                pcie = {"error": repr(e)}
         H.free()
         return dict(N=N, dt=dt, per=per, dt_loop=dt_loop, prof=prof, prof_dom=prof_dom,
                     bytes_model=bytes_model, level_sizes=level_sizes, t_gen=t_gen, t_lib=t_lib,
-                    coarse_info=info, outer=outer)
+                    coarse_info=info, outer=outer, pcie=pcie)
 
     R = run_size(args.log2_elems, args.steps, args.warmup, True)
     N, dt, dt_loop, prof, bytes_model = R["N"], R["dt"], R["dt_loop"], R["prof"], R["bytes_model"]
@@ -571,14 +590,14 @@ def main():
         "setup_s": R["t_gen"] + R["t_lib"], "setup_generator_s": R["t_gen"], "setup_library_s": R["t_lib"],
     }
     if args.also_log2_elems and args.also_log2_elems != args.log2_elems:
-        R2 = run_size(args.also_log2_elems, args.steps, args.warmup, False)
+        R2 = run_size(args.also_log2_elems, args.steps, args.warmup, False, host_entry=True)
         out[f"config3_2p{args.also_log2_elems}"] = {
             "workload": f"config 3: same hierarchy at 2^{args.also_log2_elems} fine elements (N_fine={R2['N']})",
             "value": R2["N"] * (nPre + nPost) * args.steps / R2["dt"], "unit": "DoF-updates/s",
             "ms_per_step": 1e3 * R2["dt"] / args.steps, "median_ms_per_step": 1e3 * statistics.median(R2["per"]),
             "vcycles_loop_ms_per_cycle": 1e3 * R2["dt_loop"] / args.steps,
             "setup_s": R2["t_gen"] + R2["t_lib"], "setup_generator_s": R2["t_gen"], "setup_library_s": R2["t_lib"],
-            "outer_solvers_to_1e-8": R2["outer"]}
+            "outer_solvers_to_1e-8": R2["outer"], "pcie_inclusive": R2["pcie"]}
     if args.cg_log2_elems:
         out[f"config5_2p{args.cg_log2_elems}_1gpu"] = cg_bench(mg, ctx, args, nPre, nPost, alpha)
     if not args.no_smoother_bench:
