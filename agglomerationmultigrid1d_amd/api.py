@@ -425,11 +425,18 @@ class BlockDiagonal:
     def __init__(self, mBlocks, ctx=None):
         if len(mBlocks) == 0:
             raise ArgumentError("BlockDiagonal needs at least one block")
-        m = np.asarray(mBlocks[0]).shape[0]
-        for blk in mBlocks:
-            if np.asarray(blk).shape != (m, m):
-                raise ArgumentError("All blocks must be of the same size.")   # block_diagonal.jl:35-37
-        self.mBlocks = [np.array(blk, dtype=np.float64) for blk in mBlocks]
+        if isinstance(mBlocks, np.ndarray) and mBlocks.ndim == 3:
+            # the blocks as one (nb, m, m) array (what the vectorised builders produce): no per-block Python work
+            if mBlocks.shape[1] != mBlocks.shape[2]:
+                raise ArgumentError("All blocks must be of the same size.")
+            m = mBlocks.shape[1]
+            self.mBlocks = np.ascontiguousarray(mBlocks, dtype=np.float64)
+        else:
+            m = np.asarray(mBlocks[0]).shape[0]
+            for blk in mBlocks:
+                if np.asarray(blk).shape != (m, m):
+                    raise ArgumentError("All blocks must be of the same size.")   # block_diagonal.jl:35-37
+            self.mBlocks = [np.array(blk, dtype=np.float64) for blk in mBlocks]
         self.mBlockSize = m
         nb = len(mBlocks)
         self.mBlockInds = np.arange(nb, dtype=np.int64)[None, :] * m + np.arange(1, m + 1, dtype=np.int64)[:, None]
@@ -443,7 +450,10 @@ class BlockDiagonal:
 
     def _setup(self, factorize):
         c = self._ctx
-        flat = np.ascontiguousarray(np.stack([b.T for b in self.mBlocks]))   # column-major per block
+        if isinstance(self.mBlocks, np.ndarray):
+            flat = np.ascontiguousarray(np.transpose(self.mBlocks, (0, 2, 1)))
+        else:
+            flat = np.ascontiguousarray(np.stack([b.T for b in self.mBlocks]))   # column-major per block
         h = ctypes.c_void_p()
         c.check(c.lib.aggmg_blockdiag_setup(c.handle, self.mBlockSize, len(self.mBlocks), flat.ctypes.data_as(_PD),
                                             1 if factorize else 0, ctypes.byref(h)))
@@ -812,9 +822,19 @@ class MeshHierarchy:
 
 def multigrid_v_cycle(H, x0, b, nPre=3, nPost=3, alpha=2.0 / 3.0):
     """multigrid_v_cycle(H, x0, b; nPre=3, nPost=3, alpha=2/3) -> x   (src/solvers.jl:19-50).
-    Returns a new vector; x0 and b are not modified."""
+    Returns a new vector; x0 and b are not modified.  x0, b: host arrays (-> NumPy array) or DeviceVectors
+    (-> DeviceVector, nothing leaves the device)."""
     if not isinstance(nPre, (int, np.integer)) or not isinstance(nPost, (int, np.integer)):
         raise TypeError("nPre / nPost must be integers (nPre::Integer, src/solvers.jl:20)")
+    if isinstance(x0, DeviceVector) and isinstance(b, DeviceVector):
+        # vectors already in HBM: nothing crosses PCIe, a new DeviceVector comes back (aggmg_vcycle_dev) -- the form
+        # for callers that loop; host arrays cost 3 * 8 * N bytes of PCIe per call (bench.py: pcie_inclusive)
+        N = H._ops[0].shape[0]
+        if x0.n != N or b.n != N:
+            raise DimensionMismatch("multigrid_v_cycle: x0 / b do not match the fine operator")
+        out = H.ctx.alloc(N)
+        H.vcycle_dev(x0, b, out, int(nPre), int(nPost), float(alpha))
+        return out
     x0 = _f64(x0)
     b = _f64(b)
     N = H._ops[0].shape[0]

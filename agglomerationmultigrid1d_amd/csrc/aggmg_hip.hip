@@ -104,6 +104,7 @@ extern "C" int aggmg_dev_alloc(aggmg_ctx* ctx, int64_t nbytes, void** out) {
   if (!ctx || !out || nbytes < 0) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_dev_alloc: bad argument");
   HIPCHK(hipSetDevice(ctx->device));
   HIPCHK(hipMalloc(out, (size_t)std::max<int64_t>(nbytes, 8)));
+  HIPCHK(hipMemsetAsync(*out, 0, (size_t)std::max<int64_t>(nbytes, 8), ctx->stream));   // zeroed: a fresh vector is a zero guess
   return AGGMG_OK;
 }
 

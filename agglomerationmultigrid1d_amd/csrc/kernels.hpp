@@ -468,7 +468,7 @@ __global__ __launch_bounds__(NT) void btd_fused_kernel(FusedArgs a) {
   // rows of L' (or (L'D)') for the restriction, fetched with the tile's other streams when the
   // coarse space has two modes per element (one 16-byte load per row)
   const double* lfo_pre = a.ld_out ? a.ld_out : a.lf_out;
-  const bool pre2 = a.do_residual && lfo_pre && a.mc_out == 2 && !a.par_out;
+  const bool pre2 = a.do_residual && lfo_pre && a.mc_out == 2;
   double l2x[NS], l2y[NS];
   double g[NS], bb[NS], uu[NS];
   double bi[NS][M];                              // B^{-1} rows, dead after g is formed
@@ -774,10 +774,25 @@ __global__ __launch_bounds__(NT) void btd_fused_kernel(FusedArgs a) {
     const int mc = a.mc_out;
     const int64_t eo0 = e0 + xo0 > 0 ? e0 + xo0 : 0;
     const int64_t eo1 = e0 + xo1 < ne ? e0 + xo1 : ne;
+    if (pre2) {
+      // two coarse modes: the rows of L' came in with the tile's other streams; every row thread leaves its two
+      // products in the (now free) iterate buffers and the (J, mode) threads only add
+      __syncthreads();
 #pragma unroll
-    for (int s = 0; s < NS; ++s) {
-      const int x = s * EPS + le;
-      if (active) nxt[x * M + i] = rr[s];
+      for (int s = 0; s < NS; ++s) {
+        const int x = s * EPS + le;
+        const bool own = valid[s] && x >= xo0 && x < xo1;
+        if (active) {
+          nxt[x * M + i] = own ? l2x[s] * rr[s] : 0.0;
+          cur[x * M + i] = own ? l2y[s] * rr[s] : 0.0;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const int x = s * EPS + le;
+        if (active) nxt[x * M + i] = rr[s];
+      }
     }
     __syncthreads();
     if (eo1 <= eo0) return;
@@ -788,7 +803,12 @@ __global__ __launch_bounds__(NT) void btd_fused_kernel(FusedArgs a) {
       const int64_t f0 = a.first_out[J], f1 = a.first_out[J + 1];
       const int64_t lo = f0 > eo0 ? f0 : eo0, hi = f1 < eo1 ? f1 : eo1;
       double acc = 0.0;
-      for (int64_t k = lo * M; k < hi * M; ++k) acc += lfo[k * mc + c] * nxt[k - e0 * M];  // ascending fine row
+      if (pre2) {
+        const double* pr = c ? cur : nxt;
+        for (int64_t k = lo * M; k < hi * M; ++k) acc += pr[k - e0 * M];                    // ascending fine row
+      } else {
+        for (int64_t k = lo * M; k < hi * M; ++k) acc += lfo[k * mc + c] * nxt[k - e0 * M];  // ascending fine row
+      }
       if (lo == f0 && hi == f1)
         a.rc_out[J * mc + c] = acc;
       else

@@ -648,6 +648,65 @@ def build_device_hierarchy(U, ctx=None, keep_host=False, smoother="blockJac", cs
 # CG p-chain + DG p=0 coarsest level (the realisable shape of BASELINE config 5 / config 1,
 # tests/dg_cg_heirarchy_test.jl with nCG levels and nDG = 1)
 # ------------------------------------------------------------------------------------------
+def build_device_ragged_hierarchy(n, ctx=None, p=3, pAgg=1, nAgg=3, sizes=(2, 3, 4, 5, 6), jitter=0.3, seed=0,
+                                  keep_host=False, generic=False):
+    """A hierarchy the uniform generator cannot make, at benchmark size: DG p on a mesh with PERTURBED vertices
+    (every interior vertex moved by up to jitter * h), then nAgg agglomerated levels whose agglomerates have sizes
+    drawn from `sizes` -- the fused kernels then run on parent / first-child maps instead of one ratio, an
+    agglomerate cut by a tile boundary is restricted by both tiles (two atomic adds).  Fine-level G, D, C, A in O(n)
+    (the LDG blocks of src/dg_mesh.jl:144-336 do not depend on the element sizes, the mass blocks are J_e M_ref);
+    every L_k and mass matrix from the product's builders (interpolation.py), the Galerkin recurrences, A_k and the
+    smoothers on the device (MeshHierarchy.from_dg_operators).  generic = True: the SAME operators with the block
+    lists handed over in a scrambled order, which sends every level through the generic kernels (block-Jacobi does
+    not depend on the order of its blocks) -- the unfused composition the fused path is checked against -- as
+    info["generic"], sharing H's operators.
+    -> (H, b_host, info)"""
+    from . import _lib
+    from . import interpolation as ip
+    from .api import BlockDiagonal, BlockJacobi, DeviceOperator, MeshHierarchy, default_context
+    ctx = ctx or default_context()
+    rng = np.random.default_rng(seed)
+    U = UniformDgAggHierarchy(n, p=p, pAgg=pAgg, ratios=(), workers=1)    # (one piece: keeps the LDG blocks Gl .. Cd)
+    xv = np.linspace(0.0, 1.0, n + 1)
+    xv[1:-1] += (jitter / n) * (2.0 * rng.random(n - 1) - 1.0)
+    J = np.diff(xv) / 2.0
+    M = J[:, None, None] * U.ref.mass[None, :, :]
+    Minv = (1.0 / J)[:, None, None] * np.linalg.inv(U.ref.mass)[None, :, :]
+    sub, diag, sup = U._stiffness_blocks(U.Gl, U.Gd, U.Dd, U.Du, U.Cd, M, Minv)
+    Z = np.zeros_like(U.Gd)
+
+    def csc(s_, d_, u_):
+        colptr, rowval, nzval, N = block_tridiag_to_csc(s_, d_, u_)
+        return _csc(colptr, rowval, nzval, (N, N))
+
+    A, G, D, C = csc(sub, diag, sup), csc(U.Gl, U.Gd, Z), csc(Z, U.Dd, U.Du), csc(Z, U.Cd, Z)
+    meshes = [ip.DgMesh(xv, p)]
+    for _ in range(nAgg):
+        nsub = meshes[-1].n
+        lens = rng.choice(np.asarray(sizes, dtype=np.int64), size=nsub // int(min(sizes)) + 1)
+        starts = np.concatenate([[0], np.cumsum(lens)])
+        starts = starts[starts < nsub]
+        starts = np.concatenate([starts, [nsub]]).astype(np.int64)
+        meshes.append(ip.AgglomeratedDgMesh(pAgg, starts, meshes[-1]))
+    Ls = [ip.aggdg_dg_interpolation(meshes[1], meshes[0])] + \
+         [ip.aggdg_aggdg_interpolation(meshes[k + 1], meshes[k]) for k in range(1, nAgg)]
+    masses = [BlockDiagonal(m_.mass_blocks(), ctx) for m_ in meshes[1:]]
+    H = MeshHierarchy.from_dg_operators(meshes, A, G, D, C, Ls, masses, ctx=ctx, keep_host=keep_host)
+    info = {"elements": [int(m_.n) for m_ in meshes], "mean_agglomerate": [float(meshes[k].n / meshes[k + 1].n) for k in range(nAgg)]}
+    if generic:
+        sms = []
+        for k in range(nAgg):
+            inds = np.asarray(meshes[k].mBlockInds)
+            sms.append(BlockJacobi(H._ops[k], np.ascontiguousarray(inds[:, rng.permutation(inds.shape[1])]), ctx))
+        info["generic"] = MeshHierarchy(None, list(H._ops), sms, list(H._Ls), ctx=ctx, keep_host=False)
+    # right-hand side: the load vector of f = cos with the boundary terms of the UNIFORM mesh of the same size (entries
+    # of size h, a solution of size one: the scaling of the model problem, under which the 1e-12 residual criterion
+    # is meaningful; a random vector of size one has a solution of size 1 / h^2 and round-off to match).  Not the
+    # exact load vector of the perturbed mesh -- the cycle's linear algebra does not care
+    b = U.rhs()
+    return H, b, info
+
+
 class UniformCgDgHierarchy:
     """CgMesh(p) for p in `ps` (p-coarsening by nodal injection, Galerkin operators, point-Jacobi)
     followed by one re-discretised DgMesh(p=0) level reached through the lumped-mass L2 transfer

@@ -58,6 +58,9 @@ def parse():
     ap.add_argument("--cpu-cycles", type=int, default=4)
     ap.add_argument("--cg-log2-elems", type=int, default=24,
                     help="N = 1 only: V-cycle on the CG p=4,2,1 -> DG p=0 hierarchy (config 5 shape) at 2^E elements; 0 = off")
+    ap.add_argument("--ragged-log2-elems", type=int, default=20,
+                    help="N = 1 only: V-cycle on a perturbed mesh with agglomerates of different sizes ({2..6} sub-elements) at "
+                         "2^E DG p=3 elements, beside the uniform-ratio hierarchy of the same size; 0 = off")
     ap.add_argument("--dist-config", type=int, default=4, choices=(4, 5),
                     help="N > 1 only: 4 = the config-3 DG hierarchy partitioned (default, the north-star scaling series), "
                          "5 = the CG p=4,2,1 -> DG p=0 hierarchy partitioned (2^cg-log2-elems elements)")
@@ -267,6 +270,50 @@ def smoother_bench(mg, ctx, args, alpha):
                     "frac_of_8TBs": Ssw * nsw / dt / 1e9 / HBM_PEAK_GBS}
             del opc, Sw
     out["cg_p4_element_schwarz"] = sw
+    return out
+
+
+def ragged_bench(mg, ctx, args, nPre, nPost, alpha):
+    """the fused kernels on levels whose agglomerates differ in size (parent / first-child maps, an
+    agglomerate cut by a tile boundary restricted by both tiles with atomic adds) timed at size, beside a
+    uniform-ratio hierarchy with the same number of fine elements and similar coarsening (ratios 4, 4, 4: the
+    ragged levels average 4 sub-elements per agglomerate)."""
+    from agglomerationmultigrid1d_amd.uniform import UniformDgAggHierarchy, build_device_hierarchy, build_device_ragged_hierarchy
+    E = args.ragged_log2_elems
+    n = 2 ** E
+    out = {}
+    try:
+        t0 = time.perf_counter()
+        H, b, info = build_device_ragged_hierarchy(n, ctx, p=args.p, seed=1)
+        ctx.synchronize()
+        out["setup_s"] = time.perf_counter() - t0
+        N = len(b)
+        kinds = H.level_kinds()
+        bd = ctx.to_device(b)
+        st = [ctx.to_device(np.zeros(N)), ctx.alloc(N)]
+
+        def run(reps, HH=H):
+            for _ in range(reps):
+                HH.vcycle_dev(st[0], bd, st[1], nPre, nPost, alpha)
+                st[0], st[1] = st[1], st[0]
+
+        run(args.warmup)
+        dt = _time_loop(ctx, run, args.steps)
+        out.update({"workload": f"DG p={args.p} n=2^{E} on a perturbed mesh -> 3 agglomerated levels, agglomerate sizes drawn from "
+                                f"{{2,..,6}} (elements per level {info['elements']}); level kernels {kinds}",
+                    "ms_per_step": 1e3 * dt / args.steps, "value": N * (nPre + nPost) * args.steps / dt, "unit": "DoF-updates/s"})
+        H.free()
+        U = UniformDgAggHierarchy(n, p=args.p, pAgg=1, ratios=(4, 4, 4))
+        Hu = build_device_hierarchy(U, ctx)
+        bd = ctx.to_device(U.rhs())
+        st[0], st[1] = ctx.to_device(np.zeros(N)), ctx.alloc(N)
+        run(args.warmup, Hu)
+        dtu = _time_loop(ctx, lambda reps: run(reps, Hu), args.steps)
+        out["uniform_ratio_4_4_4_ms_per_step"] = 1e3 * dtu / args.steps
+        out["ragged_over_uniform"] = dt / dtu
+        Hu.free()
+    except Exception as e:
+        out["error"] = repr(e)
     return out
 
 
@@ -598,6 +645,8 @@ def main():
             "vcycles_loop_ms_per_cycle": 1e3 * R2["dt_loop"] / args.steps,
             "setup_s": R2["t_gen"] + R2["t_lib"], "setup_generator_s": R2["t_gen"], "setup_library_s": R2["t_lib"],
             "outer_solvers_to_1e-8": R2["outer"], "pcie_inclusive": R2["pcie"]}
+    if args.ragged_log2_elems:
+        out[f"ragged_2p{args.ragged_log2_elems}"] = ragged_bench(mg, ctx, args, nPre, nPost, alpha)
     if args.cg_log2_elems:
         out[f"config5_2p{args.cg_log2_elems}_1gpu"] = cg_bench(mg, ctx, args, nPre, nPost, alpha)
     if not args.no_smoother_bench:

@@ -66,7 +66,9 @@ int aggmg_synchronize(aggmg_ctx* ctx);
  * share of an 8-rank 2^24 job: 0.448 ms per cycle with 10, 0.474 ms with 12).  Values 1 .. 12. */
 #define AGGMG_OPT_COARSE_CHUNK_LOG2 2
 int aggmg_set_option(aggmg_ctx* ctx, int option, int value);
-/* Raw device memory owned by the context's device (plumbing for harnesses without torch). */
+/* Raw device memory owned by the context's device (plumbing for harnesses without torch, and the storage of the
+ * Julia shim's DeviceVector).  aggmg_dev_alloc returns ZEROED memory: a fresh vector is the zero initial guess of
+ * ldiv! (src/solvers.jl:66,87). */
 int aggmg_dev_alloc(aggmg_ctx* ctx, int64_t nbytes, void** out);
 int aggmg_dev_free(aggmg_ctx* ctx, void* ptr);
 int aggmg_memcpy_h2d(aggmg_ctx* ctx, void* dst_dev, const void* src_host, int64_t nbytes);

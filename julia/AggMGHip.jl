@@ -9,7 +9,10 @@
 #     include("AggMGHip.jl")
 #     Hd = AggMGHip.DeviceHierarchy(H)                 # H::MeshHierarchy, built as usual
 #     x  = multigrid_v_cycle(Hd, x0, b)                # same signature / defaults / return
-#     x, iter, res, err = multigrid(Hd, x0, b, 100, 1e-10)
+#     x, iter, res, err = multigrid(Hd, x0, b, 100, 1e-10)          # device loop; err only with exact = true
+#     xd = multigrid_v_cycle(Hd, DeviceVector(Hd.ctx, x0), DeviceVector(Hd.ctx, b))   # vectors stay in HBM
+# Host arrays cross PCIe on every call (measured: 17 ms per config-3 cycle that computes in 0.7 ms); callers
+# that loop hand over DeviceVectors, and `multigrid` / `iterative_smoother_solve` loop on the device by default.
 #
 # Every function of the reference that this file gives a device method is IMPORTED and EXTENDED
 # (a `function f(...)` on an imported name adds a method; on a non-imported name it would define
@@ -289,27 +292,8 @@ function dg_agg_hierarchy(mMeshes, mBdConds, A, G, D, C; nDG::Integer = 1, nAgg:
     return MeshHierarchy(mMeshes, St, Gs, Ds, Cs, Sm, Li, mBdConds)
 end
 
-# ---- solvers (src/solvers.jl) --------------------------------------------------------------------
-# same name, positional / keyword arguments, defaults and return shape as src/solvers.jl:19-20;
-# x0 and b are not mutated, a new Vector is returned
-function multigrid_v_cycle(Hd::DeviceHierarchy, x0::AbstractVector, b::AbstractVector;
-        nPre::Integer = 3, nPost::Integer = 3, alpha::AbstractFloat = 2.0 / 3.0)
-    x0v = Vector{Float64}(x0); bv = Vector{Float64}(b); out = similar(bv)
-    GC.@preserve x0v bv out check(Hd.ctx.h, ccall((:aggmg_vcycle, LIB), Cint,
-        (Handle, Handle, Ptr{Float64}, Ptr{Float64}, Cint, Cint, Float64, Ptr{Float64}),
-        Hd.ctx.h, Hd.h, x0v, bv, nPre, nPost, Float64(alpha), out))
-    return out
-end
-
-# ldiv!(H, b) (overwrites b) / ldiv!(y, H, b): src/solvers.jl:63-92 -- one V-cycle from a zero guess
-function la.ldiv!(Hd::DeviceHierarchy, b::AbstractVector)
-    b[:] = multigrid_v_cycle(Hd, zeros(size(Hd.H.mStiffness[1], 1)), b); return
-end
-function la.ldiv!(y::AbstractVector, Hd::DeviceHierarchy, b::AbstractVector)
-    y[:] = multigrid_v_cycle(Hd, zeros(size(Hd.H.mStiffness[1], 1)), b); return
-end
-
-# device vector: aggmg_dev_alloc / aggmg_memcpy_h2d / aggmg_memcpy_d2h
+# device vector: aggmg_dev_alloc (zeroed) / aggmg_memcpy_h2d / aggmg_memcpy_d2h.  What a caller keeps between
+# calls so that nothing but the handles crosses PCIe: multigrid_v_cycle, ldiv! and multigrid take and return them.
 mutable struct DeviceVector
     ctx::Context               # strong reference: the context outlives the vector
     p::Ptr{Cvoid}
@@ -329,54 +313,111 @@ function free!(v::DeviceVector)
     v.p = C_NULL
     return nothing
 end
-function DeviceVector(ctx::Context, x::Vector{Float64})
+function DeviceVector(ctx::Context, x::AbstractVector)
+    x = Vector{Float64}(x)
     v = DeviceVector(ctx, length(x))
     GC.@preserve x check(ctx.h, ccall((:aggmg_memcpy_h2d, LIB), Cint, (Handle, Ptr{Cvoid}, Ptr{Float64}, Int64),
         ctx.h, v.p, x, 8length(x)))
     return v
 end
+Base.length(v::DeviceVector) = v.n
+Base.size(v::DeviceVector) = (v.n,)
 function download(v::DeviceVector)
     out = Vector{Float64}(undef, v.n)
     GC.@preserve out check(v.ctx.h, ccall((:aggmg_memcpy_d2h, LIB), Cint, (Handle, Ptr{Float64}, Ptr{Cvoid}, Int64),
         v.ctx.h, out, v.p, 8v.n))
     return out
 end
+Base.Vector(v::DeviceVector) = download(v)
+Base.Array(v::DeviceVector) = download(v)
+
+# ---- solvers (src/solvers.jl) --------------------------------------------------------------------
+# same name, positional / keyword arguments, defaults and return shape as src/solvers.jl:19-20;
+# x0 and b are not mutated, a new Vector is returned
+function multigrid_v_cycle(Hd::DeviceHierarchy, x0::AbstractVector, b::AbstractVector;
+        nPre::Integer = 3, nPost::Integer = 3, alpha::AbstractFloat = 2.0 / 3.0)
+    x0v = Vector{Float64}(x0); bv = Vector{Float64}(b); out = similar(bv)
+    GC.@preserve x0v bv out check(Hd.ctx.h, ccall((:aggmg_vcycle, LIB), Cint,
+        (Handle, Handle, Ptr{Float64}, Ptr{Float64}, Cint, Cint, Float64, Ptr{Float64}),
+        Hd.ctx.h, Hd.h, x0v, bv, nPre, nPost, Float64(alpha), out))
+    return out
+end
+
+# the same cycle on vectors that are already in HBM: nothing is copied, a new DeviceVector is returned and
+# x0 / b are left as they are (aggmg_vcycle_dev) -- the form for callers that loop
+function multigrid_v_cycle(Hd::DeviceHierarchy, x0::DeviceVector, b::DeviceVector;
+        nPre::Integer = 3, nPost::Integer = 3, alpha::AbstractFloat = 2.0 / 3.0)
+    (x0.n == b.n) || throw(DimensionMismatch("multigrid_v_cycle: x0 and b differ in length"))
+    out = DeviceVector(Hd.ctx, b.n)
+    check(Hd.ctx.h, ccall((:aggmg_vcycle_dev, LIB), Cint,
+        (Handle, Handle, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Cint, Float64, Ptr{Cvoid}),
+        Hd.ctx.h, Hd.h, x0.p, b.p, nPre, nPost, Float64(alpha), out.p))
+    return out
+end
+
+# ldiv!(y, H, b) with y, b in HBM: one V-cycle from a zero guess written into y (y must not be b: the entry point
+# refuses aliased output; ldiv!(H, b) for a DeviceVector goes through a fresh vector and swaps the storage)
+function la.ldiv!(y::DeviceVector, Hd::DeviceHierarchy, b::DeviceVector)
+    z = DeviceVector(Hd.ctx, b.n)                       # zeroed by aggmg_dev_alloc
+    check(Hd.ctx.h, ccall((:aggmg_vcycle_dev, LIB), Cint,
+        (Handle, Handle, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Cint, Float64, Ptr{Cvoid}),
+        Hd.ctx.h, Hd.h, z.p, b.p, 3, 3, 2.0 / 3.0, y.p))
+    return
+end
+function la.ldiv!(Hd::DeviceHierarchy, b::DeviceVector)
+    y = DeviceVector(Hd.ctx, b.n)
+    la.ldiv!(y, Hd, b)
+    b.p, y.p = y.p, b.p                                 # b now holds the result; y's finalizer frees the old storage
+    return
+end
+
+# ldiv!(H, b) (overwrites b) / ldiv!(y, H, b): src/solvers.jl:63-92 -- one V-cycle from a zero guess
+function la.ldiv!(Hd::DeviceHierarchy, b::AbstractVector)
+    b[:] = multigrid_v_cycle(Hd, zeros(size(Hd.H.mStiffness[1], 1)), b); return
+end
+function la.ldiv!(y::AbstractVector, Hd::DeviceHierarchy, b::AbstractVector)
+    y[:] = multigrid_v_cycle(Hd, zeros(size(Hd.H.mStiffness[1], 1)), b); return
+end
 
 # multigrid(H, x0, b, maxiter, tol) -> x, iter, res, err   (src/solvers.jl:116-139): a METHOD OF THE
-# REFERENCE'S FUNCTION for DeviceHierarchy.  The loop, the residual norms and the stopping test (:131)
-# stay on the device (aggmg_multigrid_dev).  The reference's `err` history needs the fine-level direct
-# solve of :120; with exact = true (default, reference behaviour) it is computed on the host from the
-# iterates, which then come back after every cycle; exact = false returns `err` empty and keeps the
-# iterate in HBM.  nPre / nPost / alpha: the defaults of multigrid_v_cycle, as the reference's loop uses.
-function multigrid(Hd::DeviceHierarchy, x0::AbstractVector, b::AbstractVector, maxiter::Integer,
-        tol::AbstractFloat; nPre::Integer = 3, nPost::Integer = 3, alpha::AbstractFloat = 2.0 / 3.0,
-        exact::Bool = true, check_every::Integer = 1)
+# REFERENCE'S FUNCTION for DeviceHierarchy.  The loop, the residual norms and the stopping test (:131) run on the
+# device (aggmg_multigrid_dev): x0 and b go up once, x comes back once.  The reference's `err` history needs the
+# fine-level sparse direct solve of :120 and every iterate on the host; it is computed only on request
+# (exact = true: the reference's loop, one PCIe round trip per cycle) -- by default `err` comes back empty.
+# nPre / nPost / alpha: the defaults of multigrid_v_cycle, as the reference's loop uses.  x0, b may be
+# DeviceVectors, in which case x is one too and nothing but the residual norms leaves the device.
+function multigrid(Hd::DeviceHierarchy, x0::Union{AbstractVector,DeviceVector}, b::Union{AbstractVector,DeviceVector},
+        maxiter::Integer, tol::AbstractFloat; nPre::Integer = 3, nPost::Integer = 3,
+        alpha::AbstractFloat = 2.0 / 3.0, exact::Bool = false, check_every::Integer = 1)
     if exact
-        u_exact = Hd.H.mStiffness[1] \ b
-        x = zeros(length(x0)); x0v = Vector{Float64}(x0)
+        x0h = x0 isa DeviceVector ? download(x0) : Vector{Float64}(x0)
+        bh = b isa DeviceVector ? download(b) : Vector{Float64}(b)
+        u_exact = Hd.H.mStiffness[1] \ bh
+        x = zeros(length(x0h))
         err = zeros(maxiter); res = zeros(maxiter); iter = maxiter
         for i in 1:maxiter
-            x = multigrid_v_cycle(Hd, x0v, b; nPre = nPre, nPost = nPost, alpha = alpha)
-            x0v = x
+            x = multigrid_v_cycle(Hd, x0h, bh; nPre = nPre, nPost = nPost, alpha = alpha)
+            x0h = x
             err[i] = la.norm(x - u_exact, 2)
-            res[i] = la.norm(Hd.H.mStiffness[1] * x - b, 2)
-            if res[i] < tol * la.norm(b, 2)
+            res[i] = la.norm(Hd.H.mStiffness[1] * x - bh, 2)
+            if res[i] < tol * la.norm(bh, 2)
                 iter = i
                 break
             end
         end
         return x, iter, res[1:iter], err[1:iter]
     end
-    N = length(b)
-    dx0 = DeviceVector(Hd.ctx, Vector{Float64}(x0)); db = DeviceVector(Hd.ctx, Vector{Float64}(b))
-    dx = DeviceVector(Hd.ctx, N)
+    on_device = x0 isa DeviceVector && b isa DeviceVector
+    dx0 = x0 isa DeviceVector ? x0 : DeviceVector(Hd.ctx, x0)
+    db = b isa DeviceVector ? b : DeviceVector(Hd.ctx, b)
+    dx = DeviceVector(Hd.ctx, db.n)
     res = zeros(cld(max(maxiter, 1), check_every)); ncyc = Ref{Cint}(0); nchk = Ref{Cint}(0)
     GC.@preserve res check(Hd.ctx.h, ccall((:aggmg_multigrid_dev, LIB), Cint,
         (Handle, Handle, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Float64, Cint, Cint, Cint, Float64, Ptr{Cvoid},
          Ptr{Float64}, Ref{Cint}, Ref{Cint}),
         Hd.ctx.h, Hd.h, dx0.p, db.p, maxiter, Float64(tol), check_every, nPre, nPost, Float64(alpha), dx.p,
         res, ncyc, nchk))
-    return download(dx), Int(ncyc[]), res[1:nchk[]], Float64[]
+    return (on_device ? dx : download(dx)), Int(ncyc[]), res[1:nchk[]], Float64[]
 end
 
 # iterative_smoother_solve(A, smoother, x0, b; maxiter = 1000, tol = 1e-6, alpha = 1.0) -> x, iter, res, err
@@ -384,9 +425,9 @@ end
 # direct solve of :194 when exact = true), the sweeps run on S.A
 function iterative_smoother_solve(A::sp.SparseMatrixCSC{Float64,Int64}, S::DeviceSmoother, x0::AbstractVector,
         b::AbstractVector; maxiter::Integer = 1000, tol::AbstractFloat = 1e-6, alpha::AbstractFloat = 1.0,
-        exact::Bool = true)
+        exact::Bool = false)
     N = length(b)
-    dx0 = DeviceVector(S.ctx, Vector{Float64}(x0)); db = DeviceVector(S.ctx, Vector{Float64}(b))
+    dx0 = DeviceVector(S.ctx, x0); db = DeviceVector(S.ctx, b)
     dx = DeviceVector(S.ctx, N)
     res = zeros(max(maxiter, 1)); nit = Ref{Cint}(0); nchk = Ref{Cint}(0)
     GC.@preserve res check(S.ctx.h, ccall((:aggmg_smoother_solve_dev, LIB), Cint,

@@ -255,3 +255,50 @@ def test_north_star_size_multigrid_converges():
     with pytest.raises(mg.UnsupportedError):
         H.set_restriction(_lib.RESTRICT_PRECONDITIONED)
     H.free()
+
+
+def test_ragged_agglomerates_at_size_fused_equals_unfused():
+    """the parent / first-child maps and the two-part atomic restriction of levels whose agglomerates
+    differ in size, at benchmark size: 2^20 DG p=3 elements on a perturbed mesh, three agglomerated levels with
+    agglomerate sizes drawn from {2, ..., 6} (product builders + device constructors).  The fused kernels against
+    the unfused composition (the same operators through the generic CSR / block kernels) on the residual at 1e-12
+    of the starting residual, linearity of the cycle, and the multi-cycle entry point against separate cycles."""
+    import agglomerationmultigrid1d_amd as mg
+    from agglomerationmultigrid1d_amd.uniform import build_device_ragged_hierarchy
+    ctx = mg.default_context()
+    H, b, info = build_device_ragged_hierarchy(2 ** 20, ctx, generic=True, seed=5)
+    Hg = info["generic"]
+    assert H.level_kinds() == ['fused_btd'] * 3 + ['coarsest'] and Hg.level_kinds() == ['generic'] * 3 + ['coarsest']
+    assert all(2.0 <= r <= 6.0 for r in info["mean_agglomerate"]) and len(set(info["elements"])) == 4
+    N = len(b)
+    bd, z = ctx.to_device(b), ctx.to_device(np.zeros(N))
+    xf, xg, r = ctx.alloc(N), ctx.alloc(N), ctx.alloc(N)
+    H.vcycle_dev(z, bd, xf)
+    Hg.vcycle_dev(z, bd, xg)
+    A0 = H._ops[0]
+    nb = np.linalg.norm(b)
+
+    def resid_of_diff(u, v):     # || A (u - v) ||   (z: a zero right-hand side that stays alive across the launch)
+        d = ctx.to_device(u.download() - v.download())
+        ctx.check(ctx.lib.aggmg_residual_dev(ctx.handle, A0.handle, d.ptr, z.ptr, r.ptr))
+        return np.linalg.norm(r.download())
+
+    rd = resid_of_diff(xf, xg)
+    xfh, xgh = xf.download(), xg.download()
+    print("ragged: ||A(xf-xg)||/||b|| =", rd / nb, " ||xf-xg||/||xf|| =", np.linalg.norm(xfh - xgh) / np.linalg.norm(xfh))
+    assert rd <= 1e-12 * nb
+    assert np.linalg.norm(xfh - xgh) <= 1e-10 * np.linalg.norm(xfh)
+    # the cycle contracts the residual, and is linear: V(0, 2 b) = 2 V(0, b)
+    ctx.check(ctx.lib.aggmg_residual_dev(ctx.handle, A0.handle, xf.ptr, bd.ptr, r.ptr))
+    assert np.linalg.norm(r.download()) < 0.5 * nb
+    x2 = ctx.alloc(N)
+    H.vcycle_dev(z, ctx.to_device(2.0 * b), x2)
+    assert np.linalg.norm(x2.download() - 2.0 * xf.download()) <= 1e-12 * np.linalg.norm(xf.download())
+    # three cycles in one call (atomic two-part restriction: equal to round-off, not bit for bit)
+    xa, xb = ctx.to_device(np.zeros(N)), ctx.alloc(N)
+    for _ in range(3):
+        H.vcycle_dev(xa, bd, xb)
+        xa, xb = xb, xa
+    xm = ctx.alloc(N)
+    H.vcycles_dev(z, bd, xm, 3)
+    assert resid_of_diff(xa, xm) <= 1e-12 * nb

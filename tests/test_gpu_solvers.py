@@ -121,3 +121,28 @@ def test_pcg_with_ldiv_preconditioner(oracle, mg):
     x0 = o.splitmix_normal(len(b), 9)
     xg2, it2, res2 = mg.pcg(H, b, x0=x0, maxiter=80, tol=1e-10)
     assert np.linalg.norm(A @ xg2 - b) <= 2e-10 * nb
+
+
+def test_v_cycle_on_device_vectors_equals_host_entry(oracle, mg):
+    """multigrid_v_cycle(H, x0, b) on DeviceVectors (the drop-in call kept device-resident: aggmg_vcycle_dev) returns a
+    DeviceVector with bit for bit the result of the host-array entry (aggmg_vcycle: same kernels, the copies staged
+    through pinned chunks by worker threads) -- at a size above the staging threshold, so that path runs -- and leaves
+    x0, b untouched"""
+    from agglomerationmultigrid1d_amd.uniform import UniformDgAggHierarchy, build_device_hierarchy
+    ctx = mg.default_context()
+    U = UniformDgAggHierarchy(2 ** 19, p=3, pAgg=1, ratios=(4, 2, 2))      # 16.8 MB vectors
+    H = build_device_hierarchy(U, ctx)
+    b = U.rhs()
+    N = len(b)
+    x0 = np.random.default_rng(3).standard_normal(N)
+    xh = mg.multigrid_v_cycle(H, x0, b)
+    d0, db = ctx.to_device(x0), ctx.to_device(b)
+    xd = mg.multigrid_v_cycle(H, d0, db)
+    assert isinstance(xd, mg.DeviceVector)
+    assert np.array_equal(xd.download(), xh)
+    assert np.array_equal(d0.download(), x0) and np.array_equal(db.download(), b)
+    xh2 = mg.multigrid_v_cycle(H, xh, b)                                    # the cached device vectors are reused
+    assert np.array_equal(mg.multigrid_v_cycle(H, xd, db).download(), xh2)
+    with pytest.raises(mg.DimensionMismatch):
+        mg.multigrid_v_cycle(H, ctx.alloc(N - 1), db)
+    H.free()
