@@ -182,19 +182,62 @@ def smoother_bench(mg, ctx, args, alpha):
                 ctx.check(lib.aggmg_residual_dev(ctx.handle, oph, _ptr(uu), _ptr(bb), _ptr(rr)))
         return run
 
-    for label, per_launch in (("sweeps_1_per_launch", 1), ("sweeps_4_per_launch", 4), ("sweeps_8_per_launch", 8)):
-        reps = 100 // per_launch
-        fn = sweeps(op.handle, S.handle, per_launch, u, v, b)
-        fn(2)
-        dt = _time_loop(ctx, fn, reps)
-        nsw = reps * per_launch
-        out[label] = {"dof_updates_per_s": N * nsw / dt, "us_per_sweep": 1e6 * dt / nsw,
-                      "algorithmic_GBs": S_bytes * nsw / dt / 1e9, "frac_of_8TBs": S_bytes * nsw / dt / 1e9 / HBM_PEAK_GBS}
-    fn = resid(op.handle, u, b, r)
-    fn(1)
-    dt = _time_loop(ctx, fn, 100)
-    out["residual"] = {"us_per_residual": 1e6 * dt / 100, "algorithmic_GBs": R_bytes * 100 / dt / 1e9,
-                       "frac_of_8TBs": R_bytes * 100 / dt / 1e9 / HBM_PEAK_GBS}
+    # Two ways to loop.  "same operator": one operator / smoother / vector set swept again and again -- ~250 MB, i.e.
+    # largely served by the 256 MB Infinity Cache (how r01 / r02 timed it: above the HBM copy ceiling).  "rotating":
+    # three independent copies taken in turn (~0.75 GB), so that every launch streams from HBM -- the figure to hold
+    # against the HBM roofline.  traffic / physical_frac: PMC bytes of exactly these launches
+    # (profiles/r03_dg_2p20_smoother_copies{1,3}.md via profiles/traffic.json).
+    sets = [(op, S, u, v, b, r)]
+    for _ in range(2):
+        o2 = mg.DeviceOperator(U.stiffness_csc(0), _lib.OP_STIFFNESS, ctx)
+        sets.append((o2, mg.BlockJacobi(o2, U.descriptor(0).mBlockInds, ctx), ctx.to_device(np.zeros(N)), ctx.alloc(N),
+                     ctx.to_device(U.rhs()), ctx.alloc(N)))
+
+    def rot_sweeps(per_launch, ncopies):
+        def run(reps):
+            for i in range(reps):
+                o_, s_, uu, vv, bb, _ = sets[i % ncopies]
+                ctx.check(lib.aggmg_smooth_dev(ctx.handle, o_.handle, s_.handle, _ptr(uu), _ptr(bb), alpha, per_launch, _ptr(vv)))
+        return run
+
+    def rot_resid(ncopies):
+        def run(reps):
+            for i in range(reps):
+                o_, _, uu, _, bb, rr = sets[i % ncopies]
+                ctx.check(lib.aggmg_residual_dev(ctx.handle, o_.handle, _ptr(uu), _ptr(bb), _ptr(rr)))
+        return run
+
+    def with_traffic(entry, key, ms_per_launch):
+        t = _traffic(f"smoother_{key}", "")
+        if isinstance(t, dict):
+            entry["traffic"] = t["hbm_bytes"]
+            entry["physical_frac"] = t["hbm_bytes"] / (ms_per_launch * 1e-3) / 1e9 / HBM_PEAK_GBS
+            entry["physical_frac_profile_mean"] = t["hbm_bytes"] / (t["ms_profile_mean"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+        return entry
+
+    for ncopies, suffix in ((1, ""), (3, "_rotating3")):
+        for label, per_launch in (("sweeps_1_per_launch", 1), ("sweeps_4_per_launch", 4), ("sweeps_8_per_launch", 8)):
+            reps = 96 // per_launch
+            fn = rot_sweeps(per_launch, ncopies)
+            fn(3)
+            dt = _time_loop(ctx, fn, reps)
+            nsw = reps * per_launch
+            out[label + suffix] = with_traffic(
+                {"dof_updates_per_s": N * nsw / dt, "us_per_sweep": 1e6 * dt / nsw, "algorithmic_GBs": S_bytes * nsw / dt / 1e9,
+                 "frac_of_8TBs": S_bytes * nsw / dt / 1e9 / HBM_PEAK_GBS,
+                 "data": "3 operator copies in turn (HBM)" if ncopies > 1 else "same operator every launch (Infinity-Cache assisted)"},
+                f"{label}_dg_log2n20_copies{ncopies}", 1e3 * dt / reps)
+        fn = rot_resid(ncopies)
+        fn(3)
+        dt = _time_loop(ctx, fn, 96)
+        out["residual" + suffix] = with_traffic(
+            {"us_per_residual": 1e6 * dt / 96, "algorithmic_GBs": R_bytes * 96 / dt / 1e9,
+             "frac_of_8TBs": R_bytes * 96 / dt / 1e9 / HBM_PEAK_GBS,
+             "data": "3 operator copies in turn (HBM)" if ncopies > 1 else "same operator every launch (Infinity-Cache assisted)"},
+            f"residual_dg_log2n20_copies{ncopies}", 1e3 * dt / 96)
+    for o_, s_, *_ in sets[1:]:
+        del o_, s_
+    del sets
     out["workload"] = f"config 2: DG n=2^20 p={args.p}, block-Jacobi m={args.p + 1}, N={N}, nnz(A)={nnzA}"
     # the generic CSR kernels (unstructured operators) on the same matrix: fused point-Jacobi sweep and CSR
     # residual, int32 indices + fp64 values actually read
@@ -322,7 +365,7 @@ def _traffic(role, tag):
     if not os.path.exists(tfile):
         return None
     try:
-        return json.load(open(tfile)).get(f"{role}_{tag}")
+        return json.load(open(tfile)).get(f"{role}_{tag}" if tag else role)
     except Exception:
         return None
 
@@ -407,6 +450,7 @@ def cg_bench(mg, ctx, args, nPre, nPost, alpha):
     per_launch = nPre * lm['sweep'] + lm['residual'] + lm['restrict']
     achieved = per_launch / (dms / dcnt * 1e-3) / 1e9
     traffic = _traffic("chain_down_L0", f"cg_log2n{E}")
+    prof_ms = _traffic("chain_down_L0", f"cg_log2n{E}_ms_profile_mean")
     coarse_ms = kern.get("coarse_L3", {}).get("ms_per_launch", 0.0)
     outer = {}
     try:
@@ -427,6 +471,7 @@ def cg_bench(mg, ctx, args, nPre, nPost, alpha):
                          "frac_basis": "algorithmic", "traffic": traffic, "algorithmic_bytes_per_launch": per_launch,
                          "physical_GBs": (traffic / (dms / dcnt * 1e-3) / 1e9) if traffic else None,
                          "physical_frac": (traffic / (dms / dcnt * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                         "physical_frac_profile_mean": (traffic / (prof_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic and prof_ms else None,
                          "ms_per_launch": dms / dcnt, "launches_timed": dcnt},
             "kernels": kern, "coarse_solve_ms_per_step": coarse_ms, "outer_solvers_to_1e-8": outer,
             "block_gs_extension": gs,
@@ -586,6 +631,7 @@ def main():
                   "fused_up": nPost * lm['sweep'] + lm['prolong']}.get(dkind, lm['sweep'])
     achieved = per_launch / (dms / dcnt * 1e-3) / 1e9
     traffic = _traffic(f"{dkind}_L{dlevel}", f"dg_log2n{args.log2_elems}")
+    prof_ms = _traffic(f"{dkind}_L{dlevel}", f"dg_log2n{args.log2_elems}_ms_profile_mean")
     kern_ms = {f"{k}_L{l}": {"ms_per_launch": v[0] / v[1], "launches": v[1]} for (k, l), v in sorted(prof.items())}
     coarse_dev = [v["ms_per_launch"] for k, v in kern_ms.items() if k.startswith("coarse_")]
     coarse_step_ms = coarse_dev[0] if coarse_dev else 0.0
@@ -608,7 +654,12 @@ def main():
                                + (" (north-star 1-vs-8-GPU size; config 3's own 2^22 in config3_2p22)"
                                   if args.log2_elems == 24 else ""),
                    "fine_dofs": N, "level_dofs": level_sizes, "nPre": nPre, "nPost": nPost,
-                   "parallelism": "single GPU"},
+                   "parallelism": "single GPU",
+                   "sizes_by_leg": {"value / roofline": f"2^{args.log2_elems} fine elements",
+                                    "config3_2p22": f"2^{args.also_log2_elems}" if args.also_log2_elems else None,
+                                    "cpu_baseline": None if args.no_cpu_baseline else f"2^{args.cpu_log2_elems} fine elements (rate-normalised: DoF-updates/s)",
+                                    "config5": f"2^{args.cg_log2_elems}" if args.cg_log2_elems else None,
+                                    "smoother_only (config 2)": "2^20", "ragged": f"2^{args.ragged_log2_elems}" if args.ragged_log2_elems else None}},
         "achieved_algorithmic_GBs_vcycle": vcycle_bytes * args.steps / dt / 1e9,
         "vcycles_loop": {"value": N * (nPre + nPost) * args.steps / dt_loop, "unit": "DoF-updates/s",
                          "ms_per_cycle": 1e3 * dt_loop / args.steps,
@@ -627,6 +678,9 @@ def main():
                      "traffic": traffic, "algorithmic_bytes_per_launch": per_launch,
                      "physical_GBs": (traffic / (dms / dcnt * 1e-3) / 1e9) if traffic else None,
                      "physical_frac": (traffic / (dms / dcnt * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                     # the same bytes over the profile's own mean duration of this launch role (profiles/*_roles.md):
+                     # the figure a reader of profiles/ recomputes
+                     "physical_frac_profile_mean": (traffic / (prof_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic and prof_ms else None,
                      "ms_per_launch": dms / dcnt, "launches_timed": dcnt,
                      "note": "achieved / frac: ALGORITHMIC bytes per launch (SURVEY 8d model: CSR int32 + fp64, every "
                              "sweep re-reading the operator) / HIP-event duration; the fused kernel reads the operator "

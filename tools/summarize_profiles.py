@@ -140,6 +140,7 @@ for nm in names:
     if hb is not None and nm.startswith("fused_"):
         key = nm.replace("fused_", "chain_") if kind == "cg" else nm
         traffic[f"{key}_{kind}_log2n{E}"] = hb
+        traffic[f"{key}_{kind}_log2n{E}_ms_profile_mean"] = statistics.mean(vals)   # the kernel-trace mean of the same role
 tot = sum(statistics.mean(dur[nm][0]) for nm in names)
 lines += ["", f"Sum of the mean kernel durations of one cycle: {tot:.4f} ms.",
           f"rocprofv3's own per-kernel stats of the same trace: profiles/{base}_kernel_stats.csv."]
