@@ -436,11 +436,13 @@ struct TileSel {
 
 // the structured transfer of a level as the fused kernel's prolongation input / restriction output
 static void xfer_in(FusedArgs& a, const TransferBtd& t) {
+  a.lf1_in = t.lf1;
   a.mc_in = t.mc;
   a.rho_in = t.rho;
   a.par_in = t.rho ? nullptr : t.parent;
 }
 static void xfer_out(FusedArgs& a, const TransferBtd& t) {
+  a.lf1_out = t.lf1;
   a.mc_out = t.mc;
   a.rho_out = t.rho;
   a.par_out = t.rho ? nullptr : t.parent;

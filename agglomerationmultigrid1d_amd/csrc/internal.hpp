@@ -157,11 +157,13 @@ struct TransferBtd {
   int mc = 0, rho = 0;   // rho: fine elements per coarse element; 0 = agglomerates of different sizes (parent / first)
   int64_t nec = 0;
   double* lf = nullptr;  // [N_f][mc]  rows of L
+  double* lf1 = nullptr; // [N_f]      their second entries when mc == 2 and every first entry is exactly 1.0, else null
   double* ld = nullptr;  // [N_f][mc]  rows of (L_e' D_e)': restriction of the preconditioned residual
   int32_t* parent = nullptr;  // [ne_f]      coarse element of every fine element      (rho == 0)
   int32_t* first = nullptr;   // [ne_c + 1]  first fine element of every coarse element (rho == 0)
   ~TransferBtd() {
     if (lf) (void)hipFree(lf);
+    if (lf1) (void)hipFree(lf1);
     if (ld) (void)hipFree(ld);
     if (parent) (void)hipFree(parent);
     if (first) (void)hipFree(first);

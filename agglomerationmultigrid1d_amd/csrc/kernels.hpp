@@ -365,12 +365,16 @@ struct FusedArgs {
   int nsweeps;
   // optional prolongation-add before the sweeps: u += LF_in * uc   (src/solvers.jl:42)
   const double* lf_in;  // [N][mc_in] rows of L for the owning coarse element
+  const double* lf1_in;  // [N] second entries of those rows when mc_in == 2 and every first entry is exactly 1.0
+                         // (detected at set-up: the constant mode of an agglomerate's modal basis evaluated at the
+                         // fine nodes, src/agglomerated_dg_mesh.jl:297-315) -- half the transfer bytes; else null
   const double* uc;
   int mc_in, rho_in;
   // optional residual after the sweeps (src/solvers.jl:36), stored and/or restricted
   int do_residual;
   double* r_out;         // may be nullptr
   const double* lf_out;  // [N][mc_out] rows of L: rc = L' r from the explicit residual
+  const double* lf1_out; // [N] as lf1_in, for lf_out
   const double* ld_out;  // [N][mc_out] rows of (L_e' D_e)': rc = (L'D) w, w = B^{-1} r -- no D, no L read
   double* rc_out;        // restricted residual
   int mc_out, rho_out;
@@ -504,9 +508,14 @@ __global__ __launch_bounds__(NT) void btd_fused_kernel(FusedArgs a) {
       bb[s] = a.b[row];
       if (a.u_in) uu[s] = a.u_in[row];
       if (pre2) {
-        const double2 t2 = *reinterpret_cast<const double2*>(lfo_pre + row * 2);
-        l2x[s] = t2.x;
-        l2y[s] = t2.y;
+        if (a.lf1_out && !a.ld_out) {   // unit first column: 1.0 * r is r, bit for bit what the stored 1.0 gives
+          l2x[s] = 1.0;
+          l2y[s] = AGGMG_LD(a.lf1_out[row]);
+        } else {
+          const double2 t2 = *reinterpret_cast<const double2*>(lfo_pre + row * 2);
+          l2x[s] = t2.x;
+          l2y[s] = t2.y;
+        }
       }
       if (CMP) {
         if (SYM) {
@@ -539,10 +548,15 @@ __global__ __launch_bounds__(NT) void btd_fused_kernel(FusedArgs a) {
         double add = 0.0;
         if (a.mc_in == 2) {  // one 16-byte load each for the L row and the coarse pair
           typedef double v2d __attribute__((ext_vector_type(2)));
-          const v2d lv2 = AGGMG_LD(*reinterpret_cast<const v2d*>(a.lf_in + row * 2));
           double2 l2;
-          l2.x = lv2.x;
-          l2.y = lv2.y;
+          if (a.lf1_in) {
+            l2.x = 1.0;
+            l2.y = AGGMG_LD(a.lf1_in[row]);
+          } else {
+            const v2d lv2 = AGGMG_LD(*reinterpret_cast<const v2d*>(a.lf_in + row * 2));
+            l2.x = lv2.x;
+            l2.y = lv2.y;
+          }
           const double2 u2 = *reinterpret_cast<const double2*>(a.uc + J * 2);
           add = l2.x * u2.x;
           add += l2.y * u2.y;

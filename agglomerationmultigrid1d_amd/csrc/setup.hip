@@ -390,6 +390,25 @@ int setup_block_smoother(aggmg_ctx* ctx, aggmg_smoother* sm, const int64_t* bloc
 // ---------------------------------------------------------------------------------------------
 // structured transfer of a block-tridiagonal level
 // ---------------------------------------------------------------------------------------------
+// two-mode transfers whose first column is exactly 1.0 in every row (the constant mode of an agglomerate's modal basis
+// at the fine nodes): keep the second column on its own, the fused kernels then read 8 instead of 16 bytes per row
+static int setup_unit_column(aggmg_ctx* ctx, TransferBtd* t, int64_t Nf) {
+  static const bool on = [] {
+    const char* e = std::getenv("AGGMG_UNIT_COLUMN");
+    return !(e && e[0] == '0');
+  }();
+  if (!on || t->mc != 2 || Nf == 0) return AGGMG_OK;
+  Flags f;
+  CHECK(f.init(ctx, 1));
+  LAUNCH(transfer_unit_check_kernel, Nf, Nf, (const double*)t->lf, f.d);
+  int notone = 0;
+  CHECK(f.read(ctx, &notone));
+  if (notone) return AGGMG_OK;
+  CHECK(dalloc(ctx, &t->lf1, Nf, false));
+  LAUNCH(transfer_second_column_kernel, Nf, Nf, (const double*)t->lf, t->lf1);
+  return AGGMG_OK;
+}
+
 int setup_transfer_btd(aggmg_ctx* ctx, const aggmg_op* L, const BtdDev* Abtd, int mf, int64_t nef, int hint_mc,
                        TransferBtd* out, bool* ok) {
   *ok = false;
@@ -423,6 +442,7 @@ int setup_transfer_btd(aggmg_ctx* ctx, const aggmg_op* L, const BtdDev* Abtd, in
     out->mc = mc;
     out->rho = (int)rho;
     out->nec = nec;
+    CHECK(setup_unit_column(ctx, out, Nf));
     *ok = true;
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return AGGMG_OK;
@@ -458,6 +478,7 @@ int setup_transfer_btd(aggmg_ctx* ctx, const aggmg_op* L, const BtdDev* Abtd, in
     out->mc = mc;
     out->rho = 0;
     out->nec = nec;
+    CHECK(setup_unit_column(ctx, out, Nf));
     *ok = true;
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return AGGMG_OK;

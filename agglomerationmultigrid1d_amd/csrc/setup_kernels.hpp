@@ -124,6 +124,17 @@ __global__ __launch_bounds__(kSetupThreads) void inds_convert_kernel(int64_t tot
   if (before > 0.0) flags[2] = 1;
 }
 
+// rows [a, b] of a two-mode transfer: *flag != 0 unless every a is exactly 1.0; the b column on its own
+__global__ __launch_bounds__(kSetupThreads) void transfer_unit_check_kernel(int64_t n, const double* __restrict__ lf, int* flag) {
+  const int64_t i = (int64_t)blockIdx.x * kSetupThreads + threadIdx.x;
+  if (i < n && lf[2 * i] != 1.0) *flag = 1;
+}
+__global__ __launch_bounds__(kSetupThreads) void transfer_second_column_kernel(int64_t n, const double* __restrict__ lf,
+                                                                               double* __restrict__ lf1) {
+  const int64_t i = (int64_t)blockIdx.x * kSetupThreads + threadIdx.x;
+  if (i < n) lf1[i] = lf[2 * i + 1];
+}
+
 // dense blocks A[inds_k, inds_k] for arbitrary (possibly overlapping) index lists: one thread per entry
 __global__ __launch_bounds__(kSetupThreads) void block_extract_generic_kernel(int64_t nb, int m,
                                                                               const int32_t* __restrict__ inds,
