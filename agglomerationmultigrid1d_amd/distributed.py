@@ -822,7 +822,8 @@ def _replicated_coarse_hierarchy(Ac, ctx, world):
     from . import _lib
     from .api import MeshHierarchy
     if world > 1:
-        ctx.set_option(_lib.OPT_COARSE_CHUNK_LOG2, 10)
+        # (measured on one rank's share of an 8-rank 2^24 job: AGGMG_DIST_COARSE_CHUNK_LOG2 = 9 / 10 / 11 / 12)
+        ctx.set_option(_lib.OPT_COARSE_CHUNK_LOG2, int(os.environ.get("AGGMG_DIST_COARSE_CHUNK_LOG2", "10")))
     try:
         return MeshHierarchy(None, [Ac], [], [], ctx=ctx, keep_host=False, coarse_mode=_lib.COARSE_AUTO)
     finally:

@@ -106,10 +106,11 @@ F, W = pmc("fetch"), pmc("write")
 # bytes the kernel's arrays hold per launch (known counts, halo re-reads not included): the calibration
 # of the PMC figures on this access pattern
 if kind == "dg":
-    # per fine element (m = 4): packed symmetric inverse 80, q row 32, b 32, u 32, L rows 64; the explicit
-    # residual behind the restriction also reads the diagonal block 128 and the sub-diagonal column 32
-    expected = {"fused_down_L0": ((80 + 32 + 32 + 32 + 64 + 128 + 32) * ne, (32 + 4) * ne),
-                "fused_up_L0": ((80 + 32 + 32 + 32 + 64 + 4) * ne, 32 * ne)}
+    # per fine element (m = 4): packed symmetric inverse 80, q row 32, b 32, u 32, L rows 32 (r03: the unit first
+    # column of the two-mode transfer is not stored, r02: 64); the explicit residual behind the restriction also
+    # reads the diagonal block 128 and the sub-diagonal column 32
+    expected = {"fused_down_L0": ((80 + 32 + 32 + 32 + 32 + 128 + 32) * ne, (32 + 4) * ne),
+                "fused_up_L0": ((80 + 32 + 32 + 32 + 32 + 4) * ne, 32 * ne)}
 else:
     # per fine block of 4 rows: dblk 128 + subrow 32 + supcol 32, b 32, u 32, perm 16, L rows 96 (3 per row)
     expected = {"fused_down_L0": ((192 + 32 + 32 + 16 + 96) * ne, (32 + 16) * ne),
