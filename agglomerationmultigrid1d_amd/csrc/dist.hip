@@ -157,6 +157,10 @@ struct aggmg_dist {
   aggmg_sendrecv_fn fn_p2p = nullptr;
   void* user = nullptr;
   ncclComm_t comm = nullptr;
+  // a communicator of its own for the side stream: two operations of ONE communicator in flight on two streams may
+  // start in a different order on different ranks and wait for each other; with one communicator per stream every
+  // communicator sees its operations in one order on every rank
+  ncclComm_t comm_side = nullptr;
   // interface exchange of the next cycle's x0 under the fine-level ascent
   hipStream_t side = nullptr;
   hipEvent_t ev_main = nullptr, ev_ends = nullptr, ev_side = nullptr;
@@ -183,9 +187,10 @@ struct aggmg_dist {
   bool graph_broken = false;    // a capture failed once (e.g. the collective backend cannot be captured): stay eager
   int64_t graph_replays = 0;
   ~aggmg_dist() {
-    if (comm) {
-      if (RcclApi* a = rccl_api(nullptr)) (void)a->CommDestroy(comm);
-    }
+    for (ncclComm_t c : {comm, comm_side})
+      if (c) {
+        if (RcclApi* a = rccl_api(nullptr)) (void)a->CommDestroy(c);
+      }
     for (auto& g : graphs)
       if (g.exec) (void)hipGraphExecDestroy(g.exec);
     for (hipEvent_t e : {ev_main, ev_ends, ev_side})
@@ -193,6 +198,11 @@ struct aggmg_dist {
     if (side) (void)hipStreamDestroy(side);
   }
 };
+
+// the communicator of the stream the call is issued on
+static ncclComm_t comm_for(const aggmg_ctx* ctx, const aggmg_dist* d) {
+  return (ctx->stream == d->side && d->comm_side) ? d->comm_side : d->comm;
+}
 
 static int dist_allgather(aggmg_ctx* ctx, aggmg_dist* d, const double* send, double* recv, int64_t count) {
   d->exchanges += 1;
@@ -208,7 +218,7 @@ static int dist_allgather(aggmg_ctx* ctx, aggmg_dist* d, const double* send, dou
     }
     case 2: {
       RcclApi* a = rccl_api(nullptr);
-      const ncclResult_t r = a->AllGather(send, recv, (size_t)count, ncclDouble, d->comm, ctx->stream);
+      const ncclResult_t r = a->AllGather(send, recv, (size_t)count, ncclDouble, comm_for(ctx, d), ctx->stream);
       if (r != ncclSuccess) return fail(ctx, AGGMG_ERR_HIP, std::string("ncclAllGather: ") + a->GetErrorString(r));
       return AGGMG_OK;
     }
@@ -304,12 +314,13 @@ static int neighbor_exchange(aggmg_ctx* ctx, aggmg_dist* d, double* x, int slot)
   switch (d->backend) {
     case 2: {
       RcclApi* a = rccl_api(nullptr);
+      const ncclComm_t comm = comm_for(ctx, d);
       ncclResult_t st = a->GroupStart();
       auto post = [&](const std::vector<NbSeg>& out, const std::vector<NbSeg>& in, int peer) {
         for (const NbSeg& g : out)
-          if (st == ncclSuccess && g.len > 0) st = a->Send(x + g.off, (size_t)g.len, ncclDouble, peer, d->comm, ctx->stream);
+          if (st == ncclSuccess && g.len > 0) st = a->Send(x + g.off, (size_t)g.len, ncclDouble, peer, comm, ctx->stream);
         for (const NbSeg& g : in)
-          if (st == ncclSuccess && g.len > 0) st = a->Recv(x + g.off, (size_t)g.len, ncclDouble, peer, d->comm, ctx->stream);
+          if (st == ncclSuccess && g.len > 0) st = a->Recv(x + g.off, (size_t)g.len, ncclDouble, peer, comm, ctx->stream);
       };
       if (hasL) post(L.to_left, L.from_left, r - 1);
       if (hasR) post(L.to_right, L.from_right, r + 1);
@@ -593,20 +604,27 @@ extern "C" int aggmg_dist_init_rccl(aggmg_ctx* ctx, aggmg_dist* d, const void* i
   RcclApi* a = rccl_api(&why);
   if (!a) return fail(ctx, AGGMG_ERR_UNSUPPORTED, why);
   HIPCHK(hipSetDevice(ctx->device));
-  ncclUniqueId uid;
-  std::memcpy(&uid, id, sizeof(uid));
-  ncclComm_t comm = nullptr;
-  ncclResult_t r = a->CommInitRank(&comm, d->world, uid, d->rank);
-  if (r != ncclSuccess) return fail(ctx, AGGMG_ERR_HIP, std::string("ncclCommInitRank: ") + a->GetErrorString(r));
+  // one id: one communicator; two ids back to back (2 * AGGMG_RCCL_ID_BYTES): a second communicator for the side stream
+  const int nid = nbytes >= 2 * AGGMG_RCCL_ID_BYTES ? 2 : 1;
+  ncclComm_t made[2] = {nullptr, nullptr};
   int cnt = 0;
-  r = a->CommCount(comm, &cnt);
-  if (r != ncclSuccess || cnt != d->world) {
-    (void)a->CommDestroy(comm);
-    return fail(ctx, AGGMG_ERR_HIP, "aggmg_dist_init_rccl: communicator reports " + std::to_string(cnt) + " ranks, expected " +
-                                        std::to_string(d->world));
+  for (int k = 0; k < nid; ++k) {
+    ncclUniqueId uid;
+    std::memcpy(&uid, static_cast<const char*>(id) + (size_t)k * AGGMG_RCCL_ID_BYTES, sizeof(uid));
+    ncclResult_t r = a->CommInitRank(&made[k], d->world, uid, d->rank);
+    if (r == ncclSuccess) r = a->CommCount(made[k], &cnt);
+    if (r != ncclSuccess || cnt != d->world) {
+      for (ncclComm_t c : made)
+        if (c) (void)a->CommDestroy(c);
+      if (r != ncclSuccess) return fail(ctx, AGGMG_ERR_HIP, std::string("ncclCommInitRank: ") + a->GetErrorString(r));
+      return fail(ctx, AGGMG_ERR_HIP, "aggmg_dist_init_rccl: communicator reports " + std::to_string(cnt) + " ranks, expected " +
+                                          std::to_string(d->world));
+    }
   }
-  if (d->comm) (void)a->CommDestroy(d->comm);
-  d->comm = comm;
+  for (ncclComm_t c : {d->comm, d->comm_side})
+    if (c) (void)a->CommDestroy(c);
+  d->comm = made[0];
+  d->comm_side = made[1];
   d->backend = 2;
   if (nranks_out) *nranks_out = cnt;
   return AGGMG_OK;

@@ -522,11 +522,15 @@ class NativeDistributedVCycle:
         import torch
         from . import _lib
         ctx, c = self.ctx, self.c
-        buf = (ctypes.c_ubyte * _lib.RCCL_ID_BYTES)()
+        nb = 2 * _lib.RCCL_ID_BYTES        # two ids: a communicator per stream (main, side)
+        buf = (ctypes.c_ubyte * nb)()
         failed = None
         if c.rank == 0:
             try:
-                ctx.check(ctx.lib.aggmg_rccl_unique_id(ctx.handle, buf, _lib.RCCL_ID_BYTES))
+                for k in range(2):
+                    one = (ctypes.c_ubyte * _lib.RCCL_ID_BYTES)()
+                    ctx.check(ctx.lib.aggmg_rccl_unique_id(ctx.handle, one, _lib.RCCL_ID_BYTES))
+                    buf[k * _lib.RCCL_ID_BYTES:(k + 1) * _lib.RCCL_ID_BYTES] = list(one)
             except Exception as exc:      # still take part in the broadcast below: the other ranks are waiting in it
                 failed = exc
         if c.world > 1:
@@ -538,11 +542,11 @@ class NativeDistributedVCycle:
             vals = t.cpu().tolist()
             if not vals[-1]:
                 raise failed or RuntimeError("rank 0 could not create the RCCL unique id")
-            buf = (ctypes.c_ubyte * _lib.RCCL_ID_BYTES)(*vals[:-1])
+            buf = (ctypes.c_ubyte * nb)(*vals[:-1])
         elif failed:
             raise failed
         n = ctypes.c_int(0)
-        ctx.check(ctx.lib.aggmg_dist_init_rccl(ctx.handle, self.handle, buf, _lib.RCCL_ID_BYTES, ctypes.byref(n)))
+        ctx.check(ctx.lib.aggmg_dist_init_rccl(ctx.handle, self.handle, buf, nb, ctypes.byref(n)))
         self.rccl_ranks = n.value
 
     def _torch_allgather(self, user, send, recv, count, stream):

@@ -330,7 +330,10 @@ int aggmg_dist_free(aggmg_ctx* ctx, aggmg_dist* d);
  *  - RCCL inside the library: rank 0 calls aggmg_rccl_unique_id, the AGGMG_RCCL_ID_BYTES bytes travel to
  *    every rank by any means (they are not secret and small), every rank calls aggmg_dist_init_rccl
  *    (ncclCommInitRank; collective).  librccl.so.1 is loaded with dlopen on first use -- the copy already
- *    in the process if there is one.  nranks_out receives what the communicator reports.
+ *    in the process if there is one.  nranks_out receives what the communicator reports.  Handing over TWO ids back
+ *    to back (nbytes = 2 * AGGMG_RCCL_ID_BYTES, two calls of aggmg_rccl_unique_id) gives the second stream -- the
+ *    interface exchange issued under the fine-level ascent -- a communicator of its own: operations of one
+ *    communicator in flight on two streams may start in a different order on different ranks and wait for each other.
  *  - a caller-supplied all-gather: recv_dev[r * count + i] = rank r's send_dev[i], ordered on hip_stream
  *    after everything enqueued there so far; returns 0 on success.
  *  - a device-local loop-back (every slot receives the caller's own data): rehearsals of one rank's

@@ -141,7 +141,7 @@ def test_four_ranks_overlapped_interface_exchange():
 
 @pytest.mark.parametrize("world,n,overlap,nex,p2p", [(2, 2048, False, 6, True), (2, 2**16, False, 9, True),
                                                      (4, 2**16, False, 9, True), (4, 2**16, True, 10, True),
-                                                     (3, 3 * 2**14, True, None, True),
+                                                     (3, 3 * 2**14, True, None, True), (4, 2**20, True, 10, True),
                                                      (4, 2**16, True, 10, False), (2, 2048, False, 6, False)])
 def test_native_schedule_matches_single_gpu(world, n, overlap, nex, p2p):
     """aggmg_dist_vcycle_dev (the schedule in C++, csrc/dist.hip) with its collectives routed through gloo:
@@ -165,6 +165,8 @@ def test_native_schedule_matches_single_gpu(world, n, overlap, nex, p2p):
         assert err == 0.0, (rank, err, scale)
         # (three ranks: 2^14 coarsest blocks per rank are whole chunks, but the plan's chunk size decides)
         assert nex is None or (got_nex == nex and chunked == (n >= 2**16)), (chunked, got_nex)
+    # (2^20 elements on four ranks: 2^18 per rank, 2^14 coarsest blocks each -- the partitioned path at a size where every
+    # rank runs many tiles per level and several chunks of the coarsest solve; the 8-rank 2^24 job itself needs 8 GPUs)
 
 
 def test_block_gauss_seidel_partitioned():
