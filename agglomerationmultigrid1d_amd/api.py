@@ -182,9 +182,14 @@ class DeviceOperator:
             m, n, colptr, rowval, nzval = A[:5]
             one_based = int(A[5]) if len(A) > 5 else 1
         else:
-            if not sp.issparse(A):
-                raise ArgumentError("DeviceOperator: dense operators are not supported "
-                                    "(the hierarchy constructors only produce sparse transfers)")
+            if isinstance(A, np.ndarray) and A.ndim == 2:
+                # a dense Matrix{Float64} in mInterpolation::Vector{AbstractMatrix{Float64}} (src/mesh_heirarchy.jl:26;
+                # dg_cg_interpolation(..., 0) returns one): its non-zero entries as a CSC operator -- `L * v` and
+                # `L' * v` add the same products in the same order
+                A = sp.csc_matrix(A)
+            elif not sp.issparse(A):
+                raise ArgumentError("DeviceOperator: a SparseMatrixCSC (SciPy sparse matrix), the (m, n, colptr, rowval, "
+                                    "nzval) arrays of one, or a dense 2-D array")
             A = sp.csc_matrix(A)
             A.sort_indices()
             m, n = A.shape

@@ -15,11 +15,11 @@ once on the reference element and scaled, instead of point by point per element)
 
     cg_cg_interpolation(low, high)                 src/interpolation.jl:5-55
     dg_dg_interpolation(low, high)                 :91-109
-    dg_cg_interpolation(low, high, interpFlag)     :145-220   (interpFlag 1, 2; 0 returns a dense matrix in the reference)
+    dg_cg_interpolation(low, high, interpFlag)     :145-220   (interpFlag 0 -- dense, as in the reference --, 1, 2)
     aggdg_aggdg_interpolation(coarse, fine)        :226-264
     aggdg_dg_interpolation(agg, base)              :270-292
     aggdg_dg_interpolation2(agg, base)             :294-324
-    aggdg_cg_interpolation(agg, base, interpFlag)  :330-410   (interpFlag 1, 2)
+    aggdg_cg_interpolation(agg, base, interpFlag)  :330-410   (interpFlag 0 -- dense --, 1, 2)
 
 Every builder returns a SciPy CSC matrix with sorted indices (hand it to DeviceOperator / MeshHierarchy).
 Checked against the loop-for-loop oracle on non-uniform meshes with ragged agglomerates in
@@ -101,6 +101,17 @@ class CgMesh(_Mesh1d):
     def mBlockInds(self):
         """the element node lists in the slot cg_smoother(mesh, A, ...) looks at (src/smoother.jl:88-139)"""
         return self.element_nodes()
+
+    def mass_matrix(self):
+        """mMassMatrix (src/cg_mesh.jl:67-75): J_e * M_ref of every element scattered to its nodes, duplicates at shared
+        vertices summed (element k-1 first, the order `sparse` meets them) -> scipy CSC"""
+        import scipy.sparse as sp
+        el = self.element_nodes() - 1                                   # (p+1, n)
+        m = self.mP + 1
+        rows = np.broadcast_to(el.T[:, :, None], (self.n, m, m))
+        cols = np.broadcast_to(el.T[:, None, :], (self.n, m, m))
+        vals = self.J[:, None, None] * self.ref.mass[None, :, :]
+        return sp.csc_matrix((vals.reshape(-1), (rows.reshape(-1), cols.reshape(-1))), shape=(self.mNumNodes, self.mNumNodes))
 
     def lumped_mass(self):
         """lumped[j] = sum(mMassMatrix[j, :]) (src/interpolation.jl:207-211): the rows of J_e * M_ref summed, vertex
@@ -250,6 +261,16 @@ def _cg_rows_csc(T, cg, base_starts, mc, vertex_weight=None, row_scale=None):
     return _csc(colptr, rowval, nzval, (cg.mNumNodes, ne * mc))
 
 
+def _consistent_mass_solve(cg, N):
+    """`cg.mMassMatrixLU \\ Array(N)` (src/interpolation.jl:205,395): sparse LU of the consistent CG mass matrix (SuperLU
+    here, UMFPACK in the reference: equal to round-off), dense right-hand side, dense result"""
+    import scipy.sparse.linalg as spla
+    if cg.mNumNodes * N.shape[1] > (1 << 27):
+        raise UnsupportedError("interpFlag = 0 yields a dense matrix of %d x %d entries: meant for small meshes"
+                               % (cg.mNumNodes, N.shape[1]))
+    return spla.splu(cg.mass_matrix()).solve(N.toarray())
+
+
 def _nodal_basis_at(ref, x):
     """evaluate_nodal_basis_fun (src/reference_element.jl:75-90): one dot product per (point, function) -> (len(x), p+1)"""
     V = legendre_vandermonde(x, ref.p)
@@ -321,13 +342,16 @@ def _ref_l2_block(ref_rows, ref_cols):
 
 def dg_cg_interpolation(lowMesh, highMesh, interpFlag):
     """src/interpolation.jl:145-220: DG (coarser, `lowMesh`) -> CG (finer, `highMesh`) on the same faces.
-    interpFlag 1: lumped-mass L2 projection; 2: nodal evaluation, interior vertices averaged; 0 (consistent mass,
-    a DENSE matrix in the reference) is not offered."""
+    interpFlag 1: lumped-mass L2 projection; 2: nodal evaluation, interior vertices averaged; 0: the consistent-mass
+    L2 projection `mMassMatrixLU \\ Array(N)` (:205) -- a DENSE (mNumNodes x lowMesh.mNumNodes) ndarray, as in the
+    reference: O(n^2) storage, small meshes only (the hierarchy constructors hard-wire flag 1)."""
     _check_same_faces(lowMesh, highMesh)
     n = lowMesh.n
     starts = np.arange(n + 1, dtype=np.int64)
-    if interpFlag == 1:
+    if interpFlag in (0, 1):
         T = lowMesh.J[:, None, None] * _ref_l2_block(highMesh.ref, lowMesh.ref)[None, :, :]
+        if interpFlag == 0:
+            return _consistent_mass_solve(highMesh, _cg_rows_csc(T, highMesh, starts, lowMesh.m))
         return _cg_rows_csc(T, highMesh, starts, lowMesh.m, row_scale=highMesh.lumped_mass())
     if interpFlag == 2:
         lowVal = _nodal_basis_at(lowMesh.ref, highMesh.ref.nodes)
@@ -335,9 +359,6 @@ def dg_cg_interpolation(lowMesh, highMesh, interpFlag):
         w = np.full(n + 1, 0.5)
         w[0] = w[n] = 1.0                                             # isBoundary(vertex)
         return _cg_rows_csc(T, highMesh, starts, lowMesh.m, vertex_weight=w)
-    if interpFlag == 0:
-        raise UnsupportedError("dg_cg_interpolation: interpFlag = 0 yields a dense matrix (src/interpolation.jl:205); "
-                               "the device hierarchy takes sparse transfers only")
     raise ValueError("Only implemented for interpFlag = 0, 1, or 2.")
 
 
@@ -391,10 +412,12 @@ def aggdg_cg_interpolation(aggMesh, baseMesh, interpFlag):
         raise ArgumentError("aggdg_cg_interpolation: aggMesh must be a first-level agglomeration")
     _check_same_faces(aggMesh.base, baseMesh)
     ref = baseMesh.ref
-    if interpFlag == 1:
+    if interpFlag in (0, 1):
         aggV = evaluate_local_modal_basis_fun(aggMesh.mP, aggMesh.lo[aggMesh.elem_of_base][:, None],
                                               aggMesh.hi[aggMesh.elem_of_base][:, None], baseMesh.ref_map(ref.gq))
         T = np.einsum('k,l,li,klj->kij', baseMesh.J, ref.gw, ref.phi, aggV)
+        if interpFlag == 0:       # `mMassMatrixLU \\ Array(N)` (:395): dense, as in the reference
+            return _consistent_mass_solve(baseMesh, _cg_rows_csc(T, baseMesh, aggMesh.base_starts, aggMesh.m))
         return _cg_rows_csc(T, baseMesh, aggMesh.base_starts, aggMesh.m, row_scale=baseMesh.lumped_mass())
     if interpFlag == 2:
         T = evaluate_local_modal_basis_fun(aggMesh.mP, aggMesh.lo[aggMesh.elem_of_base][:, None],
@@ -402,7 +425,4 @@ def aggdg_cg_interpolation(aggMesh, baseMesh, interpFlag):
         w = np.full(baseMesh.n + 1, 0.5)
         w[0] = w[baseMesh.n] = 1.0
         return _cg_rows_csc(T, baseMesh, aggMesh.base_starts, aggMesh.m, vertex_weight=w)
-    if interpFlag == 0:
-        raise UnsupportedError("aggdg_cg_interpolation: interpFlag = 0 yields a dense matrix (src/interpolation.jl:395); "
-                               "the device hierarchy takes sparse transfers only")
     raise ValueError("Only implemented for interpFlag = 0, 1, or 2.")

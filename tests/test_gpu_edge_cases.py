@@ -277,3 +277,41 @@ def test_split_ascent_is_bitwise_the_plain_ascent(oracle, mg):
         H.vcycle_up_split_dev(b, out, head, tail, 1)
         assert np.array_equal(out.download(), ref), (head, tail)
 
+
+
+def test_dense_interpolation_matrix_through_the_device(oracle, mg):
+    """mInterpolation::Vector{AbstractMatrix{Float64}} may hold a dense Matrix: dg_cg_interpolation(..., interpFlag = 0)
+    returns `mMassMatrixLU \\ Array(N)` (src/interpolation.jl:205).  The product builder gives the same dense array, a
+    DeviceOperator takes it, `L' * r` / `u + L * u_c` (src/solvers.jl:36,42) and a two-level V-cycle with it as the
+    transfer match the dense NumPy arithmetic."""
+    import scipy.sparse as sp
+    from agglomerationmultigrid1d_amd import interpolation as ip
+    from agglomerationmultigrid1d_amd import _lib
+    o = oracle
+    n = 24
+    Ho, b = o.build_cg_hierarchy(n, ps=(2,), nDG=1, pDG=0)          # CG p=2 -> DG p=0, transfer built with flag 1
+    xv = np.linspace(0.0, 1.0, n + 1)
+    L = ip.dg_cg_interpolation(ip.DgMesh(xv, 0), ip.CgMesh(xv, 2), 0)
+    assert isinstance(L, np.ndarray) and L.shape == Ho.mInterpolation[0].shape
+    Lop = mg.DeviceOperator(L, _lib.OP_TRANSFER)
+    r, uc, u = rand_like(o, L.shape[0], 1), rand_like(o, L.shape[1], 2), rand_like(o, L.shape[0], 3)
+    assert rel(mg.restrict(Lop, r), L.T @ r) < 1e-13
+    assert rel(mg.prolong_add(Lop, uc, u), u + L @ uc) < 1e-13
+    # the hierarchy with the dense transfer: Galerkin coarse operator L' A L (dense too), V-cycle against NumPy
+    A = Ho.mStiffness[0]
+    Ac = sp.csc_matrix(L.T @ (A @ L))
+    opA = mg.DeviceOperator(A)
+    H = mg.MeshHierarchy(None, [opA, Ac], [mg.JacobiSmoother(opA)], [L])
+    x = mg.multigrid_v_cycle(H, np.zeros(len(b)), b)
+    Ad, d = A.toarray(), A.diagonal()
+    v = np.zeros(len(b))
+    for _ in range(3):
+        v = v + (2.0 / 3.0) * (b - Ad @ v) / d
+    v = v + L @ np.linalg.solve(Ac.toarray(), L.T @ (b - Ad @ v))
+    for _ in range(3):
+        v = v + (2.0 / 3.0) * (b - Ad @ v) / d
+    assert np.linalg.norm(Ad @ (x - v)) <= 1e-12 * np.linalg.norm(b)
+
+
+def rand_like(o, n, seed):
+    return np.random.default_rng(100 + seed).standard_normal(n)

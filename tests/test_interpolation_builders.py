@@ -69,10 +69,39 @@ def test_dg_cg(oracle, n, pdg, pcg, flag):
          o.dg_cg_interpolation(o.DgMesh(mesh, pdg), o.CgMesh(mesh, pcg), mesh, flag))
 
 
-def test_dense_flag_and_bad_arguments(oracle):
+@pytest.mark.parametrize("n,pdg,pcg", [(8, 0, 1), (11, 1, 2), (6, 2, 4), (1, 1, 1)])
+def test_dg_cg_dense_flag_0(oracle, n, pdg, pcg):
+    """interpFlag = 0: `highMesh.mMassMatrixLU \\ Array(N)` (src/interpolation.jl:205) -- a dense matrix, as in the
+    reference; the consistent CG mass matrix of the array mesh against the oracle's assembly"""
+    o = oracle
+    mesh, xv = nonuniform_mesh(o, n, 7 * n + pcg)
+    cg, ocg = ip.CgMesh(xv, pcg), o.CgMesh(mesh, pcg)
+    M, Mo = cg.mass_matrix(), ocg.mMassMatrix.tocsc()
+    assert abs(M - Mo).max() <= 1e-15 * abs(Mo).max() and M.nnz == Mo.nnz
+    L = ip.dg_cg_interpolation(ip.DgMesh(xv, pdg), cg, 0)
+    Lo = o.dg_cg_interpolation(o.DgMesh(mesh, pdg), ocg, mesh, 0)
+    assert isinstance(L, np.ndarray) and L.shape == Lo.shape
+    assert np.abs(L - Lo).max() <= 1e-12 * np.abs(Lo).max()
+
+
+@pytest.mark.parametrize("n,pcg,sizes", [(12, 2, (4, 2, 3)), (8, 1, (2,))])
+def test_aggdg_cg_dense_flag_0(oracle, n, pcg, sizes):
+    o = oracle
+    mesh, xv = nonuniform_mesh(o, n, 11 * n + pcg)
+    agg, a, i = [], 1, 0
+    while a <= n:
+        s_ = min(sizes[i % len(sizes)], n - a + 1)
+        agg.append(list(range(a, a + s_)))
+        a, i = a + s_, i + 1
+    odg = o.DgMesh(mesh, max(pcg, 1))
+    oagg = o.AgglomeratedDgMesh1(1, agg, mesh, odg)
+    L = ip.aggdg_cg_interpolation(ip.AgglomeratedDgMesh(1, agg, ip.DgMesh(xv, max(pcg, 1))), ip.CgMesh(xv, pcg), 0)
+    Lo = o.aggdg_cg_interpolation(oagg, o.CgMesh(mesh, pcg), mesh, 0)
+    assert isinstance(L, np.ndarray) and np.abs(L - Lo).max() <= 1e-12 * np.abs(Lo).max()
+
+
+def test_bad_arguments(oracle):
     mesh, xv = nonuniform_mesh(oracle, 6, 1)
-    with pytest.raises(UnsupportedError):
-        ip.dg_cg_interpolation(ip.DgMesh(xv, 1), ip.CgMesh(xv, 2), 0)
     with pytest.raises(ValueError):
         ip.dg_cg_interpolation(ip.DgMesh(xv, 1), ip.CgMesh(xv, 2), 3)       # src/interpolation.jl:218
     with pytest.raises(ValueError):
