@@ -15,6 +15,8 @@ once on the reference element and scaled, instead of point by point per element)
 
     cg_cg_interpolation(low, high)                 src/interpolation.jl:5-55
     dg_dg_interpolation(low, high)                 :91-109
+    cg_cg_interpolation2(low, high)                :57-85    (dense L2 projection, as in the reference)
+    dg_dg_interpolation2(low, high)                :111-139
     dg_cg_interpolation(low, high, interpFlag)     :145-220   (interpFlag 0 -- dense, as in the reference --, 1, 2)
     aggdg_aggdg_interpolation(coarse, fine)        :226-264
     aggdg_dg_interpolation(agg, base)              :270-292
@@ -331,6 +333,50 @@ def dg_dg_interpolation(lowMesh, highMesh):
     V = np.broadcast_to(lowVal, (lowMesh.n,) + lowVal.shape).reshape(-1, lowMesh.m)
     starts = np.arange(lowMesh.n + 1, dtype=np.int64) * highMesh.m
     return _dg_rows_csc(V, starts, lowMesh.m, (highMesh.mNumNodes, lowMesh.mNumNodes))
+
+
+def dg_dg_interpolation2(lowMesh, highMesh):
+    """src/interpolation.jl:111-139: the interior nodes of every fine element take all coarse nodes of the element
+    (as dg_dg_interpolation), its two end nodes only the coarse end node of the same side.  Needs p >= 1 on both meshes
+    (the reference indexes mNodesInd[1:2] of both elements)."""
+    _check_same_faces(lowMesh, highMesh)
+    if lowMesh.mP < 1 or highMesh.mP < 1:
+        raise ArgumentError("dg_dg_interpolation2 needs p >= 1 on both meshes")
+    n, mh, ml = lowMesh.n, highMesh.m, lowMesh.m
+    lowVal = _nodal_basis_at(lowMesh.ref, highMesh.ref.nodes)        # (m_hi, m_lo)
+    qh = mh - 2
+    # column (k, j): [end node j of the fine element if j < 2] then its interior nodes, ascending
+    cnt = np.where(np.arange(ml) < 2, 1 + qh, qh).astype(np.int64)
+    colptr = np.concatenate([[0], np.cumsum(np.tile(cnt, n))]).astype(np.int64)
+    rowval = np.empty(int(colptr[-1]), dtype=np.int64)
+    nzval = np.empty(int(colptr[-1]))
+    k = np.arange(n, dtype=np.int64)
+    cp = colptr[:-1].reshape(n, ml)
+    ii = np.arange(qh, dtype=np.int64)
+    for j in range(ml):
+        off = 0
+        if j < 2:
+            rowval[cp[:, j]] = k * mh + j
+            nzval[cp[:, j]] = lowVal[j, j]
+            off = 1
+        if qh:
+            pos = (cp[:, j] + off)[:, None] + ii[None, :]
+            rowval[pos] = (k * mh + 2)[:, None] + ii[None, :]
+            nzval[pos] = lowVal[2:, j][None, :]
+    return _csc(colptr, rowval, nzval, (highMesh.mNumNodes, lowMesh.mNumNodes))
+
+
+def cg_cg_interpolation2(lowMesh, highMesh):
+    """src/interpolation.jl:57-85: the consistent-mass L2 projection CG(p_low) -> CG(p_high),
+    `highMesh.mMassMatrixLU \\ Array(N)` -- a DENSE ndarray, as in the reference (small meshes)"""
+    import scipy.sparse as sp
+    _check_same_faces(lowMesh, highMesh)
+    T = lowMesh.J[:, None, None] * _ref_l2_block(highMesh.ref, lowMesh.ref)[None, :, :]      # (n, m_hi, m_lo)
+    eh, el = highMesh.element_nodes() - 1, lowMesh.element_nodes() - 1
+    rows = np.broadcast_to(eh.T[:, :, None], T.shape)
+    cols = np.broadcast_to(el.T[:, None, :], T.shape)
+    N = sp.csc_matrix((T.reshape(-1), (rows.reshape(-1), cols.reshape(-1))), shape=(highMesh.mNumNodes, lowMesh.mNumNodes))
+    return _consistent_mass_solve(highMesh, N)
 
 
 def _ref_l2_block(ref_rows, ref_cols):

@@ -1068,6 +1068,42 @@ def cg_cg_interpolation(lowMesh, highMesh):
     return L
 
 
+def cg_cg_interpolation2(lowMesh, highMesh):
+    """src/interpolation.jl:57-85 (L2 projection between CG spaces; returns a DENSE matrix:
+    `highMesh.mMassMatrixLU \\ Array(N)`)."""
+    gq, gqW = gauss_quad(lowMesh.mP + highMesh.mP)
+    hiV = evaluate_nodal_basis_fun(highMesh.mRefEl.mBasisFunCoeff, gq)
+    loV = evaluate_nodal_basis_fun(lowMesh.mRefEl.mBasisFunCoeff, gq)
+    I, J, V = [], [], []
+    for k, lowEl in enumerate(lowMesh.mElements):
+        highEl = highMesh.mElements[k]
+        temp = np.zeros((len(highEl.mNodesInd), len(lowEl.mNodesInd)))
+        for j in range(len(lowEl.mNodesInd)):
+            for i in range(len(highEl.mNodesInd)):
+                for l in range(len(gq)):
+                    temp[i, j] += lowEl.mJacobian * gqW[l] * hiV[l, i] * loV[l, j]
+        for j, lowNode in enumerate(lowEl.mNodesInd):
+            for i, highNode in enumerate(highEl.mNodesInd):
+                I.append(highNode), J.append(lowNode), V.append(temp[i, j])
+    N = sparse(I, J, V, highMesh.mNumNodes, lowMesh.mNumNodes)
+    return highMesh.mMassMatrixLU.solve(N.toarray())
+
+
+def dg_dg_interpolation2(lowMesh, highMesh):
+    """src/interpolation.jl:111-139: as dg_dg_interpolation for the interior nodes of the fine element, the two
+    end nodes take the value of their own coarse end node only."""
+    lowVal = evaluate_nodal_basis_fun(lowMesh.mRefEl.mBasisFunCoeff, highMesh.mRefEl.mNodesX)
+    I, J, V = [], [], []
+    for k, lowEl in enumerate(lowMesh.mElements):
+        highEl = highMesh.mElements[k]
+        for j, lowNode in enumerate(lowEl.mNodesInd):
+            for i in range(2, len(highEl.mNodesInd)):
+                I.append(highEl.mNodesInd[i]), J.append(lowNode), V.append(lowVal[i, j])
+        for j in range(2):
+            I.append(highEl.mNodesInd[j]), J.append(lowEl.mNodesInd[j]), V.append(lowVal[j, j])
+    return sparse(I, J, V, highMesh.mNumNodes, lowMesh.mNumNodes)
+
+
 def dg_dg_interpolation(lowMesh, highMesh):
     """src/interpolation.jl:91-109"""
     lowVal = evaluate_nodal_basis_fun(lowMesh.mRefEl.mBasisFunCoeff, highMesh.mRefEl.mNodesX)

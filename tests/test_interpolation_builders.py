@@ -100,6 +100,40 @@ def test_aggdg_cg_dense_flag_0(oracle, n, pcg, sizes):
     assert isinstance(L, np.ndarray) and np.abs(L - Lo).max() <= 1e-12 * np.abs(Lo).max()
 
 
+@pytest.mark.parametrize("n,plo,phi", [(7, 1, 2), (12, 2, 4), (9, 1, 3), (4, 4, 8), (5, 3, 3)])
+def test_dg_dg_interpolation2(oracle, n, plo, phi):
+    """src/interpolation.jl:111-139 (outside SURVEY section 8, unused by MeshHierarchy): index maps bit for bit"""
+    o = oracle
+    mesh, xv = nonuniform_mesh(o, n, 13 * n + phi)
+    same(ip.dg_dg_interpolation2(ip.DgMesh(xv, plo), ip.DgMesh(xv, phi)),
+         o.dg_dg_interpolation2(o.DgMesh(mesh, plo), o.DgMesh(mesh, phi)))
+    with pytest.raises(ArgumentError):
+        ip.dg_dg_interpolation2(ip.DgMesh(xv, 0), ip.DgMesh(xv, phi))
+
+
+@pytest.mark.parametrize("n,plo,phi", [(6, 1, 2), (9, 2, 4), (5, 1, 3), (1, 1, 1)])
+def test_cg_cg_interpolation2(oracle, n, plo, phi):
+    """src/interpolation.jl:57-85: dense consistent-mass L2 projection between CG spaces"""
+    o = oracle
+    mesh, xv = nonuniform_mesh(o, n, 17 * n + phi)
+    L = ip.cg_cg_interpolation2(ip.CgMesh(xv, plo), ip.CgMesh(xv, phi))
+    Lo = o.cg_cg_interpolation2(o.CgMesh(mesh, plo), o.CgMesh(mesh, phi))
+    assert isinstance(L, np.ndarray) and L.shape == Lo.shape and np.abs(L - Lo).max() <= 1e-12 * np.abs(Lo).max()
+    # an L2 projection reproduces what the coarse space holds: coarse nodal values of a polynomial of degree p_low
+    clo, chi = ip.CgMesh(xv, plo), ip.CgMesh(xv, phi)
+    f = lambda x: 1.0 + 2.0 * x - (x ** plo)
+
+    def nodal(cg):
+        x = np.empty(cg.mNumNodes)
+        el = cg.element_nodes() - 1
+        xi = cg.ref.nodes
+        for i in range(cg.mP + 1):
+            x[el[i]] = cg.xc + cg.h / 2.0 * xi[i]
+        return f(x)
+
+    assert np.abs(L @ nodal(clo) - nodal(chi)).max() <= 1e-11
+
+
 def test_bad_arguments(oracle):
     mesh, xv = nonuniform_mesh(oracle, 6, 1)
     with pytest.raises(ValueError):
