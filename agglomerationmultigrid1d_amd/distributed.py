@@ -985,6 +985,39 @@ def bench_main(args, rank, world, local_rank, nPre, nPost, alpha):
     t_setup = time.perf_counter() - t_setup
     N = (4 * n + 1) if cfg5 else n * (args.p + 1)
 
+    # Self-check before anything is timed (untimed, two cycles): the in-library RCCL path -- grouped ncclSend / ncclRecv
+    # between the vectors, the in-place ncclAllGather, a communicator per stream -- has only ever run with one rank on
+    # the build boxes.  The same schedule with its exchanges routed through torch.distributed (its own NCCL calls, the
+    # path every torch job uses) must give the same bits; if it does not, the run goes on with the torch-routed
+    # collectives and says so, rather than reporting a rate for wrong numbers.
+    selfcheck = None
+    if (isinstance(dv, NativeDistributedVCycle) and dv.collectives == "rccl" and
+            (world > 1 or os.environ.get("AGGMG_DIST_SELFCHECK") == "force") and os.environ.get("AGGMG_DIST_SELFCHECK") != "0"):
+        try:
+            dv_t = NativeDistributedVCycle(engine, layout, comm, collectives="torch")
+            outs = []
+            for drv in (dv, dv_t):
+                p_, q_ = engine.new(layout.local_dofs(0)), engine.new(layout.local_dofs(0))
+                for _ in range(2):
+                    drv.vcycle(p_, b, q_, nPre, nPost, alpha, overlap_next=True)
+                    p_, q_ = q_, p_
+                torch.cuda.synchronize()
+                outs.append(p_[layout.owned_slice(0)] if hasattr(layout, "owned_slice") else p_[torch.as_tensor(layout.owned_index(0), device=p_.device)])
+            same = torch.tensor([1 if torch.equal(outs[0], outs[1]) else 0], dtype=torch.int32,
+                                device=engine.dev if backend == "nccl" else "cpu")
+            if world > 1:
+                dist.all_reduce(same, op=dist.ReduceOp.MIN)
+            if int(same.item()) == 1:
+                selfcheck = "owned values after two cycles bitwise equal to the torch.distributed-routed schedule"
+                dv_t.free()
+            else:
+                selfcheck = "MISMATCH against the torch.distributed-routed schedule: timed run uses torch.distributed collectives"
+                rccl_note = selfcheck
+                dv.free()
+                dv = dv_t
+        except Exception as exc:      # the check must never take the run down
+            selfcheck = f"not completed ({exc!r})"
+
     src, dst = xa, xb
     # every cycle's output is the next cycle's x0 (the loop of multigrid, src/solvers.jl:124-126):
     # its interface exchange is issued under the fine-level ascent.  AGGMG_DIST_GRAPH=1 lets the library
@@ -1046,10 +1079,13 @@ def bench_main(args, rank, world, local_rank, nPre, nPost, alpha):
                        "backend": backend,
                        "collectives": (getattr(dv, "collectives", "python schedule") if rccl_note is None else rccl_note),
                        "rccl_ranks": getattr(dv, "rccl_ranks", None),
+                       "rccl_selfcheck": selfcheck,
                        "hipgraph": (dv.graph_info() if use_graph else None),
                        "parallelism": f"element-range x{world}, deep halos W={layout.W}, "
-                                      f"{ex_per_cycle} all-gathers per cycle "
-                                      f"(x0 interface exchange issued under the fine-level ascent), "
+                                      f"{ex_per_cycle} exchanges per cycle (interface elements as grouped neighbour send/recv "
+                                      f"straight between the vectors"
+                                      + ("" if os.environ.get("AGGMG_DIST_P2P", "1") != "0" else " -- AGGMG_DIST_P2P=0: pack, all-gather, unpack")
+                                      + f"; x0 interface exchange issued under the fine-level ascent), "
                                       + ("coarsest solve: chunk elimination on each rank's own blocks, boundary system replicated"
                                          if dv.chunked else "coarsest solve gathered and replicated")},
             "roofline": {"bound": "hbm", "kernel": (f"cgt_fused_kernel<4> {dkind} level {dlevel + 1} (rank 0)" if cfg5 else
