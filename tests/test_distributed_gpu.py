@@ -386,8 +386,9 @@ def test_rccl_backend_smoke_single_rank():
     assert same and m == 3.25 and backend == "nccl"
 
 
-@pytest.mark.parametrize("dist_config,launcher", [(4, "torchrun"), (5, "torchrun"), (4, "bare")])
-def test_bench_two_ranks_under_torch_distributed_run(dist_config, launcher, tmp_path):
+@pytest.mark.parametrize("dist_config,launcher,smoother", [(4, "torchrun", "jac"), (5, "torchrun", "jac"), (4, "bare", "jac"),
+                                                           (5, "bare", "hybridSchwarz"), (5, "torchrun", "blockGS")])
+def test_bench_two_ranks_under_torch_distributed_run(dist_config, launcher, smoother, tmp_path):
     """bench.py --gpus 2 as the driver launches it (python -m torch.distributed.run, one process per rank) and in the
     bare form `python bench.py --gpus 2` (bench.py starts the ranks itself as a child process), with both
     ranks sharing this box's GPU over gloo: the N > 1 path end to end -- rank-local generators, library set-up,
@@ -398,9 +399,9 @@ def test_bench_two_ranks_under_torch_distributed_run(dist_config, launcher, tmp_
     env = dict(os.environ, AGGMG_DIST_BACKEND="gloo")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
-    port = 29600 + dist_config
+    port = 29600 + dist_config + 10 * ["jac", "hybridSchwarz", "blockGS"].index(smoother)
     tail = [os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-            "--log2-elems", "16", "--cg-log2-elems", "16", "--dist-config", str(dist_config)]
+            "--log2-elems", "16", "--cg-log2-elems", "16", "--dist-config", str(dist_config), "--dist-smoother", smoother]
     if launcher == "bare":
         cmd = [sys.executable] + tail
     else:
