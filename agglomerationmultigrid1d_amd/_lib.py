@@ -16,6 +16,7 @@ ERR_ARGUMENT, ERR_DIMENSION, ERR_SINGULAR, ERR_HIP, ERR_UNSUPPORTED = -1, -2, -3
 OP_STIFFNESS, OP_TRANSFER = 0, 1
 OPT_SYMMETRIC_PACKING = 1
 OPT_COARSE_CHUNK_LOG2 = 2
+OPT_DETECT_CHAIN = 3
 PROFILE_NTAGS = 256
 KIND_FUSED_DOWN, KIND_FUSED_UP, KIND_SMOOTH, KIND_RESIDUAL, KIND_RESTRICT, KIND_PROLONG, \
     KIND_JACOBI, KIND_BLOCK_APPLY, KIND_COARSE, KIND_FUSED_MID = range(10)

@@ -76,6 +76,11 @@ class Context:
     def set_option(self, option, value):
         """context options of the C ABI (aggmg_set_option), e.g. _lib.OPT_SYMMETRIC_PACKING"""
         self.check(self.lib.aggmg_set_option(self.handle, int(option), int(value)))
+        self.__dict__.setdefault("_options", {})[int(option)] = int(value)
+
+    def option(self, option, default):
+        """the value last given to set_option (the C ABI has no getter), `default` when it never was set"""
+        return self.__dict__.get("_options", {}).get(int(option), default)
 
     def set_stream(self, hip_stream):
         """Launch on a caller-provided hipStream_t (integer / pointer), e.g.
@@ -312,14 +317,24 @@ class JacobiSmoother(AbstractSmoother):
     mElementNodes: optional (p+1) x n matrix of the CG mesh's element node lists (1-based, column k
     = cgMesh.mElements[k].mNodesInd, src/cg_mesh.jl:35-45) -- what cg_smoother(cgMesh, A, :jac) has at
     hand.  Same smoother; with the lists the level also gets the element-contiguous chain form and
-    runs the fused point-Jacobi kernel (C ABI aggmg_jacobi_setup_elements)."""
+    runs the fused point-Jacobi kernel (C ABI aggmg_jacobi_setup_elements).
+    Without lists the library looks at the operator itself (AGGMG_OPT_DETECT_CHAIN): a CG operator in the reference's
+    vertices-first numbering is recognised from its pattern and takes the same chain kernels; detect=False keeps an
+    operator without lists on the generic CSR kernels whatever its pattern."""
 
-    def __init__(self, A, ctx=None, mElementNodes=None):
+    def __init__(self, A, ctx=None, mElementNodes=None, detect=True):
         self.A = _as_op(A, ctx=ctx)
         h = ctypes.c_void_p()
         c = self.A.ctx
         if mElementNodes is None:
-            c.check(c.lib.aggmg_jacobi_setup(c.handle, self.A.handle, ctypes.byref(h)))
+            was = c.option(_lib.OPT_DETECT_CHAIN, 1)
+            if not detect and was:
+                c.set_option(_lib.OPT_DETECT_CHAIN, 0)
+            try:
+                c.check(c.lib.aggmg_jacobi_setup(c.handle, self.A.handle, ctypes.byref(h)))
+            finally:
+                if not detect and was:
+                    c.set_option(_lib.OPT_DETECT_CHAIN, was)
         else:
             inds = np.asarray(mElementNodes, dtype=np.int64)
             if inds.ndim != 2:

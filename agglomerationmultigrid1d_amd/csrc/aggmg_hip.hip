@@ -90,6 +90,9 @@ extern "C" int aggmg_set_option(aggmg_ctx* ctx, int option, int value) {
         return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_set_option: AGGMG_OPT_COARSE_CHUNK_LOG2 takes 1 .. 12");
       ctx->cr_max_q = value;
       return AGGMG_OK;
+    case AGGMG_OPT_DETECT_CHAIN:
+      ctx->detect_chain = value != 0;
+      return AGGMG_OK;
   }
   return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_set_option: unknown option");
 }
@@ -326,6 +329,7 @@ extern "C" int aggmg_jacobi_setup(aggmg_ctx* ctx, aggmg_op* A, aggmg_smoother** 
   sm->A = A;
   sm->N = A->m;
   CHECK(setup_jacobi_diag(ctx, A, &sm->diag));  // A[i,i], 0.0 when not stored
+  if (ctx->detect_chain) CHECK(cgt_detect(ctx, sm.get()));   // AGGMG_OPT_DETECT_CHAIN
   *out = sm.release();
   return AGGMG_OK;
 }

@@ -326,8 +326,13 @@ int cgt_mid(aggmg_ctx* ctx, aggmg_hier* h, const double* cur, double* alt, const
 extern "C" int aggmg_jacobi_setup_elements(aggmg_ctx* ctx, aggmg_op* A, int64_t nodes_per_element, int64_t n_elements,
                                            const int64_t* element_nodes, int one_based, aggmg_smoother** out) {
   if (!ctx || !A || !out) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_jacobi_setup_elements: NULL argument");
-  CHECK(aggmg_jacobi_setup(ctx, A, out));
-  if (!element_nodes || n_elements <= 0 || nodes_per_element < 2) return AGGMG_OK;
+  const bool lists = element_nodes && n_elements > 0 && nodes_per_element >= 2;
+  const bool detect = ctx->detect_chain;
+  if (lists) ctx->detect_chain = false;   // the caller's lists decide, not the pattern
+  const int st0 = aggmg_jacobi_setup(ctx, A, out);
+  ctx->detect_chain = detect;
+  CHECK(st0);
+  if (!lists) return AGGMG_OK;
   std::unique_ptr<aggmg_smoother> sm(*out);
   *out = nullptr;
   CHECK(cgt_build(ctx, sm.get(), element_nodes, nodes_per_element, n_elements, one_based));

@@ -40,6 +40,7 @@ struct aggmg_ctx {
   std::string err;
   bool sym_packing = true;  // AGGMG_OPT_SYMMETRIC_PACKING
   int cr_max_q = 12;        // AGGMG_OPT_COARSE_CHUNK_LOG2
+  bool detect_chain = true; // AGGMG_OPT_DETECT_CHAIN
   int profiling = 0;  // 0 off, 1 every launch, 2 only the fine-level fused-down launch (dominant kernel)
   std::vector<ProfEvent> prof;
   std::vector<hipEvent_t> ev_pool;
@@ -407,6 +408,7 @@ int setup_block_smoother(aggmg_ctx* ctx, aggmg_smoother* sm, const int64_t* bloc
 int setup_transfer_btd(aggmg_ctx* ctx, const aggmg_op* L, const BtdDev* Abtd, int mf, int64_t nef, int hint_mc,
                        TransferBtd* out, bool* ok);
 int setup_cr(aggmg_ctx* ctx, const aggmg_op* Ac, int hint_m, CrDev* cr);
+int cgt_detect(aggmg_ctx* ctx, aggmg_smoother* sm);   // chain form from the operator's own pattern (no element lists)
 // chunk-interleaved boundary rows of the element-partitioned coarsest solve (aggmg_hip.hip; used by dist.hip)
 int coarse_chunk_forward_interleaved(aggmg_ctx* ctx, aggmg_hier* h, const double* rhs_owned, int64_t blk_lo, int64_t blk_hi, double* Z);
 int coarse_boundary_solve_interleaved(aggmg_ctx* ctx, aggmg_hier* h, const double* Z, double* xq);

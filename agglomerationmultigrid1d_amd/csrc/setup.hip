@@ -799,7 +799,33 @@ int setup_cr(aggmg_ctx* ctx, const aggmg_op* Ac, int hint_m, CrDev* cr) {
 // ---------------------------------------------------------------------------------------------
 // CG chain form
 // ---------------------------------------------------------------------------------------------
+static int cgt_build_impl(aggmg_ctx* ctx, aggmg_smoother* sm, const int64_t* elems, int64_t m1, int64_t nel, int one_based,
+                          bool generate);
+
 int cgt_build(aggmg_ctx* ctx, aggmg_smoother* sm, const int64_t* elems, int64_t m1, int64_t nel, int one_based) {
+  return cgt_build_impl(ctx, sm, elems, m1, nel, one_based, false);
+}
+
+// AGGMG_OPT_DETECT_CHAIN: no element lists came with the operator -- try the lists of a CgMesh of degree p on
+// (N - 1) / p elements in the reference's vertices-first numbering, generated on the device, for every p that divides
+// N - 1 and whose entry count is plausible; cgt_build's own checks (a chain, every coupling inside the pattern) decide
+int cgt_detect(aggmg_ctx* ctx, aggmg_smoother* sm) {
+  const aggmg_op* A = sm->A;
+  const int64_t N = A->m;
+  if (N < 3 || A->m != A->n) return AGGMG_OK;
+  for (int64_t p = 8; p >= 1 && !sm->cgt; --p) {
+    if ((N - 1) % p) continue;
+    const int64_t nel = (N - 1) / p;
+    // a CG operator of degree p holds at most nel (p + 1)^2 entries, and not much fewer (Dirichlet rows are emptied)
+    const double full = (double)nel * (double)((p + 1) * (p + 1));
+    if ((double)A->nnz > full || (double)A->nnz < 0.5 * full) continue;
+    CHECK(cgt_build_impl(ctx, sm, nullptr, p + 1, nel, 0, true));
+  }
+  return AGGMG_OK;
+}
+
+static int cgt_build_impl(aggmg_ctx* ctx, aggmg_smoother* sm, const int64_t* elems, int64_t m1, int64_t nel, int one_based,
+                          bool generate) {
   aggmg_op* A = sm->A;
   const int64_t N = A->m;
   const int64_t p = m1 - 1;
@@ -815,7 +841,11 @@ int cgt_build(aggmg_ctx* ctx, aggmg_smoother* sm, const int64_t* elems, int64_t 
   g->N = N;
   Tmp el64;
   CHECK(tmp_alloc(ctx, &el64, (size_t)nel * m1 * 8, false));
-  HIPCHK(hipMemcpyAsync(el64.p, elems, (size_t)nel * m1 * 8, hipMemcpyHostToDevice, ctx->stream));
+  if (generate) {
+    LAUNCH(chain_generate_elements_kernel, nel, nel, m, el64.as<int64_t>());
+  } else {
+    HIPCHK(hipMemcpyAsync(el64.p, elems, (size_t)nel * m1 * 8, hipMemcpyHostToDevice, ctx->stream));
+  }
   CHECK(dalloc(ctx, &g->perm, Np, false));
   CHECK(dalloc(ctx, &g->inv, N, false));
   HIPCHK(hipMemsetAsync(g->perm, 0xFF, (size_t)Np * 4, ctx->stream));

@@ -833,6 +833,17 @@ __global__ void cr_factor_last_kernel(const double* __restrict__ b, double* __re
   }
 }
 
+// mElements[e].mNodesInd of a CgMesh of degree m on nel elements in the reference's numbering (src/cg_mesh.jl:37-45,
+// 59-65), 0-based: vertices e, e + 1, then the element's m - 1 interior nodes nel + 1 + e (m - 1) + i
+__global__ __launch_bounds__(kSetupThreads) void chain_generate_elements_kernel(int64_t nel, int m, int64_t* __restrict__ elems) {
+  const int64_t e = (int64_t)blockIdx.x * kSetupThreads + threadIdx.x;
+  if (e >= nel) return;
+  int64_t* o = elems + e * (m + 1);
+  o[0] = e;
+  o[1] = e + 1;
+  for (int i = 0; i < m - 1; ++i) o[2 + i] = nel + 1 + e * (m - 1) + i;
+}
+
 // ------------------------------------------------------------------------------------------
 // CG chain form (cgt_kernels.hpp)
 // ------------------------------------------------------------------------------------------

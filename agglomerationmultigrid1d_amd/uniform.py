@@ -1100,7 +1100,7 @@ def build_device_cg_hierarchy(U, ctx=None, keep_host=False, chain=True, smoother
     # cg_smoother(cgMesh, A, :jac) with the mesh's element node lists (chain form, fused kernel);
     # chain=False is the operators-only route through the generic CSR kernels
     if smoother == "jac":
-        sms = [JacobiSmoother(ops[k], ctx, U.element_nodes(k) if chain else None) for k in range(U.nlevels - 1)]
+        sms = [JacobiSmoother(ops[k], ctx, U.element_nodes(k) if chain else None, detect=chain) for k in range(U.nlevels - 1)]
     else:
         cls = {"addSchwarz": AdditiveSchwarzSmoother, "hybridSchwarz": HybridSchwarzSmoother, "blockGS": BlockGaussSeidel}[smoother]
         sms = [cls(ops[k], U.element_nodes(k), ctx) for k in range(U.nlevels - 1)]

@@ -242,7 +242,7 @@ def smoother_bench(mg, ctx, args, alpha):
     # the generic CSR kernels (unstructured operators) on the same matrix: fused point-Jacobi sweep and CSR
     # residual, int32 indices + fp64 values actually read
     op2 = mg.DeviceOperator(U.stiffness_csc(0), _lib.OP_STIFFNESS, ctx)
-    J = mg.JacobiSmoother(op2, ctx)
+    J = mg.JacobiSmoother(op2, ctx, detect=False)
     Sj_bytes = 12 * nnzA + 4 * (N + 1) + 8 * N + 24 * N
     # (the DG operator is banded: the generic path keeps the x window of a row block in LDS and runs up to four
     # sweeps per launch -- csr_band_kernel; AGGMG_CSR_BAND=0 falls back to one csr_stream_kernel launch per sweep)
@@ -272,7 +272,7 @@ def smoother_bench(mg, ctx, args, alpha):
     cg = {"workload": f"CG n=2^20 p=4 point-Jacobi, N={Nc}, nnz(A)={nnzc}"}
     for label, elems in (("chain", C.element_nodes(0)), ("generic_csr", None)):
         opc = mg.DeviceOperator(A, _lib.OP_STIFFNESS, ctx)
-        Jc = mg.JacobiSmoother(opc, ctx, elems)
+        Jc = mg.JacobiSmoother(opc, ctx, elems, detect=(elems is not None))   # "generic_csr": pattern detection off
         for per_launch in (1, 3):
             reps = 99 // per_launch
             fn = sweeps(opc.handle, Jc.handle, per_launch, uc, vc, bc)

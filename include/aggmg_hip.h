@@ -65,6 +65,13 @@ int aggmg_synchronize(aggmg_ctx* ctx);
  * share of the chunks of the replicated coarsest system: smaller chunks keep its CUs busy (measured on one rank's
  * share of an 8-rank 2^24 job: 0.448 ms per cycle with 10, 0.474 ms with 12).  Values 1 .. 12. */
 #define AGGMG_OPT_COARSE_CHUNK_LOG2 2
+/* AGGMG_OPT_DETECT_CHAIN (default 1): aggmg_jacobi_setup -- the form without element lists -- looks at the operator
+ * itself: when, for some p in 1 .. 8, its size is n p + 1 and every entry lies in the pattern of a CG operator of
+ * degree p on n elements in the reference's vertices-first numbering (src/cg_mesh.jl:37-45,59-65: element e couples
+ * vertices e, e + 1 and its own p - 1 interior nodes n + 1 + e (p - 1) ...), the level takes the fused chain kernel
+ * exactly as if aggmg_jacobi_setup_elements had been given the mesh's lists (same smoother, same results: the check
+ * is on the entries, set-up time only).  0: operators without lists always take the generic CSR kernels. */
+#define AGGMG_OPT_DETECT_CHAIN 3
 int aggmg_set_option(aggmg_ctx* ctx, int option, int value);
 /* Raw device memory owned by the context's device (plumbing for harnesses without torch, and the storage of the
  * Julia shim's DeviceVector).  aggmg_dev_alloc returns ZEROED memory: a fresh vector is the zero initial guess of

@@ -125,6 +125,54 @@ def test_chain_fallbacks(oracle, mg):
         mg.JacobiSmoother(A, None, E)
 
 
+@pytest.mark.parametrize("p", [1, 2, 3, 4, 6, 8])
+def test_chain_detected_from_the_operator_alone(oracle, mg, p):
+    """AGGMG_OPT_DETECT_CHAIN: dg_smoother / cg_smoother(..., :jac) WITHOUT element lists (aggmg_jacobi_setup) recognises a
+    CG operator in the reference's vertices-first numbering from its pattern -- size n p + 1, every entry inside the
+    element chain -- and runs the fused chain kernels, same results; whatever does not fit (a DG operator, a stray
+    entry, a scrambled numbering) stays on the generic kernels, as does everything with detect=False"""
+    o = oracle
+    for n in (1, 5, 64, 301):
+        cg, A, b = cg_level(o, n, p)
+        S = mg.JacobiSmoother(A)                               # no lists
+        N = A.shape[0]
+        assert S.structured == (N >= 3), (p, n)                # two unknowns: nothing to fuse
+        assert not mg.JacobiSmoother(A, detect=False).structured
+        u0 = o.splitmix_normal(N, 31 + p)
+        assert rel(mg.smooth(S.A, S, u0, b, 2.0 / 3.0, 4), jacobi_sweeps(sp.csr_matrix(A), u0, b, 2.0 / 3.0, 4)) < TOL
+        assert rel(mg.residual(S.A, u0, b), b - A @ u0) < TOL
+    cg, A, b = cg_level(o, 40, p)
+    N = A.shape[0]
+    if N > 8:
+        A2 = sp.lil_matrix(A)
+        A2[0, N - 2] = 0.25                                    # a coupling no element has
+        assert not mg.JacobiSmoother(sp.csc_matrix(A2)).structured
+        perm = np.random.default_rng(p).permutation(N)         # a scrambled numbering is not the reference's
+        P = sp.csr_matrix((np.ones(N), (perm, np.arange(N))), shape=(N, N))
+        if p > 1:
+            assert not mg.JacobiSmoother((P @ A @ P.T).tocsc()).structured
+    # a DG operator of the same size class is not a CG chain
+    mesh, bd = o.model_problem(30)
+    dg = o.DgMesh(mesh, 3)
+    G, D, C = o.dg_flux_operators(dg, mesh, bd, 1000.0 * 30)
+    assert not mg.JacobiSmoother(o.dg_stiffness(dg, G, D, C)).structured
+
+
+def test_hierarchy_without_meshes_takes_the_chain_kernels(oracle, mg):
+    """MeshHierarchy(nothing but operators, :jac smoothers, transfers): the CG levels of the reference's CG-fine
+    hierarchy are recognised from the operators and fused with their transfers -- the path a caller without element
+    lists used to get was the generic CSR one (r02: 5.15 ms per cycle at 2^22 elements against ~1 ms)"""
+    o = oracle
+    Ho, b = o.build_cg_hierarchy(48, ps=(4, 2, 1), nDG=1, pDG=0)
+    ops = [mg.DeviceOperator(A) for A in Ho.mStiffness]
+    sms = [mg.JacobiSmoother(ops[k]) for k in range(3)]
+    H = mg.MeshHierarchy(None, ops, sms, Ho.mInterpolation)
+    assert H.level_kinds() == ['fused_chain'] * 3 + ['coarsest'], H.level_kinds()
+    x = mg.multigrid_v_cycle(H, np.zeros(len(b)), b)
+    xr = o.multigrid_v_cycle(Ho, np.zeros(len(b)), b)
+    assert np.linalg.norm(Ho.mStiffness[0] @ (x - xr)) <= 1e-12 * np.linalg.norm(b)
+
+
 def check_vcycle(o, mg, Ho, b, x0=None, nPre=3, nPost=3, alpha=2.0 / 3.0, it_tol=1e-9, kinds=None):
     H = mg.MeshHierarchy.from_reference(Ho)
     if kinds is not None:

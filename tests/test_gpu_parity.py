@@ -160,7 +160,8 @@ def test_generic_point_jacobi_sweeps(oracle, mg):
     H, b = o.build_cg_hierarchy(64, ps=(4, 2, 1))
     for k in range(3):
         A, So = H.mStiffness[k], H.mSmoothers[k]
-        Sg = mg.JacobiSmoother(A)
+        Sg = mg.JacobiSmoother(A, detect=False)        # the generic CSR kernels (no lists, pattern detection off)
+        assert not Sg.structured
         N = A.shape[0]
         u0, bb = rand_vec(o, N, 6), rand_vec(o, N, 7)
         for ns in (1, 2, 3, 6):
@@ -182,7 +183,7 @@ def test_banded_generic_point_jacobi_many_sweeps_per_launch(oracle, mg, n, p):
     G, D, C = o.dg_flux_operators(dg, mesh, bd, 1000.0 * n)
     A = o.dg_stiffness(dg, G, D, C)
     So = o.dg_smoother(dg, A, 'jac')
-    Sg = mg.JacobiSmoother(A)                      # no element lists: generic CSR kernels
+    Sg = mg.JacobiSmoother(A, detect=False)        # no element lists: generic CSR kernels
     assert not Sg.structured
     N = A.shape[0]
     u0, bb = rand_vec(o, N, 16), rand_vec(o, N, 17)
@@ -343,15 +344,23 @@ def test_vcycle_dg_p_hierarchy(oracle, mg):
 
 def test_vcycle_config1_cg_plus_dg0(oracle, mg):
     """BASELINE config 1: CG n=1024 p=1, point-Jacobi, + DG p=0 coarse level.  With the mesh's element
-    lists the CG level runs the fused chain kernel; without them (operators only) the generic CSR path."""
+    lists the CG level runs the fused chain kernel; without them (operators only) the library recognises the chain
+    from the operator (AGGMG_OPT_DETECT_CHAIN) -- with that switched off, the generic CSR path."""
     o = oracle
     Ho, b = o.build_cg_hierarchy(1024, ps=(1,), nDG=1, pDG=0)
     H, x, xr = check_vcycle(o, mg, Ho, b, it_tol=1e-8)
     assert H.level_kinds() == ['fused_chain', 'coarsest']
-    Hg = mg.MeshHierarchy(None, Ho.mStiffness, Ho.mSmoothers, Ho.mInterpolation)
-    assert Hg.level_kinds() == ['generic', 'coarsest']
-    xg = mg.multigrid_v_cycle(Hg, np.zeros(len(b)), b)
-    assert np.linalg.norm(Ho.mStiffness[0] @ (xg - xr)) <= TOL * np.linalg.norm(b)
+    from agglomerationmultigrid1d_amd import _lib
+    ctx = mg.default_context()
+    for detect, kinds in ((1, ['fused_chain', 'coarsest']), (0, ['generic', 'coarsest'])):
+        ctx.set_option(_lib.OPT_DETECT_CHAIN, detect)
+        try:
+            Hg = mg.MeshHierarchy(None, Ho.mStiffness, Ho.mSmoothers, Ho.mInterpolation)
+        finally:
+            ctx.set_option(_lib.OPT_DETECT_CHAIN, 1)
+        assert Hg.level_kinds() == kinds
+        xg = mg.multigrid_v_cycle(Hg, np.zeros(len(b)), b)
+        assert np.linalg.norm(Ho.mStiffness[0] @ (xg - xr)) <= TOL * np.linalg.norm(b)
 
 
 def test_vcycle_mixed_cg_dg_agg(oracle, mg):

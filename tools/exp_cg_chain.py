@@ -16,7 +16,8 @@ def main():
     ap.add_argument("--log2-elems", type=int, default=20)
     ap.add_argument("--ps", type=str, default="4,2,1")
     ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--generic", action="store_true", help="operators only (no element lists): generic CSR kernels")
+    ap.add_argument("--generic", action="store_true", help="operators only (no element lists), chain detection off: generic CSR kernels")
+    ap.add_argument("--detect", action="store_true", help="operators only; the library recognises the chain itself (AGGMG_OPT_DETECT_CHAIN)")
     args = ap.parse_args()
     import agglomerationmultigrid1d_amd as mg
     from agglomerationmultigrid1d_amd import _lib
@@ -40,10 +41,10 @@ def main():
         tic("aggmg_csc_upload stiffness", t0)
         if k < U.nlevels - 1:
             t0 = time.perf_counter()
-            el = None if args.generic else U.element_nodes(k)
+            el = None if (args.generic or args.detect) else U.element_nodes(k)
             tic("element lists (numpy)", t0)
             t0 = time.perf_counter()
-            sms.append(mg.JacobiSmoother(ops[k], ctx, el))
+            sms.append(mg.JacobiSmoother(ops[k], ctx, el, detect=not args.generic))
             tic("aggmg_jacobi_setup_elements", t0)
     for k in range(U.nlevels - 1):
         t0 = time.perf_counter()
