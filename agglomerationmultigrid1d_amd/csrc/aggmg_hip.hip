@@ -969,9 +969,30 @@ static int cr_stage_threads() {
   return t;
 }
 
+#ifdef AGGMG_CR_TRACE
+// tracing build only (tools/cr_trace.py builds it beside the product library): constant-clock stamps per workgroup
+static unsigned long long* g_cr_trace = nullptr;
+static constexpr size_t kCrTraceWords = (size_t)3 * kCrTraceWgs * 16;
+extern "C" int aggmg_debug_cr_trace(aggmg_ctx* ctx, unsigned long long* out, int clear) {
+  if (!ctx) return AGGMG_ERR_ARGUMENT;
+  if (!g_cr_trace) {
+    HIPCHK(hipMalloc((void**)&g_cr_trace, kCrTraceWords * 8));
+    HIPCHK(hipMemset(g_cr_trace, 0, kCrTraceWords * 8));
+  }
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (out) HIPCHK(hipMemcpy(out, g_cr_trace, kCrTraceWords * 8, hipMemcpyDeviceToHost));
+  if (clear) HIPCHK(hipMemset(g_cr_trace, 0, kCrTraceWords * 8));
+  return AGGMG_OK;
+}
+#endif
+
 static CrStageArgs cr_make_args(const CrDev& cr, const CrStage& S, bool tail) {
   CrStageArgs A;
   std::memset(&A, 0, sizeof(A));
+#ifdef AGGMG_CR_TRACE
+  A.trace = g_cr_trace;
+  A.trace_kind = tail ? 1 : 0;
+#endif
   A.q = S.q;
   for (int l = 0; l < S.q; ++l) A.lv[l] = cr.lv[S.l0 + l];
   A.nsteps = S.nsteps;
@@ -984,6 +1005,8 @@ static CrStageArgs cr_make_args(const CrDev& cr, const CrStage& S, bool tail) {
   A.n_out = S.n_out;
   A.stack = S.stack;
   A.stack_stride = S.stack_stride;
+  A.mid = S.mid;
+  for (int s = 0; s <= kCrMaxSteps; ++s) A.mid_off[s] = S.mid_off[s];
   A.tail = tail ? 1 : 0;
   A.lu_last = cr.lu_last;
   A.perm_last = cr.perm_last;
@@ -1033,6 +1056,9 @@ static int cr_solve_from(aggmg_ctx* ctx, CrDev& cr, int s0, const double* d, con
   for (int s = ns - 1; s >= s0; --s) {
     const CrStage& S = cr.st[s];
     CrStageArgs A = cr_make_args(cr, S, false);
+#ifdef AGGMG_CR_TRACE
+    A.trace_kind = 2;
+#endif
     if (s == s0) A.dstride = dstride;
     const unsigned grid = (unsigned)std::max<int64_t>(S.n_out, 1);
     const double* ds = s == s0 ? d : cr.st[s - 1].partR;

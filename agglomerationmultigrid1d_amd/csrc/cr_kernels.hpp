@@ -23,7 +23,10 @@
 //
 // The forward pass touches the off-diagonal blocks of the even rows only, the backward pass those
 // of the odd rows: stored apart (parity-split, a and c of one row adjacent) so that every fetched
-// line is used in full.
+// line is used in full.  The back substitution of a sub-chunk needs the reduced right-hand sides of the
+// odd rows of its inner sub-levels (three blocks of the nine at three levels per step): the forward
+// step stores them (`mid`) instead of the backward step reading the even rows' factors of all three
+// sub-levels again to recompute them (r03: 0.22 -> 0.14 GB per backward launch at 2^20 blocks of 2).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -72,11 +75,34 @@ struct CrStageArgs {
   double* stack;  // [n_chunks][stack_stride]: summed inputs of steps 1 .. nsteps-1, or null
   int stack_stride;
   int tail;       // one chunk = the whole system, n_out == 1: the last block is solved with lu_last
+  double* mid;    // reduced right-hand sides of the odd rows of the inner sub-levels, written by the forward steps
+  int64_t mid_off[kCrMaxSteps + 1];  // and read by the backward ones: step s, sub-chunk b at mid_off[s] + b (2^(qs-1) - 1) M
   int dstride;    // doubles between consecutive blocks of the step-0 input vectors d0 / d0b (0: M, contiguous)
   int ostride;    // same for the boundary rows a forward stage writes (partR / partL); 2 M = interleaved per chunk
   const double* lu_last;
   const int32_t* perm_last;
+#ifdef AGGMG_CR_TRACE
+  unsigned long long* trace;  // [3 kinds][kCrTraceWgs][16] constant-clock stamps (tools/cr_trace.py; never in the product build)
+  int trace_kind;
+#endif
 };
+
+#ifdef AGGMG_CR_TRACE
+constexpr int kCrTraceWgs = 4096;
+#define CR_STAMP(A, slot)                                                                                   \
+  do {                                                                                                      \
+    if (threadIdx.x == 0 && (A).trace && blockIdx.x < kCrTraceWgs)                                          \
+      (A).trace[(((A).trace_kind * kCrTraceWgs) + blockIdx.x) * 16 + (slot)] = wall_clock64();              \
+  } while (0)
+#define CR_STAMP_WAIT(A, slot)                                                                              \
+  do {                                                                                                      \
+    if (threadIdx.x == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                      \
+    CR_STAMP(A, slot);                                                                                      \
+  } while (0)
+#else
+#define CR_STAMP(A, slot) ((void)0)
+#define CR_STAMP_WAIT(A, slot) ((void)0)
+#endif
 
 __device__ __forceinline__ int64_t cr_level_n(const CrStageArgs& A, int l) { return l < A.q ? A.lv[l].n : A.n_out; }
 
@@ -170,10 +196,13 @@ __device__ __forceinline__ void cr_loc_fwd(const CrLevel* lv, int64_t b, double*
       const bool ok = tlo + 2 * jj + 1 <= thi;
       int64_t idx = tlo1 + jj;
       if (idx > L.n_odd - 1) idx = L.n_odd - 1;
-      double t[M];
-      cr_lu_solve_reg<M>(L.lu + idx * (M * M), L.perm + idx * M, d + (2 * jj + 1) * M, t);
+      // (the right-hand side is zeroed, not the result: a select AFTER the solve lets the compiler sink the solve and
+      // its factor loads into a branch on `ok` -- one dependent memory round trip per odd row, measured: 13.6 us per
+      // sub-chunk at block size 2 against 3.5 us for the loads of the whole input vector)
+      double rz[M];
 #pragma unroll
-      for (int e = 0; e < M; ++e) y[jj][e] = ok ? t[e] : 0.0;
+      for (int e = 0; e < M; ++e) rz[e] = ok ? d[(2 * jj + 1) * M + e] : 0.0;
+      cr_lu_solve_reg<M>(L.lu + idx * (M * M), L.perm + idx * M, rz, y[jj]);
     }
 #pragma unroll
     for (int jj = 0; jj <= NB1; ++jj) {
@@ -242,6 +271,229 @@ __device__ __forceinline__ void cr_loc_bwd(const CrLevel* lv, int64_t b, double*
 #pragma unroll
       for (int e = 0; e < M; ++e) d[(2 * jj) * M + e] = xn[jj * M + e];
     cr_loc_bwd<M, QS, I - 1>(lv, b, v);
+  }
+}
+
+// ---- block sizes 1 and 2: every factor of a sub-chunk fetched in ONE batch --------------------------------------
+// Stamps written from inside the launches (tools/cr_trace.py) show a wave spending 13.6 us between "input vector
+// loaded" and "three sub-levels done" at block size 2: the compiler, minding its register budget, issues the ~60
+// factor loads of a sub-chunk in about ten dependent batches, each a full memory round trip (cold in a cycle), and
+// fetches the level descriptors (kernel arguments: scalar loads, a round trip each) as it goes.  Up to block size 2
+// the factors of all three sub-levels fit the register file of a wave that has its SIMD to itself (10 even rows, 7
+// odd rows: 122 doubles + 14 ints at block size 2), so they are loaded up front, behind a scheduling barrier, and the
+// arithmetic starts when they are all on their way: two round trips per step (descriptors, then factors and input).
+template <int QS, int I>
+struct CrEvenOff {
+  static constexpr int rows = CrEvenOff<QS, I - 1>::rows + (1 << (QS - I)) + 1;
+};
+template <int QS>
+struct CrEvenOff<QS, 0> {
+  static constexpr int rows = 0;
+};
+template <int QS, int I>
+struct CrOddOff {
+  static constexpr int rows = CrOddOff<QS, I - 1>::rows + (1 << (QS - I));
+};
+template <int QS>
+struct CrOddOff<QS, 0> {
+  static constexpr int rows = 0;
+};
+
+template <int M, int QS>
+struct CrSubFactors {
+  double fe[CrEvenOff<QS, QS>::rows][2 * M * M];
+  double lu[CrOddOff<QS, QS>::rows][M * M];
+  int32_t perm[CrOddOff<QS, QS>::rows][M];
+};
+
+template <int M, int QS, int I>
+__device__ __forceinline__ void cr_pre_load(const CrLevel* lv, int64_t b, CrSubFactors<M, QS>& F) {
+  if constexpr (I < QS) {
+    const CrLevel& L = lv[I];
+    constexpr int NB1 = 1 << (QS - I - 1);
+    const int64_t tlo1 = b << (QS - I - 1);
+#pragma unroll
+    for (int jj = 0; jj < NB1; ++jj) {
+      int64_t idx = tlo1 + jj;
+      if (idx > L.n_odd - 1) idx = L.n_odd - 1;
+      const double* lu = L.lu + idx * (M * M);
+      const int32_t* pm = L.perm + idx * M;
+      constexpr int o = CrOddOff<QS, I>::rows;
+      if constexpr (M == 2) {
+        const double2 t0 = reinterpret_cast<const double2*>(lu)[0], t1 = reinterpret_cast<const double2*>(lu)[1];
+        const int2 pp = *reinterpret_cast<const int2*>(pm);
+        F.lu[o + jj][0] = t0.x, F.lu[o + jj][1] = t0.y, F.lu[o + jj][2] = t1.x, F.lu[o + jj][3] = t1.y;
+        F.perm[o + jj][0] = pp.x, F.perm[o + jj][1] = pp.y;
+      } else {
+#pragma unroll
+        for (int k = 0; k < M * M; ++k) F.lu[o + jj][k] = lu[k];
+#pragma unroll
+        for (int k = 0; k < M; ++k) F.perm[o + jj][k] = pm[k];
+      }
+    }
+#pragma unroll
+    for (int jj = 0; jj <= NB1; ++jj) {
+      int64_t j = tlo1 + jj;
+      if (j > L.n_even - 1) j = L.n_even - 1;
+      cr_load_pair<M>(L.fe + j * (2 * M * M), F.fe[CrEvenOff<QS, I>::rows + jj]);
+    }
+    cr_pre_load<M, QS, I + 1>(lv, b, F);
+  }
+}
+
+// cr_loc_fwd on fetched factors (same operations in the same order: bit for bit the same result)
+template <int M, int QS, int I>
+__device__ __forceinline__ void cr_loc_fwd_pre(const CrLevel* lv, const CrSubFactors<M, QS>& F, int64_t b, double* v) {
+  if constexpr (I < QS) {
+    const CrLevel& L = lv[I];
+    constexpr int NB1 = 1 << (QS - I - 1);
+    int64_t thi = (b + 1) << (QS - I);
+    if (thi > L.n - 1) thi = L.n - 1;
+    const int64_t tlo = b << (QS - I);
+    double* d = v + CrOff<QS, I>::blocks * M;
+    double* dn = v + CrOff<QS, I + 1>::blocks * M;
+    double y[NB1][M];
+#pragma unroll
+    for (int jj = 0; jj < NB1; ++jj) {
+      const bool ok = tlo + 2 * jj + 1 <= thi;
+      double rz[M];
+#pragma unroll
+      for (int e = 0; e < M; ++e) rz[e] = ok ? d[(2 * jj + 1) * M + e] : 0.0;
+      cr_lu_solve_reg<M>(F.lu[CrOddOff<QS, I>::rows + jj], F.perm[CrOddOff<QS, I>::rows + jj], rz, y[jj]);
+    }
+#pragma unroll
+    for (int jj = 0; jj <= NB1; ++jj) {
+      const double* ac = F.fe[CrEvenOff<QS, I>::rows + jj];
+      double acc[M];
+#pragma unroll
+      for (int e = 0; e < M; ++e) acc[e] = d[(2 * jj) * M + e];
+      if (jj > 0) {
+#pragma unroll
+        for (int i = 0; i < M; ++i)
+#pragma unroll
+          for (int k = 0; k < M; ++k) acc[i] -= ac[i * M + k] * y[jj > 0 ? jj - 1 : 0][k];
+      }
+      if (jj < NB1) {
+#pragma unroll
+        for (int i = 0; i < M; ++i)
+#pragma unroll
+          for (int k = 0; k < M; ++k) acc[i] -= ac[M * M + i * M + k] * y[jj < NB1 ? jj : 0][k];
+      }
+#pragma unroll
+      for (int e = 0; e < M; ++e) dn[jj * M + e] = acc[e];
+    }
+    cr_loc_fwd_pre<M, QS, I + 1>(lv, F, b, v);
+  }
+}
+
+// inner sub-levels' odd rows of a sub-chunk: sub-level I (1 <= I < QS) holds 2^(QS-I-1) of them
+template <int QS, int I>
+struct CrMidOff {
+  static constexpr int blocks = CrMidOff<QS, I - 1>::blocks + (1 << (QS - I));
+};
+template <int QS>
+struct CrMidOff<QS, 1> {
+  static constexpr int blocks = 0;
+};
+template <int QS>
+struct CrMidOff<QS, 0> {
+  static constexpr int blocks = 0;
+};
+template <int QS>
+constexpr int cr_mid_blocks() {
+  return (1 << (QS - 1)) - 1;
+}
+
+template <int M, int QS, int I, bool STORE>
+__device__ __forceinline__ void cr_mid_move(double* mid, double* v) {
+  if constexpr (I < QS) {
+    constexpr int NB1 = 1 << (QS - I - 1);
+#pragma unroll
+    for (int jj = 0; jj < NB1; ++jj)
+#pragma unroll
+      for (int e = 0; e < M; ++e) {
+        double& r = v[(CrOff<QS, I>::blocks + 2 * jj + 1) * M + e];
+        double& g = mid[(CrMidOff<QS, I>::blocks + jj) * M + e];
+        if constexpr (STORE) g = r; else r = g;
+      }
+    cr_mid_move<M, QS, I + 1, STORE>(mid, v);
+  }
+}
+
+// what the back substitution of a sub-chunk reads, fetched in one batch (block sizes 1 and 2, as above)
+template <int M, int QS>
+struct CrSubFactorsB {
+  double fo[CrOddOff<QS, QS>::rows][2 * M * M];
+  double lu[CrOddOff<QS, QS>::rows][M * M];
+  int32_t perm[CrOddOff<QS, QS>::rows][M];
+};
+
+template <int M, int QS, int I>
+__device__ __forceinline__ void cr_pre_load_b(const CrLevel* lv, int64_t b, CrSubFactorsB<M, QS>& F) {
+  if constexpr (I < QS) {
+    const CrLevel& L = lv[I];
+    constexpr int NB1 = 1 << (QS - I - 1);
+    const int64_t tlo1 = b << (QS - I - 1);
+#pragma unroll
+    for (int jj = 0; jj < NB1; ++jj) {
+      int64_t idx = tlo1 + jj;
+      if (idx > L.n_odd - 1) idx = L.n_odd - 1;
+      const double* lu = L.lu + idx * (M * M);
+      const int32_t* pm = L.perm + idx * M;
+      constexpr int o = CrOddOff<QS, I>::rows;
+      cr_load_pair<M>(L.fo + idx * (2 * M * M), F.fo[o + jj]);
+      if constexpr (M == 2) {
+        const double2 t0 = reinterpret_cast<const double2*>(lu)[0], t1 = reinterpret_cast<const double2*>(lu)[1];
+        const int2 pp = *reinterpret_cast<const int2*>(pm);
+        F.lu[o + jj][0] = t0.x, F.lu[o + jj][1] = t0.y, F.lu[o + jj][2] = t1.x, F.lu[o + jj][3] = t1.y;
+        F.perm[o + jj][0] = pp.x, F.perm[o + jj][1] = pp.y;
+      } else {
+#pragma unroll
+        for (int k = 0; k < M * M; ++k) F.lu[o + jj][k] = lu[k];
+#pragma unroll
+        for (int k = 0; k < M; ++k) F.perm[o + jj][k] = pm[k];
+      }
+    }
+    cr_pre_load_b<M, QS, I + 1>(lv, b, F);
+  }
+}
+
+// cr_loc_bwd on fetched factors
+template <int M, int QS, int I>
+__device__ __forceinline__ void cr_loc_bwd_pre(const CrLevel* lv, const CrSubFactorsB<M, QS>& F, int64_t b, double* v) {
+  if constexpr (I >= 0) {
+    const CrLevel& L = lv[I];
+    constexpr int NB1 = 1 << (QS - I - 1);
+    const int64_t tlo = b << (QS - I);
+    double* d = v + CrOff<QS, I>::blocks * M;
+    const double* xn = v + CrOff<QS, I + 1>::blocks * M;
+#pragma unroll
+    for (int jj = 0; jj < NB1; ++jj) {
+      const int64_t r = tlo + 2 * jj + 1;
+      const double* ac = F.fo[CrOddOff<QS, I>::rows + jj];
+      double rhs[M], x[M];
+      const bool has_next = r + 1 < L.n;
+      double xr[M];
+#pragma unroll
+      for (int k = 0; k < M; ++k) xr[k] = has_next ? xn[(jj + 1) * M + k] : 0.0;
+#pragma unroll
+      for (int i = 0; i < M; ++i) {
+        double s = d[(2 * jj + 1) * M + i];
+#pragma unroll
+        for (int k = 0; k < M; ++k) s -= ac[i * M + k] * xn[jj * M + k];
+#pragma unroll
+        for (int k = 0; k < M; ++k) s -= ac[M * M + i * M + k] * xr[k];
+        rhs[i] = s;
+      }
+      cr_lu_solve_reg<M>(F.lu[CrOddOff<QS, I>::rows + jj], F.perm[CrOddOff<QS, I>::rows + jj], rhs, x);
+#pragma unroll
+      for (int e = 0; e < M; ++e) d[(2 * jj + 1) * M + e] = x[e];
+    }
+#pragma unroll
+    for (int jj = 0; jj <= NB1; ++jj)
+#pragma unroll
+      for (int e = 0; e < M; ++e) d[(2 * jj) * M + e] = xn[jj * M + e];
+    cr_loc_bwd_pre<M, QS, I - 1>(lv, F, b, v);
   }
 }
 
@@ -359,9 +611,28 @@ __device__ __forceinline__ void cr_step_forward(const CrStageArgs& A, int s, int
     double v[CrOff<QS, QS + 1>::blocks * M];
     int64_t thi;
     bool tshared;
-    cr_loc_load<M, QS>(A, s, g, b, d0, d0b, sh, v, thi, tshared, wg_shared && s > 0 && i == g.nb - 1);
-    cr_loc_fwd<M, QS, 0>(&A.lv[g.a], b, v);
+    if constexpr (M <= 2) {
+      CrSubFactors<M, QS> F;
+      cr_pre_load<M, QS, 0>(&A.lv[g.a], b, F);
+      __builtin_amdgcn_sched_barrier(0);
+      cr_loc_load<M, QS>(A, s, g, b, d0, d0b, sh, v, thi, tshared, wg_shared && s > 0 && i == g.nb - 1);
+#ifdef AGGMG_CR_TRACE
+      if (s == 0 && i == (int)threadIdx.x) CR_STAMP_WAIT(A, 2);
+#endif
+      cr_loc_fwd_pre<M, QS, 0>(&A.lv[g.a], F, b, v);
+    } else {
+      cr_loc_load<M, QS>(A, s, g, b, d0, d0b, sh, v, thi, tshared, wg_shared && s > 0 && i == g.nb - 1);
+      cr_loc_fwd<M, QS, 0>(&A.lv[g.a], b, v);
+    }
+    if constexpr (QS >= 2) cr_mid_move<M, QS, 1, true>(A.mid + A.mid_off[s] + b * (cr_mid_blocks<QS>() * M), v);
     const double* top = v + CrOff<QS, QS>::blocks * M;
+#ifdef AGGMG_CR_TRACE
+    if (s == 0 && i == (int)threadIdx.x) {
+      double t0 = top[0];
+      asm volatile("" : "+v"(t0));
+      CR_STAMP_WAIT(A, 3);
+    }
+#endif
 #pragma unroll
     for (int e = 0; e < M; ++e) Rout[i * M + e] = top[e];
     if (b + 1 <= g.n_out - 1) {
@@ -385,18 +656,34 @@ __device__ __forceinline__ void cr_step_backward(const CrStageArgs& A, int s, in
     double v[CrOff<QS, QS + 1>::blocks * M];
     int64_t thi;
     bool tshared;
-    cr_loc_load<M, QS>(A, s, g, b, d0, d0b, sh, v, thi, tshared, wg_shared && s > 0 && i == g.nb - 1);
-    cr_loc_fwd<M, QS, 0>(&A.lv[g.a], b, v);
+    // sub-level 0 from the step's input, the inner sub-levels' odd rows as the forward step left them
     double* top = v + CrOff<QS, QS>::blocks * M;
     const bool has_right = b + 1 <= g.n_out - 1;
     const int64_t br = has_right ? b + 1 : b;
+    if constexpr (M <= 2) {
+      CrSubFactorsB<M, QS> F;
+      cr_pre_load_b<M, QS, 0>(&A.lv[g.a], b, F);
+      __builtin_amdgcn_sched_barrier(0);
+      cr_loc_load<M, QS>(A, s, g, b, d0, d0b, sh, v, thi, tshared, wg_shared && s > 0 && i == g.nb - 1);
+      if constexpr (QS >= 2) cr_mid_move<M, QS, 1, false>(A.mid + A.mid_off[s] + b * (cr_mid_blocks<QS>() * M), v);
 #pragma unroll
-    for (int e = 0; e < M; ++e) {
-      top[e] = xtop[(b - xtop_lo) * M + e];
-      const double xr = xtop[(br - xtop_lo) * M + e];
-      top[M + e] = has_right ? xr : 0.0;
+      for (int e = 0; e < M; ++e) {
+        top[e] = xtop[(b - xtop_lo) * M + e];
+        const double xr = xtop[(br - xtop_lo) * M + e];
+        top[M + e] = has_right ? xr : 0.0;
+      }
+      cr_loc_bwd_pre<M, QS, QS - 1>(&A.lv[g.a], F, b, v);
+    } else {
+      cr_loc_load<M, QS>(A, s, g, b, d0, d0b, sh, v, thi, tshared, wg_shared && s > 0 && i == g.nb - 1);
+      if constexpr (QS >= 2) cr_mid_move<M, QS, 1, false>(A.mid + A.mid_off[s] + b * (cr_mid_blocks<QS>() * M), v);
+#pragma unroll
+      for (int e = 0; e < M; ++e) {
+        top[e] = xtop[(b - xtop_lo) * M + e];
+        const double xr = xtop[(br - xtop_lo) * M + e];
+        top[M + e] = has_right ? xr : 0.0;
+      }
+      cr_loc_bwd<M, QS, QS - 1>(&A.lv[g.a], b, v);
     }
-    cr_loc_bwd<M, QS, QS - 1>(&A.lv[g.a], b, v);
     const int64_t tlo = b << QS;
     double* o = xout + (tlo - xout_lo) * M;
     if (tshared && s == 0) {
@@ -434,6 +721,7 @@ __device__ __forceinline__ void cr_forward_steps(const CrStageArgs& A, int64_t c
       if constexpr (Q >= 3) cr_step_forward<M, 3>(A, s, c, wg_shared, d0, d0b, sh);
     }
     __syncthreads();
+    CR_STAMP(A, 4 + s);
   }
 }
 
@@ -460,6 +748,7 @@ __device__ __forceinline__ void cr_backward_steps(const CrStageArgs& A, int64_t 
       if constexpr (Q >= 3) cr_step_backward<M, 3>(A, s, c, wg_shared, d0, d0b, xtop, xtop_lo, xout, xout_lo, sh);
     }
     __syncthreads();
+    CR_STAMP_WAIT(A, 8 + s);
   }
 }
 
@@ -467,8 +756,10 @@ __device__ __forceinline__ void cr_backward_steps(const CrStageArgs& A, int64_t 
 template <int M>
 __device__ __forceinline__ void cr_tail_body(const CrStageArgs& T, const double* __restrict__ d0,
                                              const double* __restrict__ d0b, double* __restrict__ x0, double* sh) {
+  CR_STAMP(T, 0);
   for (int t = threadIdx.x; t < T.lds_total; t += blockDim.x) sh[t] = 0.0;
   __syncthreads();
+  CR_STAMP(T, 1);
   if (T.nsteps == 0) {  // a single block
     if (threadIdx.x == 0) {
       double r[M], y[M];
@@ -492,7 +783,9 @@ __device__ __forceinline__ void cr_tail_body(const CrStageArgs& T, const double*
     for (int e = 0; e < M; ++e) X[e] = y[e];
   }
   __syncthreads();
+  CR_STAMP(T, 12);
   cr_backward_steps<M>(T, 0, false, d0, d0b, nullptr, x0, sh);
+  CR_STAMP_WAIT(T, 15);
 }
 
 template <int M>
@@ -516,8 +809,10 @@ __global__ __launch_bounds__(kCrThreads) CR_WAVES_ATTR void cr_stage_forward_ker
   __shared__ unsigned int s_ticket;
   const int64_t c = A.c0 + blockIdx.x;
   const bool wg_shared = ((c + 1) << A.q) <= A.lv[0].n - 1;
+  CR_STAMP(A, 0);
   for (int t = threadIdx.x; t < A.lds_total; t += blockDim.x) sh[t] = 0.0;
   __syncthreads();
+  CR_STAMP(A, 1);
   cr_forward_steps<M>(A, c, wg_shared, d0, d0b, sh);
   {
     const double* R = sh + A.lds_off[A.nsteps];  // level q: blocks c, c + 1
@@ -539,6 +834,7 @@ __global__ __launch_bounds__(kCrThreads) CR_WAVES_ATTR void cr_stage_forward_ker
       o += cnt;
     }
   }
+  CR_STAMP_WAIT(A, 15);
   if constexpr (FUSE_TAIL) {
     __threadfence();  // partR / partL of this workgroup visible device-wide before the ticket
     __syncthreads();
@@ -559,8 +855,10 @@ __global__ __launch_bounds__(kCrThreads) CR_WAVES_ATTR void cr_stage_backward_ke
   extern __shared__ double sh[];
   const int64_t c = A.c0 + blockIdx.x;
   const bool wg_shared = ((c + 1) << A.q) <= A.lv[0].n - 1;
+  CR_STAMP(A, 0);
   for (int t = threadIdx.x; t < A.lds_total; t += blockDim.x) sh[t] = 0.0;
   __syncthreads();
+  CR_STAMP(A, 1);
   if (A.nsteps > 1) {
     if (A.stack) {
       const double* st = A.stack + c * (int64_t)A.stack_stride;
@@ -572,11 +870,13 @@ __global__ __launch_bounds__(kCrThreads) CR_WAVES_ATTR void cr_stage_backward_ke
         o += cnt;
       }
       __syncthreads();
+      CR_STAMP_WAIT(A, 2);
     } else {
       cr_forward_steps<M>(A, c, wg_shared, d0, d0b, sh);
     }
   }
   cr_backward_steps<M>(A, c, wg_shared, d0, d0b, xq, x0, sh);
+  CR_STAMP_WAIT(A, 15);
 }
 
 }  // namespace aggmg

@@ -216,6 +216,9 @@ struct CrStage {
   double *partR = nullptr, *partL = nullptr, *xq = nullptr;  // the stage's boundary system (n_out blocks)
   double* stack = nullptr;      // per chunk: summed inputs of the steps after the first
   int stack_stride = 0;
+  double* mid = nullptr;        // per step and sub-chunk: reduced right-hand sides of the inner sub-levels' odd rows
+  int64_t mid_off[kCrMaxSteps + 1] = {0};
+  int64_t mid_total = 0;        // doubles
 };
 
 struct CrDev {
@@ -257,6 +260,15 @@ inline void cr_plan_steps(CrStage* S, int m) {
   S->lds_total = o;
   S->stack_stride = 0;
   for (int s = 1; s < S->nsteps; ++s) S->stack_stride += ((1 << (S->q - S->step_a[s])) + 1) * m;
+  // sub-chunk b of step s (a block index of the step's output level: at most (n_in >> a1) + 1 of them) keeps
+  // 2^(qs-1) - 1 blocks; every region 16-byte aligned
+  S->mid_total = 0;
+  for (int s = 0; s < S->nsteps; ++s) {
+    const int qs = S->step_a[s + 1] - S->step_a[s];
+    S->mid_off[s] = S->mid_total;
+    const int64_t cnt = ((S->n_in >> S->step_a[s + 1]) + 2) * (((int64_t)1 << (qs - 1)) - 1) * m;
+    S->mid_total += (cnt + 1) & ~(int64_t)1;
+  }
 }
 
 struct aggmg_hier {

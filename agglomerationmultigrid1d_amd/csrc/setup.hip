@@ -722,6 +722,7 @@ int setup_cr(aggmg_ctx* ctx, const aggmg_op* Ac, int hint_m, CrDev* cr) {
     S.partL = S.partR + nb;  // partL[0] is never written: stays zero
     S.xq = S.partL + nb;
     if (S.stack_stride > 0) CHECK(dz((S.n_out + 1) * (int64_t)S.stack_stride, &S.stack));
+    if (S.mid_total > 0) CHECK(dz(S.mid_total, &S.mid));
     cr->st.push_back(S);
     l0 += S.q;
   }
@@ -734,6 +735,7 @@ int setup_cr(aggmg_ctx* ctx, const aggmg_op* Ac, int hint_m, CrDev* cr) {
   cr->tail.n_in = level_n(l0);
   cr->tail.n_out = 1;
   cr_plan_steps(&cr->tail, m);
+  if (cr->tail.mid_total > 0) CHECK(dz(cr->tail.mid_total, &cr->tail.mid));
   // The small levels (the tail and the last steps of the stage before it) are worked through by a
   // few threads, one dependent step after the other: their factors go into ONE allocation, so that a
   // step touches a couple of pages instead of four arrays per level each on a page of its own -- an
