@@ -47,7 +47,7 @@ constexpr int kCrMaxSteps = 8;
 struct CrLevel {
   const double* fe;    // [n_even][2][M][M]  (a_{2j}, c_{2j})
   const double* fo;    // [n_odd][2][M][M]   (a_{2j+1}, c_{2j+1})
-  const double* lu;    // [n_odd][M][M]  unit-lower L and U of the row-permuted b_{2j+1}
+  const double* lu;    // [n_odd][M][M]  unit-lower L and U of the row-permuted b_{2j+1}, diagonal of U as reciprocals
   const int32_t* perm; // [n_odd][M]     row permutation: (P b) = L U, solve uses rhs[perm[k]]
   int64_t n, n_even, n_odd;
 };
@@ -133,8 +133,10 @@ __device__ __forceinline__ void cr_load_pair(const double* __restrict__ p, doubl
 template <int M>
 __device__ __forceinline__ void cr_lu_solve_reg(const double* __restrict__ lu, const int32_t* __restrict__ perm,
                                                 const double* r, double (&y)[M]) {
+  // (the factors carry the pivots of U as reciprocals: a fp64 division is a dependent chain of a dozen instructions, and
+  // the small steps of a launch are one wave issuing such chains -- 14 divisions per sub-chunk and pass at block size 2)
   if constexpr (M == 1) {
-    y[0] = r[0] / lu[0];
+    y[0] = r[0] * lu[0];
   } else {
     double f[M * M];
 #pragma unroll
@@ -167,7 +169,7 @@ __device__ __forceinline__ void cr_lu_solve_reg(const double* __restrict__ lu, c
       double s = y[i];
 #pragma unroll
       for (int j = i + 1; j < M; ++j) s -= f[i * M + j] * y[j];
-      y[i] = s / f[i * M + i];
+      y[i] = s * f[i * M + i];
     }
   }
 }

@@ -728,7 +728,7 @@ __global__ __launch_bounds__(kSetupThreads) void cr_factor_odd_kernel(int64_t n_
   for (int r = 0; r < M; ++r) {
     perm_out[j * M + r] = perm[r];
 #pragma unroll
-    for (int q = 0; q < M; ++q) lu_out[j * M * M + r * M + q] = B[r][q];
+    for (int q = 0; q < M; ++q) lu_out[j * M * M + r * M + q] = r == q ? 1.0 / B[r][r] : B[r][q];  // pivots as reciprocals
   }
   lu_perm_solve_dev<M>(B, perm, A_, X);
 #pragma unroll
@@ -829,7 +829,7 @@ __global__ void cr_factor_last_kernel(const double* __restrict__ b, double* __re
   for (int r = 0; r < M; ++r) {
     perm_out[r] = perm[r];
 #pragma unroll
-    for (int q = 0; q < M; ++q) lu_out[r * M + q] = B[r][q];
+    for (int q = 0; q < M; ++q) lu_out[r * M + q] = r == q ? 1.0 / B[r][r] : B[r][q];
   }
 }
 
