@@ -1115,6 +1115,9 @@ static int cr_phase_t(aggmg_ctx* ctx, CrDev& cr, int phase, const double* d_owne
     hipLaunchKernelGGL((cr_stage_forward_kernel<M, false>), dim3(grid), dim3(cr_stage_threads()), lds, ctx->stream, A, d0,
                        (const double*)nullptr, partR, partL, T, (double*)nullptr, (unsigned int*)nullptr);
   } else {
+#ifdef AGGMG_CR_TRACE
+    A.trace_kind = 2;
+#endif
     hipLaunchKernelGGL((cr_stage_backward_kernel<M>), dim3(grid), dim3(cr_stage_threads()), lds, ctx->stream, A, d0,
                        (const double*)nullptr, xq, x_owned - blk_lo * M);
   }

@@ -67,9 +67,33 @@ def main():
         H.vcycle_dev(z, b, x, 0, 0, 1.0)
         fn(ctx.handle, out.ctypes.data_as(ctypes.c_void_p), 0)
         runs.append(out.astype(np.int64).copy())
-    T = runs[-1]
-    t_first = T[0, :, 0][T[0, :, 0] > 0].min()
     print(f"case {args.case}: N = {N}; stamps in us relative to the first forward workgroup's entry (last of {args.reps} solves)")
+    report(runs[-1])
+    spans = []
+    for R in runs:
+        t0 = R[0, :, 0][R[0, :, 0] > 0].min()
+        spans.append({kind: [round(float((R[k, :, 0][R[k, :, 0] > 0].min() - t0) / 100.0), 2),
+                             round(float((R[k].max() - t0) / 100.0), 2)] for k, kind in enumerate(KINDS) if (R[k, :, 0] > 0).any()})
+    print("\nfirst entry / last stamp per launch, every solve:", json.dumps(spans))
+    r = A @ x.download() - b.download()
+    print("rel residual", float(np.linalg.norm(r) / np.linalg.norm(b.download())))
+
+
+def trace_fn(ctx):
+    fn = ctx.lib.aggmg_debug_cr_trace
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+    fn.restype = ctypes.c_int
+    return fn
+
+
+def fetch(ctx, fn, clear=0):
+    out = np.zeros((3, WGS, SLOTS), dtype=np.uint64)
+    fn(ctx.handle, out.ctypes.data_as(ctypes.c_void_p), clear)
+    return out.astype(np.int64)
+
+
+def report(T):
+    t_first = T[0, :, 0][T[0, :, 0] > 0].min()
     for k, kind in enumerate(KINDS):
         S = T[k]
         live = S[:, 0] > 0
@@ -87,14 +111,6 @@ def main():
             absu = (v[ok] - t_first) / 100.0
             print(f"  {SLOT_NAMES[kind][slot]:38s} since own entry: min {rel_entry.min():6.2f} med {np.median(rel_entry):6.2f} "
                   f"max {rel_entry.max():6.2f} | absolute: min {absu.min():6.2f} med {np.median(absu):6.2f} max {absu.max():6.2f}")
-    spans = []
-    for R in runs:
-        t0 = R[0, :, 0][R[0, :, 0] > 0].min()
-        spans.append({kind: [round(float((R[k, :, 0][R[k, :, 0] > 0].min() - t0) / 100.0), 2),
-                             round(float((R[k].max() - t0) / 100.0), 2)] for k, kind in enumerate(KINDS) if (R[k, :, 0] > 0).any()})
-    print("\nfirst entry / last stamp per launch, every solve:", json.dumps(spans))
-    r = A @ x.download() - b.download()
-    print("rel residual", float(np.linalg.norm(r) / np.linalg.norm(b.download())))
 
 
 if __name__ == "__main__":

@@ -48,6 +48,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--profile", action="store_true")
     ap.add_argument("--graph", action="store_true", help="AGGMG_DIST_GRAPH: replay the cycle as a hipGraph")
+    ap.add_argument("--cr-trace", action="store_true",
+                    help="the coarsest solve's in-kernel timeline of the last cycle (needs AGGMG_HIP_LIB=build_trace/libaggmg_hip_trace.so)")
     ap.add_argument("--python-schedule", action="store_true",
                     help="the Python schedule (one ctypes / torch call per launch) instead of aggmg_dist_vcycle_dev")
     args = ap.parse_args()
@@ -129,6 +131,14 @@ def main():
         out["kernels_ms"] = {f"{k}_L{l}": v[0] / v[1] for (k, l), v in sorted(prof.items())}
         out["kernels_sum_ms"] = sum(v[0] / v[1] for v in prof.values())
     print(json.dumps(out), flush=True)
+    if args.cr_trace:
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        import cr_trace
+        fn = cr_trace.trace_fn(ctx)
+        fn(ctx.handle, None, 1)
+        dv.vcycle(src, b, dst, nPre, nPost, alpha, **kw)
+        torch.cuda.synchronize()
+        cr_trace.report(cr_trace.fetch(ctx, fn))
 
 
 if __name__ == "__main__":
