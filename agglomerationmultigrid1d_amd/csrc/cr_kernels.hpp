@@ -3,9 +3,10 @@
 // (UMFPACK) of src/solvers.jl:39.
 //
 // Level l holds n block rows  a_i x_{i-1} + b_i x_i + c_i x_{i+1} = d_i  (m x m blocks).
-// Odd rows are eliminated with their pivoted LU factors (never an explicit inverse):
-//   forward   d'_j     = d_{2j} - a_{2j} (b_{2j-1} \ d_{2j-1}) - c_{2j} (b_{2j+1} \ d_{2j+1})
-//   backward  x_{2j+1} = b_{2j+1} \ (d_{2j+1} - a_{2j+1} x_{2j} - c_{2j+1} x_{2j+2})
+// Odd rows are eliminated by block elimination with pivoted LU factors of their diagonal blocks:
+//   forward   d'_j     = d_{2j} - (a_{2j} b_{2j-1}^-1) d_{2j-1} - (c_{2j} b_{2j+1}^-1) d_{2j+1}
+//             with the multipliers in brackets formed once at set-up from the factors (as the Schur complements are),
+//   backward  x_{2j+1} = b_{2j+1} \ (d_{2j+1} - a_{2j+1} x_{2j} - c_{2j+1} x_{2j+2})   (triangular solves per cycle)
 //
 // Schedule.  A dependent chain of log2(n) levels is latency, not bandwidth, so the levels are
 // taken three at a time: a *thread* owns the 2^3 + 1 blocks [8b, 8b + 8] of its sub-chunk, keeps
@@ -45,7 +46,7 @@ constexpr int kCrMaxStageLevels = 12;
 constexpr int kCrMaxSteps = 8;
 
 struct CrLevel {
-  const double* fe;    // [n_even][2][M][M]  (a_{2j}, c_{2j})
+  const double* fe;    // [n_even][2][M][M]  forward multipliers (a_{2j} b_{2j-1}^-1, c_{2j} b_{2j+1}^-1)
   const double* fo;    // [n_odd][2][M][M]   (a_{2j+1}, c_{2j+1})
   const double* lu;    // [n_odd][M][M]  unit-lower L and U of the row-permuted b_{2j+1}, diagonal of U as reciprocals
   const int32_t* perm; // [n_odd][M]     row permutation: (P b) = L U, solve uses rhs[perm[k]]
@@ -191,20 +192,13 @@ __device__ __forceinline__ void cr_loc_fwd(const CrLevel* lv, int64_t b, double*
     const int64_t tlo = tlo1 << 1;
     double* d = v + CrOff<QS, I>::blocks * M;
     double* dn = v + CrOff<QS, I + 1>::blocks * M;
-    // b \ d of the odd rows, each used by both even neighbours; zero for rows that do not exist
+    // the odd rows' right-hand sides, each used by both even neighbours; zero for rows that do not exist
     double y[NB1][M];
 #pragma unroll
     for (int jj = 0; jj < NB1; ++jj) {
       const bool ok = tlo + 2 * jj + 1 <= thi;
-      int64_t idx = tlo1 + jj;
-      if (idx > L.n_odd - 1) idx = L.n_odd - 1;
-      // (the right-hand side is zeroed, not the result: a select AFTER the solve lets the compiler sink the solve and
-      // its factor loads into a branch on `ok` -- one dependent memory round trip per odd row, measured: 13.6 us per
-      // sub-chunk at block size 2 against 3.5 us for the loads of the whole input vector)
-      double rz[M];
 #pragma unroll
-      for (int e = 0; e < M; ++e) rz[e] = ok ? d[(2 * jj + 1) * M + e] : 0.0;
-      cr_lu_solve_reg<M>(L.lu + idx * (M * M), L.perm + idx * M, rz, y[jj]);
+      for (int e = 0; e < M; ++e) y[jj][e] = ok ? d[(2 * jj + 1) * M + e] : 0.0;
     }
 #pragma unroll
     for (int jj = 0; jj <= NB1; ++jj) {
@@ -281,8 +275,8 @@ __device__ __forceinline__ void cr_loc_bwd(const CrLevel* lv, int64_t b, double*
 // loaded" and "three sub-levels done" at block size 2: the compiler, minding its register budget, issues the ~60
 // factor loads of a sub-chunk in about ten dependent batches, each a full memory round trip (cold in a cycle), and
 // fetches the level descriptors (kernel arguments: scalar loads, a round trip each) as it goes.  Up to block size 2
-// the factors of all three sub-levels fit the register file of a wave that has its SIMD to itself (10 even rows, 7
-// odd rows: 122 doubles + 14 ints at block size 2), so they are loaded up front, behind a scheduling barrier, and the
+// the factors of all three sub-levels fit the register file (forward: the multipliers of 10 even rows, 80 doubles at block
+// size 2; backward: 7 odd rows, 84 doubles + 14 ints), so they are loaded up front, behind a scheduling barrier, and the
 // arithmetic starts when they are all on their way: two round trips per step (descriptors, then factors and input).
 template <int QS, int I>
 struct CrEvenOff {
@@ -304,8 +298,6 @@ struct CrOddOff<QS, 0> {
 template <int M, int QS>
 struct CrSubFactors {
   double fe[CrEvenOff<QS, QS>::rows][2 * M * M];
-  double lu[CrOddOff<QS, QS>::rows][M * M];
-  int32_t perm[CrOddOff<QS, QS>::rows][M];
 };
 
 template <int M, int QS, int I>
@@ -314,25 +306,6 @@ __device__ __forceinline__ void cr_pre_load(const CrLevel* lv, int64_t b, CrSubF
     const CrLevel& L = lv[I];
     constexpr int NB1 = 1 << (QS - I - 1);
     const int64_t tlo1 = b << (QS - I - 1);
-#pragma unroll
-    for (int jj = 0; jj < NB1; ++jj) {
-      int64_t idx = tlo1 + jj;
-      if (idx > L.n_odd - 1) idx = L.n_odd - 1;
-      const double* lu = L.lu + idx * (M * M);
-      const int32_t* pm = L.perm + idx * M;
-      constexpr int o = CrOddOff<QS, I>::rows;
-      if constexpr (M == 2) {
-        const double2 t0 = reinterpret_cast<const double2*>(lu)[0], t1 = reinterpret_cast<const double2*>(lu)[1];
-        const int2 pp = *reinterpret_cast<const int2*>(pm);
-        F.lu[o + jj][0] = t0.x, F.lu[o + jj][1] = t0.y, F.lu[o + jj][2] = t1.x, F.lu[o + jj][3] = t1.y;
-        F.perm[o + jj][0] = pp.x, F.perm[o + jj][1] = pp.y;
-      } else {
-#pragma unroll
-        for (int k = 0; k < M * M; ++k) F.lu[o + jj][k] = lu[k];
-#pragma unroll
-        for (int k = 0; k < M; ++k) F.perm[o + jj][k] = pm[k];
-      }
-    }
 #pragma unroll
     for (int jj = 0; jj <= NB1; ++jj) {
       int64_t j = tlo1 + jj;
@@ -358,10 +331,8 @@ __device__ __forceinline__ void cr_loc_fwd_pre(const CrLevel* lv, const CrSubFac
 #pragma unroll
     for (int jj = 0; jj < NB1; ++jj) {
       const bool ok = tlo + 2 * jj + 1 <= thi;
-      double rz[M];
 #pragma unroll
-      for (int e = 0; e < M; ++e) rz[e] = ok ? d[(2 * jj + 1) * M + e] : 0.0;
-      cr_lu_solve_reg<M>(F.lu[CrOddOff<QS, I>::rows + jj], F.perm[CrOddOff<QS, I>::rows + jj], rz, y[jj]);
+      for (int e = 0; e < M; ++e) y[jj][e] = ok ? d[(2 * jj + 1) * M + e] : 0.0;
     }
 #pragma unroll
     for (int jj = 0; jj <= NB1; ++jj) {

@@ -521,6 +521,7 @@ static int cr_levels_t(aggmg_ctx* ctx, CrDev* cr, double* a, double* b, double* 
     CHECK(dalloc(ctx, &fo, std::max<int64_t>(no, 1) * 2 * mm2, false));
     own(fo);
     LAUNCH(cr_split_kernel, n * 2 * mm2, n, mm2, (const double*)a, (const double*)c, fe, fo);
+    LAUNCH((cr_even_multipliers_kernel<M>), no, no, ne, (const double*)lu, (const int32_t*)perm, fe);
     HIPCHK(hipStreamSynchronize(ctx->stream));
     CrLevel L;
     L.n = n;

@@ -585,7 +585,8 @@ __global__ __launch_bounds__(kSetupThreads) void cr_pack_kernel(int64_t N, int m
   }
 }
 
-// parity-split storage of one level's off-diagonal blocks: fe[j] = (a_{2j}, c_{2j}), fo[j] = (a_{2j+1}, c_{2j+1})
+// parity-split storage of one level's off-diagonal blocks: fe[j] = (a_{2j}, c_{2j}) (turned into the forward multipliers
+// by cr_even_multipliers_kernel), fo[j] = (a_{2j+1}, c_{2j+1})
 __global__ __launch_bounds__(kSetupThreads) void cr_split_kernel(int64_t n, int mm2, const double* __restrict__ a,
                                                                  const double* __restrict__ c, double* __restrict__ fe,
                                                                  double* __restrict__ fo) {
@@ -740,6 +741,63 @@ __global__ __launch_bounds__(kSetupThreads) void cr_factor_odd_kernel(int64_t n_
   for (int r = 0; r < M; ++r)
 #pragma unroll
     for (int q = 0; q < M; ++q) Zc[j * M * M + r * M + q] = X[r][q];
+}
+
+// The forward pass of the solve eliminates an odd row with its even neighbours' MULTIPLIERS a_{2j} b_{2j-1}^-1 and
+// c_{2j} b_{2j+1}^-1 (row-vector solves with the pivoted factors  P b = L U:  a b^-1 = ((a U^-1) L^-1) P), formed here
+// once -- the same block elimination the Schur complements above come from -- so that the per-cycle forward pass is
+// multiply-adds on the even rows' blocks alone: it reads neither the LU factors nor the permutations and carries no
+// triangular solves in its dependent chain.  One thread per odd row 2k+1 rewrites, in place, the c half of even row k
+// and the a half of even row k+1 of fe (lu: unit-lower L, U with reciprocal pivots).
+template <int M>
+__global__ __launch_bounds__(kSetupThreads) void cr_even_multipliers_kernel(int64_t n_odd, int64_t n_even,
+                                                                            const double* __restrict__ lu,
+                                                                            const int32_t* __restrict__ perm,
+                                                                            double* __restrict__ fe) {
+  const int64_t k = (int64_t)blockIdx.x * kSetupThreads + threadIdx.x;
+  if (k >= n_odd) return;
+  double F[M][M];
+  int pm[M];
+#pragma unroll
+  for (int r = 0; r < M; ++r) {
+    pm[r] = perm[k * M + r];
+#pragma unroll
+    for (int q = 0; q < M; ++q) F[r][q] = lu[k * M * M + r * M + q];
+  }
+#pragma unroll
+  for (int side = 0; side < 2; ++side) {
+    const int64_t row = k + side;  // side 0: c of even row k (right neighbour), side 1: a of even row k + 1 (left neighbour)
+    if (row >= n_even) continue;
+    double* blk = fe + row * 2 * M * M + (side == 0 ? M * M : 0);
+#pragma unroll
+    for (int r = 0; r < M; ++r) {
+      double z[M], w[M];
+#pragma unroll
+      for (int q = 0; q < M; ++q) {  // z U = a_r
+        double t = blk[r * M + q];
+#pragma unroll
+        for (int p2 = 0; p2 < q; ++p2) t -= z[p2] * F[p2][q];
+        z[q] = t * F[q][q];
+      }
+#pragma unroll
+      for (int q = M - 1; q >= 0; --q) {  // w L = z
+        double t = z[q];
+#pragma unroll
+        for (int p2 = q + 1; p2 < M; ++p2) t -= w[p2] * F[p2][q];
+        w[q] = t;
+      }
+      double out[M];
+#pragma unroll
+      for (int c2 = 0; c2 < M; ++c2) {  // (w P)_c = w_k for c = perm[k]
+        double t = 0.0;
+#pragma unroll
+        for (int q = 0; q < M; ++q) t = (pm[q] == c2) ? w[q] : t;
+        out[c2] = t;
+      }
+#pragma unroll
+      for (int c2 = 0; c2 < M; ++c2) blk[r * M + c2] = out[c2];
+    }
+  }
 }
 
 // even block rows: Schur complement blocks of the next level
