@@ -83,8 +83,13 @@ def per_role(rows, value):
     return out, ncyc, names
 
 
-kt = glob.glob(os.path.join(src, "kt", "*", "*kernel_trace.csv"))[0]
-stats = glob.glob(os.path.join(src, "kt", "*", "*kernel_stats.csv"))[0]
+def newest(pattern):
+    """gpurun merges a call's outputs INTO the local directory: an earlier run's files (other pids) may still lie there"""
+    return max(glob.glob(pattern), key=os.path.getmtime)
+
+
+kt = newest(os.path.join(src, "kt", "*", "*kernel_trace.csv"))
+stats = newest(os.path.join(src, "kt", "*", "*kernel_stats.csv"))
 base = f"{tag}_{kind}_2p{E}"
 shutil.copy(stats, os.path.join(ROOT, "profiles", f"{base}_kernel_stats.csv"))
 dur, ncyc, names = per_role(load_trace(kt), lambda r: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6)
@@ -97,7 +102,7 @@ def pmc(which):
     f = glob.glob(os.path.join(src, which, "*", "*counter_collection.csv"))
     if not f:
         return None
-    rows = load_trace(f[0])
+    rows = load_trace(max(f, key=os.path.getmtime))
     return per_role(rows, lambda r: float(r["Counter_Value"]))[0]
 
 
