@@ -90,19 +90,35 @@ struct CrStageArgs {
 
 #ifdef AGGMG_CR_TRACE
 constexpr int kCrTraceWgs = 4096;
-#define CR_STAMP(A, slot)                                                                                   \
-  do {                                                                                                      \
-    if (threadIdx.x == 0 && (A).trace && blockIdx.x < kCrTraceWgs)                                          \
-      (A).trace[(((A).trace_kind * kCrTraceWgs) + blockIdx.x) * 16 + (slot)] = wall_clock64();              \
+// stamps go to LDS and leave for global memory when the launch ends: a global store per stamp would sit in front of the
+// next barrier's vmcnt(0) and show up as a memory round trip in every step
+__device__ __forceinline__ unsigned long long* cr_trace_slots() {
+  __shared__ unsigned long long t[16];
+  return t;
+}
+#define CR_STAMP(A, slot)                                                        \
+  do {                                                                           \
+    if (threadIdx.x == 0) cr_trace_slots()[slot] = wall_clock64();               \
   } while (0)
 #define CR_STAMP_WAIT(A, slot)                                                                              \
   do {                                                                                                      \
     if (threadIdx.x == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                      \
     CR_STAMP(A, slot);                                                                                      \
   } while (0)
+#define CR_TRACE_BEGIN()                                                         \
+  do {                                                                           \
+    if (threadIdx.x < 16) cr_trace_slots()[threadIdx.x] = 0;                     \
+  } while (0)
+#define CR_TRACE_FLUSH(A)                                                                                             \
+  do {                                                                                                                \
+    if (threadIdx.x < 16 && (A).trace && blockIdx.x < kCrTraceWgs)                                                    \
+      (A).trace[(((A).trace_kind * kCrTraceWgs) + blockIdx.x) * 16 + threadIdx.x] = cr_trace_slots()[threadIdx.x];    \
+  } while (0)
 #else
 #define CR_STAMP(A, slot) ((void)0)
 #define CR_STAMP_WAIT(A, slot) ((void)0)
+#define CR_TRACE_BEGIN() ((void)0)
+#define CR_TRACE_FLUSH(A) ((void)0)
 #endif
 
 __device__ __forceinline__ int64_t cr_level_n(const CrStageArgs& A, int l) { return l < A.q ? A.lv[l].n : A.n_out; }
@@ -721,7 +737,7 @@ __device__ __forceinline__ void cr_backward_steps(const CrStageArgs& A, int64_t 
       if constexpr (Q >= 3) cr_step_backward<M, 3>(A, s, c, wg_shared, d0, d0b, xtop, xtop_lo, xout, xout_lo, sh);
     }
     __syncthreads();
-    CR_STAMP_WAIT(A, 8 + s);
+    CR_STAMP(A, 8 + s);
   }
 }
 
@@ -729,6 +745,7 @@ __device__ __forceinline__ void cr_backward_steps(const CrStageArgs& A, int64_t 
 template <int M>
 __device__ __forceinline__ void cr_tail_body(const CrStageArgs& T, const double* __restrict__ d0,
                                              const double* __restrict__ d0b, double* __restrict__ x0, double* sh) {
+  CR_TRACE_BEGIN();
   CR_STAMP(T, 0);
   for (int t = threadIdx.x; t < T.lds_total; t += blockDim.x) sh[t] = 0.0;
   __syncthreads();
@@ -759,6 +776,7 @@ __device__ __forceinline__ void cr_tail_body(const CrStageArgs& T, const double*
   CR_STAMP(T, 12);
   cr_backward_steps<M>(T, 0, false, d0, d0b, nullptr, x0, sh);
   CR_STAMP_WAIT(T, 15);
+  CR_TRACE_FLUSH(T);
 }
 
 template <int M>
@@ -782,6 +800,7 @@ __global__ __launch_bounds__(kCrThreads) CR_WAVES_ATTR void cr_stage_forward_ker
   __shared__ unsigned int s_ticket;
   const int64_t c = A.c0 + blockIdx.x;
   const bool wg_shared = ((c + 1) << A.q) <= A.lv[0].n - 1;
+  CR_TRACE_BEGIN();
   CR_STAMP(A, 0);
   for (int t = threadIdx.x; t < A.lds_total; t += blockDim.x) sh[t] = 0.0;
   __syncthreads();
@@ -808,6 +827,7 @@ __global__ __launch_bounds__(kCrThreads) CR_WAVES_ATTR void cr_stage_forward_ker
     }
   }
   CR_STAMP_WAIT(A, 15);
+  CR_TRACE_FLUSH(A);
   if constexpr (FUSE_TAIL) {
     __threadfence();  // partR / partL of this workgroup visible device-wide before the ticket
     __syncthreads();
@@ -828,6 +848,7 @@ __global__ __launch_bounds__(kCrThreads) CR_WAVES_ATTR void cr_stage_backward_ke
   extern __shared__ double sh[];
   const int64_t c = A.c0 + blockIdx.x;
   const bool wg_shared = ((c + 1) << A.q) <= A.lv[0].n - 1;
+  CR_TRACE_BEGIN();
   CR_STAMP(A, 0);
   for (int t = threadIdx.x; t < A.lds_total; t += blockDim.x) sh[t] = 0.0;
   __syncthreads();
@@ -843,13 +864,14 @@ __global__ __launch_bounds__(kCrThreads) CR_WAVES_ATTR void cr_stage_backward_ke
         o += cnt;
       }
       __syncthreads();
-      CR_STAMP_WAIT(A, 2);
+      CR_STAMP(A, 2);
     } else {
       cr_forward_steps<M>(A, c, wg_shared, d0, d0b, sh);
     }
   }
   cr_backward_steps<M>(A, c, wg_shared, d0, d0b, xq, x0, sh);
   CR_STAMP_WAIT(A, 15);
+  CR_TRACE_FLUSH(A);
 }
 
 }  // namespace aggmg
