@@ -438,6 +438,11 @@ struct TileSel {
   int64_t head = 0, tail = 0;
 };
 
+static int cr_env_int_early(const char* name, int dflt) {
+  const char* e = std::getenv(name);
+  return e && *e ? std::atoi(e) : dflt;
+}
+
 // the structured transfer of a level as the fused kernel's prolongation input / restriction output
 static void xfer_in(FusedArgs& a, const TransferBtd& t) {
   a.lf1_in = t.lf1;
@@ -452,6 +457,9 @@ static void xfer_out(FusedArgs& a, const TransferBtd& t) {
   a.par_out = t.rho ? nullptr : t.parent;
   a.first_out = t.rho ? nullptr : t.first;
   a.nec_out = t.nec;
+  // (AGGMG_AGG_ALIGN=0: the two-part atomic restriction for every size, as before r03)
+  static const int max_shift = cr_env_int_early("AGGMG_AGG_ALIGN", 1) ? 8 : -1;
+  a.agg_shift = (!t.rho && t.maxagg >= 1 && t.maxagg - 1 <= max_shift) ? t.maxagg - 1 : -1;
 }
 
 template <int M, bool CMP>
@@ -459,16 +467,23 @@ static int launch_btd_t(aggmg_ctx* ctx, FusedArgs a, int halo, const TileSel& se
   using T = BtdTile<M, CMP>;
   const bool vr = (a.lf_out || a.ld_out) && a.par_out;
   const int align = ((a.lf_out || a.ld_out) && !vr) ? a.rho_out : 1;
+  if (a.gs) halo += a.nsweeps;  // two half-sweeps per sweep, one element of halo each
+  int shift = 0;
   if (vr) {
     if (sel.mode != 0) return fail(ctx, AGGMG_ERR_UNSUPPORTED, "tile selection on a level with agglomerates of different sizes");
-    // agglomerates cut by a tile boundary are summed from two tiles
-    HIPCHK(hipMemsetAsync(a.rc_out, 0, (size_t)a.nec_out * a.mc_out * sizeof(double), ctx->stream));
+    if (a.agg_shift >= 0 && T::TE - 2 * halo - a.agg_shift >= T::TE / 2) {
+      shift = a.agg_shift;  // owned ranges on agglomerate boundaries: plain stores
+    } else {
+      a.agg_shift = -1;     // agglomerates cut by a tile boundary are summed from two tiles
+      HIPCHK(hipMemsetAsync(a.rc_out, 0, (size_t)a.nec_out * a.mc_out * sizeof(double), ctx->stream));
+    }
+  } else {
+    a.agg_shift = -1;
   }
-  if (a.gs) halo += a.nsweeps;  // two half-sweeps per sweep, one element of halo each
-  int owned = ((T::TE - 2 * halo) / align) * align;
+  int owned = ((T::TE - 2 * halo - shift) / align) * align;
   if (owned <= 0) return fail(ctx, AGGMG_ERR_UNSUPPORTED, "fused tile too small for the requested halo");
   a.owned = owned;
-  a.halo_left = halo;
+  a.halo_left = halo + shift;
   int64_t ntiles = (a.lv.ne + owned - 1) / owned;
   a.tile_split = 0;
   a.tile_skip = 0;

@@ -162,6 +162,7 @@ struct TransferBtd {
   double* ld = nullptr;  // [N_f][mc]  rows of (L_e' D_e)': restriction of the preconditioned residual
   int32_t* parent = nullptr;  // [ne_f]      coarse element of every fine element      (rho == 0)
   int32_t* first = nullptr;   // [ne_c + 1]  first fine element of every coarse element (rho == 0)
+  int maxagg = 0;             // fine elements of the largest agglomerate                 (rho == 0)
   ~TransferBtd() {
     if (lf) (void)hipFree(lf);
     if (lf1) (void)hipFree(lf1);

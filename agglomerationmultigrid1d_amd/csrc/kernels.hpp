@@ -379,12 +379,17 @@ struct FusedArgs {
   double* rc_out;        // restricted residual
   int mc_out, rho_out;
   // agglomerates of different sizes (rho_in / rho_out unused then): coarse element of every fine element,
-  // first fine element of every coarse element.  An agglomerate cut by a tile boundary is restricted by
-  // both tiles, each adding its part atomically (rc_out zeroed by the caller; two parts: order-independent)
+  // first fine element of every coarse element.  agg_shift >= 0: the tiles' owned ranges are moved to agglomerate
+  // boundaries -- the agglomerate holding a tile's nominal first element belongs to that tile as a whole, which costs
+  // agg_shift = (largest agglomerate - 1) more elements of halo on the left -- so every agglomerate is restricted by
+  // ONE tile with a plain store (no zeroing of rc_out, no atomics, run-to-run identical).  agg_shift < 0 (very large
+  // agglomerates): an agglomerate cut by a tile boundary is restricted by both tiles, each adding its part atomically
+  // (rc_out zeroed by the caller; two parts: order-independent).
   const int32_t* par_in;
   const int32_t* par_out;
   const int32_t* first_out;
   int64_t nec_out;  // coarse elements behind rc_out
+  int agg_shift;
   // tiling
   int owned;      // owned elements per tile (multiple of rho_out)
   int halo_left;  // elements of halo on the left of the owned range
@@ -459,6 +464,16 @@ __global__ __launch_bounds__(NT) void btd_fused_kernel(FusedArgs a) {
   const int i = tid - le * M;
   const int64_t ne = a.lv.ne;
   const int64_t e0 = fused_tile(a) * a.owned - a.halo_left;  // element at x = 0
+  // owned elements x in [own0, own1) of the tile; with agglomerates of different sizes below, on agglomerate
+  // boundaries (FusedArgs::agg_shift; two dependent index loads, issued here with the tile's other streams)
+  int own0 = a.halo_left, own1 = a.halo_left + a.owned;
+  if (a.par_out && a.agg_shift >= 0 && (a.lf_out || a.ld_out)) {
+    const int64_t n0 = e0 + a.halo_left, n1 = n0 + a.owned;
+    const int64_t s0 = n0 < ne ? a.first_out[a.par_out[n0]] : ne;
+    const int64_t s1 = n1 < ne ? a.first_out[a.par_out[n1]] : ne;
+    own0 = (int)(s0 - e0);
+    own1 = (int)(s1 - e0);
+  }
 
   if (tid < M) {
     buf0[-M + tid] = 0.0;
@@ -698,7 +713,7 @@ __global__ __launch_bounds__(NT) void btd_fused_kernel(FusedArgs a) {
   }
 
   // ---- store the iterate of the owned elements ---------------------------------------------
-  const int xo0 = a.halo_left, xo1 = a.halo_left + a.owned;
+  const int xo0 = own0, xo1 = own1;
   if (a.u_out) {
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
@@ -823,7 +838,7 @@ __global__ __launch_bounds__(NT) void btd_fused_kernel(FusedArgs a) {
       } else {
         for (int64_t k = lo * M; k < hi * M; ++k) acc += lfo[k * mc + c] * nxt[k - e0 * M];  // ascending fine row
       }
-      if (lo == f0 && hi == f1)
+      if (lo == f0 && hi == f1)  // (always, with the owned range on agglomerate boundaries)
         a.rc_out[J * mc + c] = acc;
       else
         atomicAdd(&a.rc_out[J * mc + c], acc);

@@ -415,7 +415,7 @@ int setup_transfer_btd(aggmg_ctx* ctx, const aggmg_op* L, const BtdDev* Abtd, in
   const int64_t Nf = L->m, Nc = L->n;
   if (Nf != nef * mf) return AGGMG_OK;
   Flags bad;
-  CHECK(bad.init(ctx, 1));
+  CHECK(bad.init(ctx, 2));  // [0]: pattern does not fit, [1]: largest agglomerate (transfer_vr_kernel)
   for (int mc = 1; mc <= 16; ++mc) {
     if (hint_mc > 0 && mc != hint_mc) continue;
     if (Nc % mc) continue;
@@ -428,8 +428,9 @@ int setup_transfer_btd(aggmg_ctx* ctx, const aggmg_op* L, const BtdDev* Abtd, in
     CHECK(bad.clear(ctx));
     LAUNCH(transfer_scatter_kernel, Nc, Nc, mf, mc, rho, (const int32_t*)L->csc.rowptr, (const int32_t*)L->csc.colind,
            (const double*)L->csc.vals, lf, bad.d);
-    int b1 = 0;
-    CHECK(bad.read(ctx, &b1));
+    int bf[2] = {0, 0};
+    CHECK(bad.read(ctx, bf));
+    const int b1 = bf[0];
     if (b1) {
       (void)hipFree(lf);
       continue;
@@ -462,8 +463,9 @@ int setup_transfer_btd(aggmg_ctx* ctx, const aggmg_op* L, const BtdDev* Abtd, in
     CHECK(bad.clear(ctx));
     LAUNCH(transfer_vr_kernel, nec, nec, nef, mf, mc, 64, (const int32_t*)L->csc.rowptr, (const int32_t*)L->csc.colind,
            (const double*)L->csc.vals, first, parent, lf, bad.d);
-    int b1 = 0;
-    CHECK(bad.read(ctx, &b1));
+    int bf[2] = {0, 0};
+    CHECK(bad.read(ctx, bf));
+    const int b1 = bf[0];
     if (b1) {
       (void)hipFree(lf), (void)hipFree(first), (void)hipFree(parent);
       continue;
@@ -477,6 +479,7 @@ int setup_transfer_btd(aggmg_ctx* ctx, const aggmg_op* L, const BtdDev* Abtd, in
     }
     out->mc = mc;
     out->rho = 0;
+    out->maxagg = bf[1];
     out->nec = nec;
     CHECK(setup_unit_column(ctx, out, Nf));
     *ok = true;

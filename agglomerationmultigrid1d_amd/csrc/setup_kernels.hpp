@@ -515,6 +515,7 @@ __global__ __launch_bounds__(kSetupThreads) void transfer_vr_kernel(int64_t nec,
     }
   }
   first[J] = (int32_t)(r0 / mf);
+  atomicMax(&bad[1], (int)(len / mf));  // bad[1]: the largest agglomerate (fine elements)
   if (J == nec - 1) first[nec] = (int32_t)nef;
   for (int64_t e = r0 / mf; e < (r0 + len) / mf; ++e) parent[e] = (int32_t)J;
 }

@@ -258,7 +258,7 @@ def test_north_star_size_multigrid_converges():
 
 
 def test_ragged_agglomerates_at_size_fused_equals_unfused():
-    """the parent / first-child maps and the two-part atomic restriction of levels whose agglomerates
+    """the parent / first-child maps and the restriction of levels whose agglomerates
     differ in size, at benchmark size: 2^20 DG p=3 elements on a perturbed mesh, three agglomerated levels with
     agglomerate sizes drawn from {2, ..., 6} (product builders + device constructors).  The fused kernels against
     the unfused composition (the same operators through the generic CSR / block kernels) on the residual at 1e-12
@@ -294,11 +294,11 @@ def test_ragged_agglomerates_at_size_fused_equals_unfused():
     x2 = ctx.alloc(N)
     H.vcycle_dev(z, ctx.to_device(2.0 * b), x2)
     assert np.linalg.norm(x2.download() - 2.0 * xf.download()) <= 1e-12 * np.linalg.norm(xf.download())
-    # three cycles in one call (atomic two-part restriction: equal to round-off, not bit for bit)
+    # three cycles in one call: bit for bit the separate cycles (owned ranges on agglomerate boundaries, plain stores)
     xa, xb = ctx.to_device(np.zeros(N)), ctx.alloc(N)
     for _ in range(3):
         H.vcycle_dev(xa, bd, xb)
         xa, xb = xb, xa
     xm = ctx.alloc(N)
     H.vcycles_dev(z, bd, xm, 3)
-    assert resid_of_diff(xa, xm) <= 1e-12 * nb
+    assert np.array_equal(xa.download(), xm.download())
