@@ -88,6 +88,29 @@ def test_cr_solve_matches_sparse_lu(mg, nb, m, ragged):
     H.free()
 
 
+@pytest.mark.parametrize("nb,m", [(7, 2), (513, 2), ((1 << 15) + 3, 2), (1500, 3), (33000, 4), (600, 7), (513, 8), (1 << 18, 2)])
+def test_cr_with_row_pivoting_inside_the_blocks(mg, nb, m):
+    """the equations of every block row in reverse order: the same solution, but every diagonal block (and every Schur
+    complement of the reduction) now needs its rows exchanged -- the stored permutations are not the identity, which the
+    diagonally dominant systems above never produce.  Exercises the permuted triangular solves of the back substitution
+    and the row-vector solves  a b^-1 = ((a U^-1) L^-1) P  behind the forward multipliers (cr_even_multipliers_kernel)."""
+    A0 = block_tridiag(nb, m, seed=nb * 17 + m)
+    N = A0.shape[0]
+    rev = (np.arange(N) // m) * m + (m - 1 - np.arange(N) % m)
+    A = sp.csc_matrix(A0.tocsr()[rev, :])
+    ctx, H = one_level(mg, A)
+    info = H.coarse_info()
+    assert info["on_device"] and info["block_size"] == m and info["probe_backward_error"] < 1e-13
+    b = np.random.default_rng(11).standard_normal(N)
+    xd, z = ctx.alloc(N), ctx.to_device(np.zeros(N))
+    H.vcycle_dev(z, ctx.to_device(b), xd, 0, 0, 1.0)
+    x = xd.download()
+    ref = spla.splu(A).solve(b)
+    assert np.linalg.norm(A @ x - b) <= 1e-12 * np.linalg.norm(b)
+    assert np.linalg.norm(x - ref) <= 1e-11 * np.linalg.norm(ref)
+    H.free()
+
+
 @pytest.mark.parametrize("nb,m", [(1 << 14, 1), (1 << 15, 2), (3 << 13, 1), (1 << 16, 4), (1 << 20, 1)])
 def test_cr_phases_reproduce_the_one_call_solve(mg, nb, m):
     """every 'rank' eliminates / back-substitutes the chunks of its own block range; the boundary system is solved
