@@ -360,6 +360,16 @@ def ragged_bench(mg, ctx, args, nPre, nPost, alpha):
     return out
 
 
+def _coarse_roofline(tag, coarse_ms):
+    """the kernel furthest below its roofline: HBM bytes of the coarsest solve's launches (PMC, profiles/)
+    over its event time in this run -- a latency-bound chain of log2(n) levels, reported so that it is not hidden"""
+    t = _traffic("coarse", tag)
+    if not t or not coarse_ms:
+        return {}
+    return {"traffic": t, "physical_GBs": t / (coarse_ms * 1e-3) / 1e9,
+            "physical_frac": t / (coarse_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+
+
 def _traffic(role, tag):
     tfile = os.path.join(ROOT, "profiles", "traffic.json")
     if not os.path.exists(tfile):
@@ -473,7 +483,8 @@ def cg_bench(mg, ctx, args, nPre, nPost, alpha):
                          "physical_frac": (traffic / (dms / dcnt * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                          "physical_frac_profile_mean": (traffic / (prof_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic and prof_ms else None,
                          "ms_per_launch": dms / dcnt, "launches_timed": dcnt},
-            "kernels": kern, "coarse_solve_ms_per_step": coarse_ms, "outer_solvers_to_1e-8": outer,
+            "kernels": kern, "coarse_solve_ms_per_step": coarse_ms, "coarse_solve": _coarse_roofline(f"cg_log2n{E}", coarse_ms),
+            "outer_solvers_to_1e-8": outer,
             "block_gs_extension": gs,
             "setup_s": t_gen + t_lib, "setup_generator_s": t_gen, "setup_library_s": t_lib}
 
@@ -667,7 +678,7 @@ def main():
                                  "V-cycles (bitwise), post-smoothing of cycle i and pre-smoothing of cycle i+1 in one "
                                  "fine-level launch"},
         "outer_solvers_to_1e-8": R["outer"],
-        "coarse_solve": R["coarse_info"],
+        "coarse_solve": dict(R["coarse_info"], **_coarse_roofline(f"dg_log2n{args.log2_elems}", coarse_step_ms)),
         # SURVEY 8d times the coarsest solve separately: the `coarse` entry of the per-kernel table
         # (HIP events, untimed second pass)
         "coarse_solve_ms_per_step": coarse_step_ms,

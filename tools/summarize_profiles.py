@@ -143,6 +143,10 @@ for nm in names:
     lines.append(f"| {nm} | `{k}` ({g}) | {vg} | {ld} | {statistics.mean(vals):.4f} | {statistics.median(vals):.4f} | "
                  f"{min(vals):.4f} | {f if f is None else round(f, 1)} | {w if w is None else round(w, 1)} | "
                  f"{'' if hb is None else f'{hb:.4g}'} | {tbs} | {er} | {ew} |")
+    if hb is not None and nm.startswith("coarse_"):   # the coarsest solve: its launches summed under one key
+        ck = f"coarse_{kind}_log2n{E}"
+        traffic[ck] = traffic.get(ck, 0.0) + hb
+        traffic[ck + "_ms_profile_mean"] = traffic.get(ck + "_ms_profile_mean", 0.0) + statistics.mean(vals)
     if hb is not None and nm.startswith("fused_"):
         key = nm.replace("fused_", "chain_") if kind == "cg" else nm
         traffic[f"{key}_{kind}_log2n{E}"] = hb
