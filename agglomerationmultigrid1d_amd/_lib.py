@@ -132,6 +132,7 @@ SYMBOLS = {
     "aggmg_hier_level_kind": (c_int, [_P, _P, c_int, POINTER(c_int)]),
     "aggmg_hier_coarse_info": (c_int, [_P, _P, POINTER(c_int), POINTER(c_int), POINTER(c_double)]),
     "aggmg_hier_coarse_probe": (c_int, [_P, _P, POINTER(c_double)]),
+    "aggmg_hier_coarse_tail": (c_int, [_P, _P, POINTER(c_int), POINTER(c_int64)]),
     "aggmg_hier_last_coarse_ms": (c_int, [_P, _P, POINTER(c_double)]),
     "aggmg_copy_segments_dev": (c_int, [_P, c_int, POINTER(_P), POINTER(_P), POINTER(c_int64), POINTER(c_int64),
                                         POINTER(c_int64), POINTER(c_int64)]),

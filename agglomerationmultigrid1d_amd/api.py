@@ -816,7 +816,7 @@ class MeshHierarchy:
         return r.value, s_.value, n.value
 
     def coarse_info(self):
-        """-> dict(on_device, block_size, cond_est, probe_backward_error) of the coarsest direct solver;
+        """-> dict(on_device, block_size, cond_est, probe_backward_error, tail, tail_blocks) of the coarsest direct solver;
         probe_backward_error: ||d - A x|| / ||d|| of the probe solve that aggmg_hier_create accepts (< 1e-10) or rejects the
         device factorisation on (-1: none attempted)"""
         a, b, c = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_double(0.0)
@@ -824,7 +824,10 @@ class MeshHierarchy:
                                                            ctypes.byref(b), ctypes.byref(c)))
         e = ctypes.c_double(0.0)
         self.ctx.check(self.ctx.lib.aggmg_hier_coarse_probe(self.ctx.handle, self.handle, ctypes.byref(e)))
-        return dict(on_device=bool(a.value), block_size=b.value, cond_est=c.value, probe_backward_error=e.value)
+        k, nb = ctypes.c_int(0), ctypes.c_int64(0)
+        self.ctx.check(self.ctx.lib.aggmg_hier_coarse_tail(self.ctx.handle, self.handle, ctypes.byref(k), ctypes.byref(nb)))
+        return dict(on_device=bool(a.value), block_size=b.value, cond_est=c.value, probe_backward_error=e.value,
+                    tail=("none", "cyclic reduction", "parallel cyclic reduction")[k.value], tail_blocks=nb.value)
 
     def last_coarse_ms(self):
         ms = ctypes.c_double(0.0)

@@ -1028,6 +1028,32 @@ static CrStageArgs cr_make_args(const CrDev& cr, const CrStage& S, bool tail) {
   return A;
 }
 
+// the tail system: parallel cyclic reduction when set-up prepared it, the register-blocked reduction otherwise
+template <int M>
+static void cr_launch_tail(aggmg_ctx* ctx, CrDev& cr, const CrStageArgs& T, size_t tail_lds, const double* d, const double* db,
+                           double* x) {
+  if constexpr (M <= 2) {
+    if (cr.pcr.valid) {
+      PcrArgs P;
+      std::memset(&P, 0, sizeof(P));
+      P.mult = cr.pcr.mult;
+      P.lu = cr.pcr.lu;
+      P.perm = cr.pcr.perm;
+      P.n = cr.pcr.n;
+      P.L = cr.pcr.L;
+      P.dstride = T.dstride;
+#ifdef AGGMG_CR_TRACE
+      P.trace = g_cr_trace;
+#endif
+      const unsigned threads = (unsigned)((cr.pcr.n + 63) / 64 * 64);
+      hipLaunchKernelGGL((cr_pcr_tail_kernel<M>), dim3(1), dim3(threads), (size_t)2 * cr.pcr.n * M * sizeof(double), ctx->stream,
+                         P, d, db, x);
+      return;
+    }
+  }
+  hipLaunchKernelGGL((cr_tail_kernel<M>), dim3(1), dim3(kCrThreads), tail_lds, ctx->stream, T, d, db, x);
+}
+
 // Stages s0.. and the tail for the right-hand side d (+ db) of stage s0's input system into x:
 // forward launches stage by stage (the last one goes on to solve the tail system in its
 // last-arriving workgroup), then the back substitutions in reverse.
@@ -1044,7 +1070,7 @@ static int cr_solve_from(aggmg_ctx* ctx, CrDev& cr, int s0, const double* d, con
     return e && e[0] == '1';
   }();
   if (s0 >= ns) {
-    hipLaunchKernelGGL((cr_tail_kernel<M>), dim3(1), dim3(kCrThreads), tail_lds, ctx->stream, T, d, db, x);
+    cr_launch_tail<M>(ctx, cr, T, tail_lds, d, db, x);
     HIPCHK(hipGetLastError());
     return AGGMG_OK;
   }
@@ -1062,8 +1088,7 @@ static int cr_solve_from(aggmg_ctx* ctx, CrDev& cr, int s0, const double* d, con
       hipLaunchKernelGGL((cr_stage_forward_kernel<M, false>), dim3(grid), dim3(cr_stage_threads()), lds, ctx->stream, A, din,
                          dinb, S.partR, S.partL, T, (double*)nullptr, (unsigned int*)nullptr);
       if (s == ns - 1)
-        hipLaunchKernelGGL((cr_tail_kernel<M>), dim3(1), dim3(kCrThreads), tail_lds, ctx->stream, T,
-                           (const double*)S.partR, (const double*)S.partL, S.xq);
+        cr_launch_tail<M>(ctx, cr, T, tail_lds, (const double*)S.partR, (const double*)S.partL, S.xq);
     }
     din = S.partR;
     dinb = S.partL;
@@ -1266,18 +1291,26 @@ extern "C" int aggmg_hier_create(aggmg_ctx* ctx, int nlevels, aggmg_op* const* s
         // alone -- solve one probe system and keep it only if the backward error is at round-off level.
         Level& lc = h->lv[nlevels - 1];
         const int64_t Nc = lc.N;
-        double nd = 0.0, nr = 0.0;
-        CHECK(setup_probe_vector(ctx, Nc, lc.u[1]));
-        HIPCHK(hipMemsetAsync(lc.rhs, 0, (size_t)Nc * sizeof(double), ctx->stream));
-        CHECK(setup_csc_scatter(ctx, Ac, lc.u[1], 1.0, lc.rhs));                  // d = A w
-        CHECK(cr_solve(ctx, h->cr, lc.rhs, lc.u[0], nlevels - 1));                // x = CR(d)
-        HIPCHK(hipMemcpyAsync(lc.tmp, lc.rhs, (size_t)Nc * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
-        CHECK(setup_csc_scatter(ctx, Ac, lc.u[0], -1.0, lc.tmp));                 // r = d - A x
-        CHECK(aggmg_norm2_dev(ctx, lc.rhs, Nc, &nd));
-        CHECK(aggmg_norm2_dev(ctx, lc.tmp, Nc, &nr));
-        h->cr_probe_backward_error = nd > 0.0 ? nr / nd : 0.0;
-        for (double* p : {lc.u[0], lc.u[1], lc.rhs, lc.tmp}) HIPCHK(hipMemsetAsync(p, 0, (size_t)lc.Nalloc * sizeof(double), ctx->stream));
         const double tol = 1e-10;
+        auto probe_once = [&]() -> int {
+          double nd = 0.0, nr = 0.0;
+          CHECK(setup_probe_vector(ctx, Nc, lc.u[1]));
+          HIPCHK(hipMemsetAsync(lc.rhs, 0, (size_t)Nc * sizeof(double), ctx->stream));
+          CHECK(setup_csc_scatter(ctx, Ac, lc.u[1], 1.0, lc.rhs));                  // d = A w
+          CHECK(cr_solve(ctx, h->cr, lc.rhs, lc.u[0], nlevels - 1));                // x = CR(d)
+          HIPCHK(hipMemcpyAsync(lc.tmp, lc.rhs, (size_t)Nc * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+          CHECK(setup_csc_scatter(ctx, Ac, lc.u[0], -1.0, lc.tmp));                 // r = d - A x
+          CHECK(aggmg_norm2_dev(ctx, lc.rhs, Nc, &nd));
+          CHECK(aggmg_norm2_dev(ctx, lc.tmp, Nc, &nr));
+          h->cr_probe_backward_error = nd > 0.0 ? nr / nd : 0.0;
+          for (double* p : {lc.u[0], lc.u[1], lc.rhs, lc.tmp}) HIPCHK(hipMemsetAsync(p, 0, (size_t)lc.Nalloc * sizeof(double), ctx->stream));
+          return AGGMG_OK;
+        };
+        CHECK(probe_once());
+        if (!(h->cr_probe_backward_error < tol) && h->cr.pcr.valid) {  // the tail once more in its register-blocked form
+          h->cr.pcr.valid = false;
+          CHECK(probe_once());
+        }
         if (!(h->cr_probe_backward_error < tol)) cr_discard(&h->cr);              // NaN included
       }
       if (!h->cr.valid && coarse_mode == AGGMG_COARSE_DEVICE_CR)
@@ -1799,6 +1832,13 @@ extern "C" int aggmg_hier_coarse_info(aggmg_ctx* ctx, const aggmg_hier* h, int* 
   if (on_device) *on_device = h->cr.valid ? 1 : 0;
   if (block_size) *block_size = h->cr.valid ? h->cr.m : 0;
   if (cond_est) *cond_est = h->cr.valid ? h->cr.cond_est : 0.0;
+  return AGGMG_OK;
+}
+
+extern "C" int aggmg_hier_coarse_tail(aggmg_ctx* ctx, const aggmg_hier* h, int* kind, int64_t* blocks) {
+  if (!ctx || !h) return AGGMG_ERR_ARGUMENT;
+  if (kind) *kind = !h->cr.valid ? 0 : h->cr.pcr.valid ? 2 : 1;
+  if (blocks) *blocks = h->cr.valid ? h->cr.tail.n_in : 0;
   return AGGMG_OK;
 }
 

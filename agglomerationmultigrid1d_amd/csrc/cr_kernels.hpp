@@ -874,4 +874,122 @@ __global__ __launch_bounds__(kCrThreads) CR_WAVES_ATTR void cr_stage_backward_ke
   CR_TRACE_FLUSH(A);
 }
 
+// ---- the tail by PARALLEL cyclic reduction ---------------------------------------------------------------------------
+// The boundary system the last stage leaves (a few hundred blocks) is a chain of log2(n) dependent levels either way;
+// the register-blocked cyclic reduction above takes them three at a time with 32, 4, 1 threads working and pays 1.6 - 3.5 us
+// per step down and again per step up (tools/cr_trace.py).  Parallel cyclic reduction keeps every row through all levels:
+// at level k row i drops its couplings to rows i -+ 2^k,
+//     d_i <- d_i - alpha_i^k d_{i-2^k} - gamma_i^k d_{i+2^k},
+// with the multipliers alpha = a b^-1, gamma = c b^-1 of every (level, row) formed at set-up (pcr_reduce_kernel), after
+// ceil(log2 n) levels every row stands alone, x_i = b_i \ d_i: one thread per row, two small matrix-vector products and a
+// barrier per level, no way back up.  The multipliers of the first D levels are fetched up front, the slot of a level is
+// refilled with level k + D as soon as it has been used.
+constexpr int kPcrMaxLevels = 10;  // up to 1024 rows, one thread each
+struct PcrArgs {
+  const double* mult;   // [L][n][2][M][M]
+  const double* lu;     // [n][M][M]  diagonal blocks after the last level: pivoted LU, reciprocal pivots
+  const int32_t* perm;  // [n][M]
+  int n, L;
+  int dstride;          // doubles between consecutive blocks of d0 / d0b (0: M)
+#ifdef AGGMG_CR_TRACE
+  unsigned long long* trace;
+#endif
+};
+
+template <int M>
+__global__ __launch_bounds__(1024) void cr_pcr_tail_kernel(PcrArgs P, const double* __restrict__ d0,
+                                                            const double* __restrict__ d0b, double* __restrict__ x0) {
+  extern __shared__ double sh[];
+  constexpr int D = M == 1 ? kPcrMaxLevels : 5, W = 2 * M * M;
+  const int i = threadIdx.x, n = P.n;
+  const bool act = i < n;
+  const int ic = act ? i : n - 1;
+#ifdef AGGMG_CR_TRACE
+  unsigned long long t_in = 0;
+  if (i == 0) t_in = wall_clock64();
+#endif
+  double f[D][W];
+#pragma unroll
+  for (int j = 0; j < D; ++j) {
+    const int lv = j < P.L ? j : 0;
+    const double* src = P.mult + ((int64_t)lv * n + ic) * W;
+#pragma unroll
+    for (int k = 0; k < W / 2; ++k) {
+      const double2 t = reinterpret_cast<const double2*>(src)[k];
+      f[j][2 * k] = t.x, f[j][2 * k + 1] = t.y;
+    }
+  }
+  double luf[M * M];
+  int32_t pf[M];
+#pragma unroll
+  for (int k = 0; k < M * M; ++k) luf[k] = P.lu[(int64_t)ic * (M * M) + k];
+#pragma unroll
+  for (int k = 0; k < M; ++k) pf[k] = P.perm[(int64_t)ic * M + k];
+  const int ds = P.dstride ? P.dstride : M;
+  double v[M];
+#pragma unroll
+  for (int e = 0; e < M; ++e) v[e] = d0[(int64_t)ic * ds + e];
+  if (d0b) {
+#pragma unroll
+    for (int e = 0; e < M; ++e) v[e] += d0b[(int64_t)ic * ds + e];
+  }
+  double* cur = sh;
+  double* nxt = sh + (int64_t)n * M;
+  if (act) {
+#pragma unroll
+    for (int e = 0; e < M; ++e) cur[i * M + e] = v[e];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < kPcrMaxLevels; ++k) {
+    if (k < P.L) {
+      const int s = 1 << k;
+      const int il = ic - s >= 0 ? ic - s : 0, ir = ic + s < n ? ic + s : n - 1;  // (missing neighbours: zero multipliers)
+      double dl[M], dr[M];
+#pragma unroll
+      for (int e = 0; e < M; ++e) dl[e] = cur[il * M + e], dr[e] = cur[ir * M + e];
+#pragma unroll
+      for (int r = 0; r < M; ++r) {
+        double t = v[r];
+#pragma unroll
+        for (int q = 0; q < M; ++q) t -= f[k % D][r * M + q] * dl[q];
+#pragma unroll
+        for (int q = 0; q < M; ++q) t -= f[k % D][M * M + r * M + q] * dr[q];
+        v[r] = t;
+      }
+      if (k + D < P.L) {  // the slot is free: the multipliers of level k + D
+        const double* src = P.mult + ((int64_t)(k + D) * n + ic) * W;
+#pragma unroll
+        for (int q = 0; q < W / 2; ++q) {
+          const double2 t = reinterpret_cast<const double2*>(src)[q];
+          f[k % D][2 * q] = t.x, f[k % D][2 * q + 1] = t.y;
+        }
+      }
+      if (k + 1 < P.L) {
+        if (act) {
+#pragma unroll
+          for (int e = 0; e < M; ++e) nxt[i * M + e] = v[e];
+        }
+        __syncthreads();
+        double* t = cur;
+        cur = nxt;
+        nxt = t;
+      }
+    }
+  }
+  double y[M];
+  cr_lu_solve_reg<M>(luf, pf, v, y);
+  if (act) {
+#pragma unroll
+    for (int e = 0; e < M; ++e) x0[(int64_t)i * M + e] = y[e];
+  }
+#ifdef AGGMG_CR_TRACE
+  if (i == 0 && P.trace) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    P.trace[(1 * kCrTraceWgs + 0) * 16 + 0] = t_in;
+    P.trace[(1 * kCrTraceWgs + 0) * 16 + 15] = wall_clock64();
+  }
+#endif
+}
+
 }  // namespace aggmg

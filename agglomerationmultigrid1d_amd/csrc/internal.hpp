@@ -235,6 +235,22 @@ struct CrDev {
   double *d0 = nullptr, *x0 = nullptr;  // staging for padded systems (N not a multiple of m) / in-place calls
   unsigned int* ticket = nullptr;       // last-arriving-workgroup counter of the fused forward + tail launch
   double cond_est = 0.0;
+  // the tail's system by parallel cyclic reduction (cr_pcr_tail_kernel; block sizes 1, 2, up to 1024 blocks): multipliers
+  // of every (level, row), final diagonal blocks factored; allocations in `owned`
+  struct Pcr {
+    bool valid = false;
+    int n = 0, L = 0;
+    double* mult = nullptr;
+    double* lu = nullptr;
+    int32_t* perm = nullptr;
+  } pcr;
+  // set-up only: copies of the (a, b, c) blocks of the small levels, until the plan says which one the tail starts at
+  struct Raw {
+    int level;
+    int64_t n;
+    double *a, *b, *c;
+  };
+  std::vector<Raw> raw;
 };
 
 // step split and LDS layout of a stage of q levels with block size m

@@ -497,6 +497,14 @@ static int cr_levels_t(aggmg_ctx* ctx, CrDev* cr, double* a, double* b, double* 
   const int mm2 = M * M;
   auto own = [&](void* p) { cr->owned.push_back(p); };
   while (n > 1) {
+    if (M <= 2 && n <= 1024) {  // a candidate for the tail's first level (parallel cyclic reduction, setup_pcr)
+      CrDev::Raw R{(int)cr->lv.size(), n, nullptr, nullptr, nullptr};
+      for (double** p : {&R.a, &R.b, &R.c}) CHECK(dalloc(ctx, p, n * mm2, false));
+      HIPCHK(hipMemcpyAsync(R.a, a, n * mm2 * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+      HIPCHK(hipMemcpyAsync(R.b, b, n * mm2 * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+      HIPCHK(hipMemcpyAsync(R.c, c, n * mm2 * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+      cr->raw.push_back(R);
+    }
     const int64_t ne = (n + 1) / 2, no = n / 2;
     double *lu = nullptr, *Za = nullptr, *Zc = nullptr, *a2 = nullptr, *b2 = nullptr, *c2 = nullptr;
     int32_t* perm = nullptr;
@@ -561,7 +569,60 @@ static int cr_levels_t(aggmg_ctx* ctx, CrDev* cr, double* a, double* b, double* 
   return AGGMG_OK;
 }
 
+static void cr_raw_release(CrDev* c) {
+  for (auto& R : c->raw)
+    for (double* p : {R.a, R.b, R.c})
+      if (p) (void)hipFree(p);
+  c->raw.clear();
+}
+
+// parallel cyclic reduction of the tail's system (internal.hpp CrDev::Pcr): log2(n) levels of multipliers from the blocks
+// kept in `raw`; leaves pcr.valid false when a diagonal block of some level is singular (the register-blocked tail stays)
+template <int M>
+static int setup_pcr_t(aggmg_ctx* ctx, CrDev* cr, const CrDev::Raw& R) {
+  const int64_t n = R.n;
+  constexpr int MM = M * M;
+  int L = 0;
+  while (((int64_t)1 << L) < n) ++L;
+  if (L < 1 || L > kPcrMaxLevels) return AGGMG_OK;
+  double *mult = nullptr, *lu = nullptr, *a2 = nullptr, *b2 = nullptr, *c2 = nullptr;
+  int32_t* perm = nullptr;
+  CHECK(dalloc(ctx, &mult, (int64_t)L * n * 2 * MM, true));
+  CHECK(dalloc(ctx, &lu, n * MM, false));
+  CHECK(dalloc(ctx, &perm, n * M, false));
+  Tmp ta, tb, tc;
+  CHECK(tmp_alloc(ctx, &ta, (size_t)n * MM * sizeof(double), false));
+  CHECK(tmp_alloc(ctx, &tb, (size_t)n * MM * sizeof(double), false));
+  CHECK(tmp_alloc(ctx, &tc, (size_t)n * MM * sizeof(double), false));
+  a2 = ta.as<double>(), b2 = tb.as<double>(), c2 = tc.as<double>();
+  Flags bad;
+  CHECK(bad.init(ctx, 1));
+  double *a = R.a, *b = R.b, *c = R.c;  // (the copies are scratch from here on: ping-pong with a2, b2, c2)
+  for (int k = 0; k < L; ++k) {
+    LAUNCH((pcr_factor_kernel<M>), n, n, (const double*)b, lu, perm, bad.d);
+    LAUNCH((pcr_reduce_kernel<M>), n, n, (int64_t)1 << k, (const double*)a, (const double*)b, (const double*)c,
+           (const double*)lu, (const int32_t*)perm, mult + (int64_t)k * n * 2 * MM, a2, b2, c2);
+    std::swap(a, a2), std::swap(b, b2), std::swap(c, c2);
+  }
+  LAUNCH((pcr_factor_kernel<M>), n, n, (const double*)b, lu, perm, bad.d);
+  int b1 = 0;
+  CHECK(bad.read(ctx, &b1));
+  if (b1) {
+    (void)hipFree(mult), (void)hipFree(lu), (void)hipFree(perm);
+    return AGGMG_OK;
+  }
+  cr->owned.push_back(mult), cr->owned.push_back(lu), cr->owned.push_back(perm);
+  cr->pcr.n = (int)n;
+  cr->pcr.L = L;
+  cr->pcr.mult = mult;
+  cr->pcr.lu = lu;
+  cr->pcr.perm = perm;
+  cr->pcr.valid = true;
+  return AGGMG_OK;
+}
+
 static void cr_release(CrDev* c) {
+  cr_raw_release(c);
   for (void* p : c->owned)
     if (p) (void)hipFree(p);
   *c = CrDev();
@@ -786,6 +847,16 @@ int setup_cr(aggmg_ctx* ctx, const aggmg_op* Ac, int hint_m, CrDev* cr) {
     }
     cr->owned.push_back(arena);
   }
+  // the tail's system by parallel cyclic reduction where it applies (AGGMG_CR_PCR=0: off)
+  if (m <= 2 && cr->tail.nsteps >= 1 && env_int("AGGMG_CR_PCR", 1, 0, 1)) {
+    for (const auto& R : cr->raw)
+      if (R.level == cr->tail.l0 && R.n == cr->tail.n_in) {
+        if (m == 1) CHECK(setup_pcr_t<1>(ctx, cr, R));
+        if (m == 2) CHECK(setup_pcr_t<2>(ctx, cr, R));
+      }
+  }
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  cr_raw_release(cr);
   if (n * m != N) {
     CHECK(dz(n * m, &cr->d0));
     CHECK(dz(n * m, &cr->x0));

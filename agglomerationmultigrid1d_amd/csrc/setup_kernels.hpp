@@ -801,6 +801,141 @@ __global__ __launch_bounds__(kSetupThreads) void cr_even_multipliers_kernel(int6
   }
 }
 
+// ---- parallel cyclic reduction of the tail's boundary system (cr_kernels.hpp: cr_pcr_tail_kernel) ----------------------
+// blk B^-1 by row-vector solves with the pivoted factors P B = L U (F: unit-lower L, U with RECIPROCAL pivots)
+template <int M>
+__device__ __forceinline__ void lu_rowsolve_dev(const double (&F)[M][M], const int (&pm)[M], const double (&blk)[M][M],
+                                                double (&out)[M][M]) {
+#pragma unroll
+  for (int r = 0; r < M; ++r) {
+    double z[M], w[M];
+#pragma unroll
+    for (int q = 0; q < M; ++q) {  // z U = blk_r
+      double t = blk[r][q];
+#pragma unroll
+      for (int p2 = 0; p2 < q; ++p2) t -= z[p2] * F[p2][q];
+      z[q] = t * F[q][q];
+    }
+#pragma unroll
+    for (int q = M - 1; q >= 0; --q) {  // w L = z
+      double t = z[q];
+#pragma unroll
+      for (int p2 = q + 1; p2 < M; ++p2) t -= w[p2] * F[p2][q];
+      w[q] = t;
+    }
+#pragma unroll
+    for (int c2 = 0; c2 < M; ++c2) {  // (w P)_c = w_k for c = perm[k]
+      double t = 0.0;
+#pragma unroll
+      for (int q = 0; q < M; ++q) t = (pm[q] == c2) ? w[q] : t;
+      out[r][c2] = t;
+    }
+  }
+}
+
+// pivoted LU of every diagonal block of one PCR level (reciprocal pivots), bad[0] = 1 on a singular block
+template <int M>
+__global__ __launch_bounds__(kSetupThreads) void pcr_factor_kernel(int64_t n, const double* __restrict__ b,
+                                                                   double* __restrict__ lu, int32_t* __restrict__ perm,
+                                                                   int* __restrict__ bad) {
+  const int64_t i = (int64_t)blockIdx.x * kSetupThreads + threadIdx.x;
+  if (i >= n) return;
+  double B[M][M];
+  int pm[M];
+#pragma unroll
+  for (int r = 0; r < M; ++r)
+#pragma unroll
+    for (int q = 0; q < M; ++q) B[r][q] = b[i * M * M + r * M + q];
+  if (!lu_perm_dev<M>(B, pm)) {
+    bad[0] = 1;
+    return;
+  }
+#pragma unroll
+  for (int r = 0; r < M; ++r) {
+    perm[i * M + r] = pm[r];
+#pragma unroll
+    for (int q = 0; q < M; ++q) lu[i * M * M + r * M + q] = r == q ? 1.0 / B[r][r] : B[r][q];
+  }
+}
+
+// one PCR level at distance s: row i is rid of its couplings to rows i - s and i + s,
+//   alpha = a_i b_{i-s}^-1, gamma = c_i b_{i+s}^-1  (kept: mult[i] = (alpha, gamma); zero where the neighbour does not exist)
+//   a'_i = -alpha a_{i-s},  c'_i = -gamma c_{i+s},  b'_i = b_i - alpha c_{i-s} - gamma a_{i+s}   (couplings to i -+ 2s)
+template <int M>
+__global__ __launch_bounds__(kSetupThreads) void pcr_reduce_kernel(int64_t n, int64_t s, const double* __restrict__ a,
+                                                                   const double* __restrict__ b, const double* __restrict__ c,
+                                                                   const double* __restrict__ lu, const int32_t* __restrict__ perm,
+                                                                   double* __restrict__ mult, double* __restrict__ a2,
+                                                                   double* __restrict__ b2, double* __restrict__ c2) {
+  const int64_t i = (int64_t)blockIdx.x * kSetupThreads + threadIdx.x;
+  if (i >= n) return;
+  constexpr int MM = M * M;
+  double Bn[M][M], An[M][M], Cn[M][M];
+#pragma unroll
+  for (int r = 0; r < M; ++r)
+#pragma unroll
+    for (int q = 0; q < M; ++q) {
+      Bn[r][q] = b[i * MM + r * M + q];
+      An[r][q] = 0.0;
+      Cn[r][q] = 0.0;
+    }
+#pragma unroll
+  for (int side = 0; side < 2; ++side) {
+    const int64_t j = side == 0 ? i - s : i + s;
+    double X[M][M];
+#pragma unroll
+    for (int r = 0; r < M; ++r)
+#pragma unroll
+      for (int q = 0; q < M; ++q) X[r][q] = 0.0;
+    if (j >= 0 && j < n) {
+      double F[M][M], blk[M][M], aj[M][M], cj[M][M];
+      int pm[M];
+#pragma unroll
+      for (int r = 0; r < M; ++r) {
+        pm[r] = perm[j * M + r];
+#pragma unroll
+        for (int q = 0; q < M; ++q) {
+          F[r][q] = lu[j * MM + r * M + q];
+          blk[r][q] = (side == 0 ? a : c)[i * MM + r * M + q];
+          aj[r][q] = a[j * MM + r * M + q];
+          cj[r][q] = c[j * MM + r * M + q];
+        }
+      }
+      lu_rowsolve_dev<M>(F, pm, blk, X);
+#pragma unroll
+      for (int r = 0; r < M; ++r)
+#pragma unroll
+        for (int q = 0; q < M; ++q) {
+          double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+          for (int k = 0; k < M; ++k) {
+            t1 += X[r][k] * aj[k][q];
+            t2 += X[r][k] * cj[k][q];
+          }
+          if (side == 0) {  // row i - s: its a couples to i - 2s, its c back to i
+            An[r][q] = -t1;
+            Bn[r][q] -= t2;
+          } else {          // row i + s: its a couples back to i, its c to i + 2s
+            Bn[r][q] -= t1;
+            Cn[r][q] = -t2;
+          }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < M; ++r)
+#pragma unroll
+      for (int q = 0; q < M; ++q) mult[i * 2 * MM + side * MM + r * M + q] = X[r][q];
+  }
+#pragma unroll
+  for (int r = 0; r < M; ++r)
+#pragma unroll
+    for (int q = 0; q < M; ++q) {
+      a2[i * MM + r * M + q] = An[r][q];
+      b2[i * MM + r * M + q] = Bn[r][q];
+      c2[i * MM + r * M + q] = Cn[r][q];
+    }
+}
+
 // even block rows: Schur complement blocks of the next level
 template <int M>
 __global__ __launch_bounds__(kSetupThreads) void cr_schur_even_kernel(int64_t n, int64_t n_even, const double* __restrict__ a,

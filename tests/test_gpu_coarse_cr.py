@@ -69,6 +69,10 @@ def test_cr_solve_matches_sparse_lu(mg, nb, m, ragged):
     ctx, H = one_level(mg, A)
     info = H.coarse_info()
     assert info["on_device"] and 1 <= info["block_size"] <= 8   # the smallest block size that fits the band
+    # the boundary system of the chunk stages (or a small system as a whole) by parallel cyclic reduction where set-up
+    # offers it: block sizes 1 and 2, 2 .. 1024 blocks
+    want = "parallel cyclic reduction" if info["block_size"] <= 2 and 2 <= info["tail_blocks"] <= 1024 else "cyclic reduction"
+    assert info["tail"] == want, info
     rng = np.random.default_rng(5)
     b = rng.standard_normal(N)
     bd, xd, z = ctx.to_device(b), ctx.alloc(N), ctx.to_device(np.zeros(N))
