@@ -443,4 +443,5 @@ int coarse_chunk_forward_interleaved(aggmg_ctx* ctx, aggmg_hier* h, const double
 int coarse_boundary_solve_interleaved(aggmg_ctx* ctx, aggmg_hier* h, const double* Z, double* xq);
 void cr_discard(CrDev* cr);                                                  // frees the factors, valid = false
 int setup_probe_vector(aggmg_ctx* ctx, int64_t n, double* w);                // hash-random entries in [-1, 1)
+int setup_smooth_vector(aggmg_ctx* ctx, int64_t n, double* w);               // 1 + cos(pi i / n) / 2
 int setup_csc_scatter(aggmg_ctx* ctx, const aggmg_op* A, const double* x, double sign, double* y);  // y += sign A x

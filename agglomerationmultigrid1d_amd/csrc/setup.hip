@@ -659,6 +659,19 @@ int setup_probe_vector(aggmg_ctx* ctx, int64_t n, double* w) {
   return AGGMG_OK;
 }
 
+// a smooth positive vector, 1 + cos(pi i / n) / 2: as a RIGHT-HAND SIDE of an elliptic coarse operator it asks for a large
+// smooth solution -- where a reduction that accumulates like an inverse loses most against one that substitutes back
+__global__ __launch_bounds__(kSetupThreads) void smooth_vector_kernel(int64_t n, double* __restrict__ w) {
+  const int64_t i = (int64_t)blockIdx.x * kSetupThreads + threadIdx.x;
+  if (i >= n) return;
+  w[i] = 1.0 + 0.5 * cos(3.141592653589793 * (double)i / (double)n);
+}
+
+int setup_smooth_vector(aggmg_ctx* ctx, int64_t n, double* w) {
+  LAUNCH(smooth_vector_kernel, n, n, w);
+  return AGGMG_OK;
+}
+
 int setup_csc_scatter(aggmg_ctx* ctx, const aggmg_op* A, const double* x, double sign, double* y) {
   LAUNCH(csc_scatter_kernel, A->n, A->n, (const int32_t*)A->csc.rowptr, (const int32_t*)A->csc.colind,
          (const double*)A->csc.vals, x, sign, y);
