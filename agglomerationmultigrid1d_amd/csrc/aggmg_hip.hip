@@ -1316,7 +1316,7 @@ extern "C" int aggmg_hier_create(aggmg_ctx* ctx, int nlevels, aggmg_op* const* s
           // The parallel cyclic reduction of the tail accumulates like an inverse; on an ill-conditioned tail system (a
           // small coarsest operator taken as a whole: Neumann end, Dirichlet penalty) its residual for a right-hand side
           // with a large smooth solution was measured at 5000 x the register-blocked form's (1.8e-8 against 3.4e-12 of
-          // ||d||, tools/exp_pcr_accuracy.py), on the boundary systems of the benchmarked hierarchies at 1 - 4 x.  So it
+          // ||d||, tests/exp_pcr_accuracy.py), on the boundary systems of the benchmarked hierarchies at 1 - 4 x.  So it
           // is kept on evidence as well: both forms solve one such system, and the parallel one stays only where its
           // residual is within 8 x of the other's.
           auto smooth_residual = [&](double* res) -> int {

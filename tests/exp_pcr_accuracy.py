@@ -1,4 +1,5 @@
-"""Accuracy of the tail forms of the coarsest solve on the config-5 shaped hierarchy of tests/test_gpu_chain.py (coarsest level:
+"""(a measurement script, not a test: it lives here because it imports the oracle, which tools/ may not)
+Accuracy of the tail forms of the coarsest solve on the config-5 shaped hierarchy of tests/test_gpu_chain.py (coarsest level:
 DG p = 0, n scalar rows, Neumann / Dirichlet-penalty ends): probe backward error and the V-cycle's distance to the oracle's,
 parallel cyclic reduction against the register-blocked cyclic reduction (AGGMG_CR_PCR=0)."""
 import os
