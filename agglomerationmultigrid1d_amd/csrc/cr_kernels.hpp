@@ -896,11 +896,13 @@ struct PcrArgs {
 #endif
 };
 
-template <int M>
-__global__ __launch_bounds__(1024) void cr_pcr_tail_kernel(PcrArgs P, const double* __restrict__ d0,
-                                                            const double* __restrict__ d0b, double* __restrict__ x0) {
+// D: levels of multipliers a thread holds at once.  Up to 512 rows (TPB = 512: two waves per SIMD, 256 registers) that is
+// all of them, fetched in one batch before the first level; 1024 rows leave 128 registers per thread: five at block size 2.
+template <int M, int D, int TPB>
+__global__ __launch_bounds__(TPB) void cr_pcr_tail_kernel(PcrArgs P, const double* __restrict__ d0,
+                                                           const double* __restrict__ d0b, double* __restrict__ x0) {
   extern __shared__ double sh[];
-  constexpr int D = M == 1 ? kPcrMaxLevels : 5, W = 2 * M * M;
+  constexpr int W = 2 * M * M;
   const int i = threadIdx.x, n = P.n;
   const bool act = i < n;
   const int ic = act ? i : n - 1;
