@@ -1046,12 +1046,14 @@ static void cr_launch_tail(aggmg_ctx* ctx, CrDev& cr, const CrStageArgs& T, size
       P.trace = g_cr_trace;
 #endif
       const unsigned threads = (unsigned)((cr.pcr.n + 63) / 64 * 64);
-      const size_t lds = (size_t)2 * cr.pcr.n * M * sizeof(double);
-      if (threads <= 512)
-        hipLaunchKernelGGL((cr_pcr_tail_kernel<M, kPcrMaxLevels, 512>), dim3(1), dim3(threads), lds, ctx->stream, P, d, db, x);
-      else
-        hipLaunchKernelGGL((cr_pcr_tail_kernel<M, (M == 1 ? kPcrMaxLevels : 5), 1024>), dim3(1), dim3(threads), lds, ctx->stream, P,
-                           d, db, x);
+      const size_t lds = (size_t)2 * (cr.pcr.n + 1) * M * sizeof(double);
+      if (cr.pcr.pre) {
+        P.lv0 = cr.lv[cr.tail.l0];
+        P.n_full = (int)cr.tail.n_in;
+        hipLaunchKernelGGL((cr_pcr_tail_kernel<M, true>), dim3(1), dim3(threads), lds, ctx->stream, P, d, db, x);
+      } else {
+        hipLaunchKernelGGL((cr_pcr_tail_kernel<M, false>), dim3(1), dim3(threads), lds, ctx->stream, P, d, db, x);
+      }
       return;
     }
   }

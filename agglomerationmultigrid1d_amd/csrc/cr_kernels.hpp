@@ -882,27 +882,30 @@ __global__ __launch_bounds__(kCrThreads) CR_WAVES_ATTR void cr_stage_backward_ke
 //     d_i <- d_i - alpha_i^k d_{i-2^k} - gamma_i^k d_{i+2^k},
 // with the multipliers alpha = a b^-1, gamma = c b^-1 of every (level, row) formed at set-up (pcr_reduce_kernel), after
 // ceil(log2 n) levels every row stands alone, x_i = b_i \ d_i: one thread per row, two small matrix-vector products and a
-// barrier per level, no way back up.  The multipliers of the first D levels are fetched up front, the slot of a level is
-// refilled with level k + D as soon as it has been used.
-constexpr int kPcrMaxLevels = 10;  // up to 1024 rows, one thread each
+// barrier per level, no way back up.  Up to 512 rows; 513 .. 1024 rows take one ordinary cyclic-reduction level first (PRE).
+constexpr int kPcrMaxLevels = 9;  // up to 512 rows in the parallel part, one thread each
 struct PcrArgs {
   const double* mult;   // [L][n][2][M][M]
   const double* lu;     // [n][M][M]  diagonal blocks after the last level: pivoted LU, reciprocal pivots
   const int32_t* perm;  // [n][M]
   int n, L;
   int dstride;          // doubles between consecutive blocks of d0 / d0b (0: M)
+  // PRE: one level of ordinary cyclic reduction around the parallel part (513 .. 1024 rows): thread t takes even row 2t through
+  // the parallel levels and solves odd row 2t + 1 from its two even neighbours afterwards -- the level's own factors
+  CrLevel lv0;
+  int n_full;
 #ifdef AGGMG_CR_TRACE
   unsigned long long* trace;
 #endif
 };
 
-// D: levels of multipliers a thread holds at once.  Up to 512 rows (TPB = 512: two waves per SIMD, 256 registers) that is
-// all of them, fetched in one batch before the first level; 1024 rows leave 128 registers per thread: five at block size 2.
-template <int M, int D, int TPB>
-__global__ __launch_bounds__(TPB) void cr_pcr_tail_kernel(PcrArgs P, const double* __restrict__ d0,
+// Every multiplier a thread needs is fetched in ONE batch before the first level (512 threads: two waves per SIMD, 256
+// registers each -- nine levels of two M x M blocks at block size 2 are 144 of them).
+template <int M, bool PRE>
+__global__ __launch_bounds__(512) void cr_pcr_tail_kernel(PcrArgs P, const double* __restrict__ d0,
                                                            const double* __restrict__ d0b, double* __restrict__ x0) {
   extern __shared__ double sh[];
-  constexpr int W = 2 * M * M;
+  constexpr int W = 2 * M * M, D = kPcrMaxLevels;
   const int i = threadIdx.x, n = P.n;
   const bool act = i < n;
   const int ic = act ? i : n - 1;
@@ -929,14 +932,59 @@ __global__ __launch_bounds__(TPB) void cr_pcr_tail_kernel(PcrArgs P, const doubl
   for (int k = 0; k < M; ++k) pf[k] = P.perm[(int64_t)ic * M + k];
   const int ds = P.dstride ? P.dstride : M;
   double v[M];
+  // PRE: the level's factors of even row 2 i (forward multipliers) and odd row 2 i + 1 (couplings, factored block), and the
+  // right-hand sides of rows 2 i - 1, 2 i, 2 i + 1
+  double fe0[PRE ? W : 1], fo0[PRE ? W : 1], lu0[PRE ? M * M : 1], dodd[M];
+  int32_t p0[M];
+  bool has_odd = false;
+  if constexpr (PRE) {
+    const int nf = P.n_full;
+    const int64_t io = 2 * ic + 1 < nf ? ic : (P.lv0.n_odd > 0 ? P.lv0.n_odd - 1 : 0);  // odd row 2 ic + 1 (clamped)
+    has_odd = act && 2 * i + 1 < nf;
+    cr_load_pair<M>(P.lv0.fe + (int64_t)ic * W, fe0);
+    cr_load_pair<M>(P.lv0.fo + io * W, fo0);
 #pragma unroll
-  for (int e = 0; e < M; ++e) v[e] = d0[(int64_t)ic * ds + e];
-  if (d0b) {
+    for (int k = 0; k < M * M; ++k) lu0[k] = P.lv0.lu[io * (M * M) + k];
 #pragma unroll
-    for (int e = 0; e < M; ++e) v[e] += d0b[(int64_t)ic * ds + e];
+    for (int k = 0; k < M; ++k) p0[k] = P.lv0.perm[io * M + k];
+    const int64_t rl = 2 * ic - 1 >= 0 ? 2 * ic - 1 : 0, rr = 2 * ic + 1 < nf ? 2 * ic + 1 : nf - 1;
+    double dl[M], dr[M];
+#pragma unroll
+    for (int e = 0; e < M; ++e) {
+      v[e] = d0[(int64_t)(2 * ic) * ds + e];
+      dl[e] = d0[rl * ds + e];
+      dr[e] = d0[rr * ds + e];
+    }
+    if (d0b) {
+#pragma unroll
+      for (int e = 0; e < M; ++e) {
+        v[e] += d0b[(int64_t)(2 * ic) * ds + e];
+        dl[e] += d0b[rl * ds + e];
+        dr[e] += d0b[rr * ds + e];
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < M; ++e) dodd[e] = dr[e];
+    // (a missing neighbour: its multiplier is zero)
+#pragma unroll
+    for (int r = 0; r < M; ++r) {
+      double t = v[r];
+#pragma unroll
+      for (int q = 0; q < M; ++q) t -= fe0[r * M + q] * dl[q];
+#pragma unroll
+      for (int q = 0; q < M; ++q) t -= fe0[M * M + r * M + q] * dr[q];
+      v[r] = t;
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < M; ++e) v[e] = d0[(int64_t)ic * ds + e];
+    if (d0b) {
+#pragma unroll
+      for (int e = 0; e < M; ++e) v[e] += d0b[(int64_t)ic * ds + e];
+    }
   }
   double* cur = sh;
-  double* nxt = sh + (int64_t)n * M;
+  double* nxt = sh + (int64_t)(n + 1) * M;
   if (act) {
 #pragma unroll
     for (int e = 0; e < M; ++e) cur[i * M + e] = v[e];
@@ -954,18 +1002,10 @@ __global__ __launch_bounds__(TPB) void cr_pcr_tail_kernel(PcrArgs P, const doubl
       for (int r = 0; r < M; ++r) {
         double t = v[r];
 #pragma unroll
-        for (int q = 0; q < M; ++q) t -= f[k % D][r * M + q] * dl[q];
+        for (int q = 0; q < M; ++q) t -= f[k][r * M + q] * dl[q];
 #pragma unroll
-        for (int q = 0; q < M; ++q) t -= f[k % D][M * M + r * M + q] * dr[q];
+        for (int q = 0; q < M; ++q) t -= f[k][M * M + r * M + q] * dr[q];
         v[r] = t;
-      }
-      if (k + D < P.L) {  // the slot is free: the multipliers of level k + D
-        const double* src = P.mult + ((int64_t)(k + D) * n + ic) * W;
-#pragma unroll
-        for (int q = 0; q < W / 2; ++q) {
-          const double2 t = reinterpret_cast<const double2*>(src)[q];
-          f[k % D][2 * q] = t.x, f[k % D][2 * q + 1] = t.y;
-        }
       }
       if (k + 1 < P.L) {
         if (act) {
@@ -981,9 +1021,42 @@ __global__ __launch_bounds__(TPB) void cr_pcr_tail_kernel(PcrArgs P, const doubl
   }
   double y[M];
   cr_lu_solve_reg<M>(luf, pf, v, y);
-  if (act) {
+  if constexpr (PRE) {
+    // x of the even rows to LDS (one more slot: the right neighbour of the last odd row may not exist), odd rows from them
+    __syncthreads();
+    if (act) {
 #pragma unroll
-    for (int e = 0; e < M; ++e) x0[(int64_t)i * M + e] = y[e];
+      for (int e = 0; e < M; ++e) nxt[i * M + e] = y[e];
+    }
+    if (i == 0) {
+#pragma unroll
+      for (int e = 0; e < M; ++e) nxt[n * M + e] = 0.0;
+    }
+    __syncthreads();
+    if (act) {
+#pragma unroll
+      for (int e = 0; e < M; ++e) x0[(int64_t)(2 * i) * M + e] = y[e];
+    }
+    if (has_odd) {
+      double rhs[M], xo[M];
+#pragma unroll
+      for (int r = 0; r < M; ++r) {
+        double t = dodd[r];
+#pragma unroll
+        for (int q = 0; q < M; ++q) t -= fo0[r * M + q] * y[q];
+#pragma unroll
+        for (int q = 0; q < M; ++q) t -= fo0[M * M + r * M + q] * nxt[(i + 1) * M + q];
+        rhs[r] = t;
+      }
+      cr_lu_solve_reg<M>(lu0, p0, rhs, xo);
+#pragma unroll
+      for (int e = 0; e < M; ++e) x0[(int64_t)(2 * i + 1) * M + e] = xo[e];
+    }
+  } else {
+    if (act) {
+#pragma unroll
+      for (int e = 0; e < M; ++e) x0[(int64_t)i * M + e] = y[e];
+    }
   }
 #ifdef AGGMG_CR_TRACE
   if (i == 0 && P.trace) {

@@ -235,10 +235,12 @@ struct CrDev {
   double *d0 = nullptr, *x0 = nullptr;  // staging for padded systems (N not a multiple of m) / in-place calls
   unsigned int* ticket = nullptr;       // last-arriving-workgroup counter of the fused forward + tail launch
   double cond_est = 0.0;
-  // the tail's system by parallel cyclic reduction (cr_pcr_tail_kernel; block sizes 1, 2, up to 1024 blocks): multipliers
+  // the tail's system by parallel cyclic reduction (cr_pcr_tail_kernel; block sizes 1, 2, up to 1024 blocks -- above 512
+  // the parallel part takes the even rows, one ordinary reduction level around it): multipliers
   // of every (level, row), final diagonal blocks factored; allocations in `owned`
   struct Pcr {
     bool valid = false;
+    bool pre = false;   // one ordinary cyclic-reduction level of the tail's first level around the parallel part
     int n = 0, L = 0;
     double* mult = nullptr;
     double* lu = nullptr;

@@ -862,11 +862,17 @@ int setup_cr(aggmg_ctx* ctx, const aggmg_op* Ac, int hint_m, CrDev* cr) {
   }
   // the tail's system by parallel cyclic reduction where it applies (AGGMG_CR_PCR=0: off)
   if (m <= 2 && cr->tail.nsteps >= 1 && env_int("AGGMG_CR_PCR", 1, 0, 1)) {
-    for (const auto& R : cr->raw)
-      if (R.level == cr->tail.l0 && R.n == cr->tail.n_in) {
-        if (m == 1) CHECK(setup_pcr_t<1>(ctx, cr, R));
-        if (m == 2) CHECK(setup_pcr_t<2>(ctx, cr, R));
-      }
+    // up to 512 rows: all of them in the parallel part; 513 .. 1024: its even rows (the next level's system)
+    const bool pre = cr->tail.n_in > 512;
+    const int want_level = cr->tail.l0 + (pre ? 1 : 0);
+    const int64_t want_n = pre ? (cr->tail.n_in + 1) / 2 : cr->tail.n_in;
+    if (cr->tail.n_in <= 1024 && (!pre || cr->tail.q >= 2))
+      for (const auto& R : cr->raw)
+        if (R.level == want_level && R.n == want_n) {
+          if (m == 1) CHECK(setup_pcr_t<1>(ctx, cr, R));
+          if (m == 2) CHECK(setup_pcr_t<2>(ctx, cr, R));
+          cr->pcr.pre = pre;
+        }
   }
   HIPCHK(hipStreamSynchronize(ctx->stream));
   cr_raw_release(cr);

@@ -305,7 +305,8 @@ int aggmg_hier_coarse_info(aggmg_ctx* ctx, const aggmg_hier* h, int* on_device, 
  * (-1 when no device factorisation was attempted). */
 int aggmg_hier_coarse_probe(aggmg_ctx* ctx, const aggmg_hier* h, double* backward_error);
 /* How the device solve ends: the boundary system its chunk stages leave (or the whole system when it is small) goes to
- * ONE workgroup -- *kind = 2: parallel cyclic reduction (block sizes 1 and 2, up to 1024 blocks; kept only where
+ * ONE workgroup -- *kind = 2: parallel cyclic reduction (block sizes 1 and 2, up to 1024 blocks -- above 512 with one
+ * ordinary reduction level around it; kept only where
  * aggmg_hier_create measured it as accurate as kind 1 on a system with a large smooth solution), 1: the register-blocked
  * cyclic reduction of the stages, 0: no device factorisation; *blocks = block rows of that system. */
 int aggmg_hier_coarse_tail(aggmg_ctx* ctx, const aggmg_hier* h, int* kind, int64_t* blocks);
