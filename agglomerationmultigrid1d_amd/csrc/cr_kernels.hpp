@@ -18,9 +18,10 @@
 // its chunk of 2^q blocks is down to its two end blocks (a "stage": one launch forward, one
 // backward; the first step streams the level's vector and factors from HBM, all later ones are
 // 8, 64, ... times smaller); the boundary system of all chunks is the next stage's input, and
-// what fits one workgroup (the "tail") is reduced to a single block and solved back in the same
-// launch -- by the workgroup of the last stage that finishes last.  2^24 scalar rows: one stage
-// (q = 12) + tail = 2 launches forward/tail, 1 backward.
+// what fits one workgroup (the "tail") is solved in a launch of its own: by parallel cyclic reduction
+// (end of this file: block sizes 1 and 2, up to 1024 blocks) or reduced to a single block and solved
+// back by the steps above.  2^24 scalar rows: one stage (q = 12) forward, tail, one stage backward
+// = 3 launches.
 //
 // The forward pass touches the off-diagonal blocks of the even rows only, the backward pass those
 // of the odd rows: stored apart (parity-split, a and c of one row adjacent) so that every fetched
