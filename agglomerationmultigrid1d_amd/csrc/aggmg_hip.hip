@@ -1318,7 +1318,11 @@ extern "C" int aggmg_hier_create(aggmg_ctx* ctx, int nlevels, aggmg_op* const* s
           CHECK(probe_once());
         }
         if (!(h->cr_probe_backward_error < tol)) cr_discard(&h->cr);              // NaN included
-        if (h->cr.valid && h->cr.pcr.valid) {
+        static const bool pcr_guard = [] {
+          const char* e = std::getenv("AGGMG_CR_PCR_GUARD");   // =0: testing aid, keep the parallel tail unexamined
+          return !(e && e[0] == '0');
+        }();
+        if (h->cr.valid && h->cr.pcr.valid && pcr_guard) {
           // The parallel cyclic reduction of the tail accumulates like an inverse; on an ill-conditioned tail system (a
           // small coarsest operator taken as a whole: Neumann end, Dirichlet penalty) its residual for a right-hand side
           // with a large smooth solution was measured at 5000 x the register-blocked form's (1.8e-8 against 3.4e-12 of
