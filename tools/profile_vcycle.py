@@ -25,6 +25,9 @@ def main():
     ap.add_argument("--log2-elems", type=int, default=24)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--cr-trace", action="store_true",
+                    help="in-kernel timeline of the coarsest solve INSIDE the last cycle "
+                         "(AGGMG_HIP_LIB=build_trace/libaggmg_hip_trace.so, tools/cr_trace.py)")
     args = ap.parse_args()
     import agglomerationmultigrid1d_amd as mg
     from agglomerationmultigrid1d_amd import uniform
@@ -43,6 +46,14 @@ def main():
         H.vcycle_dev(xa, b, xb)
         xa, xb = xb, xa
     ctx.synchronize()
+    if args.cr_trace:
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        import cr_trace
+        fn = cr_trace.trace_fn(ctx)
+        fn(ctx.handle, None, 1)
+        H.vcycle_dev(xa, b, xb)
+        ctx.synchronize()
+        cr_trace.report(cr_trace.fetch(ctx, fn))
     print(json.dumps({"kind": args.kind, "log2_elems": args.log2_elems, "steps": args.steps, "levels": H.level_kinds()}))
 
 
