@@ -97,6 +97,7 @@ SYMBOLS = {
     "aggmg_op_download_csc": (c_int, [_P, _P, POINTER(c_int32), POINTER(c_int32), _PD]),
     "aggmg_smoother_download_blocks": (c_int, [_P, _P, _PD]),
     "aggmg_debug_scan_counts": (c_int, [_P, POINTER(c_int32), c_int64, POINTER(c_int64)]),
+    "aggmg_debug_stream_copy": (c_int, [_P, _P, _P, c_int64, c_int, c_int, POINTER(c_double)]),
     "aggmg_blockjacobi_setup": (c_int, [_P, _P, c_int64, c_int64, POINTER(c_int64), c_int, c_int,
                                         POINTER(_P)]),
     "aggmg_blockdiag_setup": (c_int, [_P, c_int64, c_int64, _PD, c_int, POINTER(_P)]),
@@ -157,9 +158,9 @@ SYMBOLS = {
     "aggmg_norm2_dev": (c_int, [_P, _P, c_int64, POINTER(c_double)]),
     "aggmg_residual_norm_dev": (c_int, [_P, _P, _P, _P, POINTER(c_double)]),
     "aggmg_multigrid_dev": (c_int, [_P, _P, _P, _P, c_int, c_double, c_int, c_int, c_int, c_double, _P,
-                                    _PD, POINTER(c_int), POINTER(c_int)]),
+                                    _PD, POINTER(c_int), POINTER(c_int), _P, _PD]),
     "aggmg_smoother_solve_dev": (c_int, [_P, _P, _P, _P, _P, c_int, c_double, c_double, c_int, _P,
-                                         _PD, POINTER(c_int), POINTER(c_int)]),
+                                         _PD, POINTER(c_int), POINTER(c_int), _P, _PD]),
     "aggmg_pcg_dev": (c_int, [_P, _P, _P, _P, c_int, c_double, c_int, c_int, c_double, _PD, POINTER(c_int)]),
     "aggmg_profile_enable": (c_int, [_P, c_int]),
     "aggmg_profile_collect": (c_int, [_P, _PD, POINTER(c_int64)]),

@@ -127,15 +127,34 @@ def default_context():
     return _default_ctx
 
 
+class _DevPtr(ctypes.c_void_p):
+    """Device address handed out by DeviceVector.ptr.  It keeps its vector referenced for as long as the pointer object
+    itself lives -- the argument tuple of a ctypes call included -- so `ctx.to_device(x).ptr` passed straight into a
+    `*_dev` entry point cannot be finalised (aggmg_dev_free) before the call has enqueued its launches; the free that
+    follows synchronises the context's stream first (aggmg_dev_free), i.e. it waits for them.  (r03: such a temporary was
+    freed between `.ptr` and the launch -- a dangling device pointer, a memory access fault on the GPU.)"""
+    _owner = None
+
+
 class DeviceVector:
-    """fp64 vector in HBM owned by a Context."""
+    """fp64 vector in HBM owned by a Context.  `.ptr` is the device address (a c_void_p that keeps the vector alive);
+    after free() it raises instead of yielding a stale address."""
 
     def __init__(self, ctx, n):
         self.ctx = ctx
         self.n = int(n)
+        self._p = None
         p = ctypes.c_void_p()
         ctx.check(ctx.lib.aggmg_dev_alloc(ctx.handle, self.n * 8, ctypes.byref(p)))
-        self.ptr = p
+        self._p = p
+
+    @property
+    def ptr(self):
+        if self._p is None:
+            raise ArgumentError("DeviceVector: used after free() -- its device memory has been released")
+        q = _DevPtr(self._p.value)
+        q._owner = self
+        return q
 
     def upload(self, x):
         x = _f64(x)
@@ -149,14 +168,14 @@ class DeviceVector:
         return out
 
     def free(self):
-        if self.ptr:
-            self.ctx.lib.aggmg_dev_free(self.ctx.handle, self.ptr)
-            self.ptr = None
+        """release the device memory (waits for the launches already enqueued on the context's stream)"""
+        p, self._p = self._p, None
+        if p is not None and self.ctx.handle:
+            self.ctx.lib.aggmg_dev_free(self.ctx.handle, p)
 
     def __del__(self):
         try:
-            if self.ctx.handle:
-                self.free()
+            self.free()
         except Exception:
             pass
 
@@ -917,63 +936,92 @@ def dot(x, y, ctx=None):
     return out.value
 
 
-def multigrid_dev(H, x0, b, maxiter, tol, check_every=1, nPre=3, nPost=3, alpha=2.0 / 3.0):
+class DirectSolver:
+    """`A \\ b` for a device operator -- the fine-level direct solve behind the reference's `err` histories
+    (`u_exact = H.mStiffness[1] \\ b`, src/solvers.jl:120; `uExact = A \\ b`, :194).  A one-level hierarchy of the operator
+    IS the direct solve (src/solvers.jl:39): block cyclic reduction on the device when A is block-tridiagonal with
+    well-conditioned pivot blocks (every DG / agglomerated operator; accepted on a probe solve, include/aggmg_hip.h),
+    the library's host banded LU otherwise; operators neither can take (CG operators in the vertices-first numbering:
+    no band) are solved with SciPy's sparse LU on the host and the solution is uploaded -- once per call, not per cycle.
+    `where` says which: 'device', 'host banded LU', 'host sparse LU'."""
+
+    def __init__(self, op, host_matrix=None):
+        self.op, self.ctx = op, op.ctx
+        self._host = host_matrix
+        self.H = None
+        self._lu = None
+        try:
+            self.H = MeshHierarchy(None, [op], [], [], ctx=self.ctx, coarse_mode=_lib.COARSE_AUTO)
+            self.where = "device" if self.H.coarse_info()["on_device"] else "host banded LU"
+        except _lib.UnsupportedError:
+            self.where = "host sparse LU"
+
+    def solve_dev(self, b):
+        """b: DeviceVector -> DeviceVector"""
+        N = self.op.shape[0]
+        if self.H is not None:
+            x, z = self.ctx.alloc(N), self.ctx.alloc(N)
+            self.H.vcycle_dev(z, b, x, 0, 0, 1.0)
+            return x
+        if self._lu is None:
+            A = self._host if self._host is not None else self.op.to_scipy()
+            self._lu = spla.splu(sp.csc_matrix(A))
+        return self.ctx.to_device(self._lu.solve(b.download()))
+
+
+def _direct_solver(owner, op, host_matrix=None):
+    """the DirectSolver of `op`, cached on `owner` (a hierarchy or a smoother: factored once, reused by every call)"""
+    ds = owner.__dict__.get("_direct_solver")
+    if ds is None or ds.op is not op:
+        ds = DirectSolver(op, host_matrix)
+        owner.__dict__["_direct_solver"] = ds
+    return ds
+
+
+def multigrid_dev(H, x0, b, maxiter, tol, check_every=1, nPre=3, nPost=3, alpha=2.0 / 3.0, u_exact=None):
     """The loop of multigrid (src/solvers.jl:122-134) resident on the device -- C ABI
-    aggmg_multigrid_dev.  x0, b: DeviceVectors.  -> (x DeviceVector, cycles, res list)"""
+    aggmg_multigrid_dev.  x0, b: DeviceVectors.  -> (x DeviceVector, cycles, res list) or, with u_exact (DeviceVector:
+    the fine-level direct solution of :120), -> (x, cycles, res list, err list) with err[i] = ||x_i - u_exact||_2 (:128)
+    formed on the device."""
     c = H.ctx
     N = H._ops[0].shape[0]
-    if x0.n != N or b.n != N:
+    if x0.n != N or b.n != N or (u_exact is not None and u_exact.n != N):
         raise DimensionMismatch("multigrid: x0 / b do not match the fine operator")
     x = c.alloc(N)
     nchk = max(1, -(-int(maxiter) // max(1, int(check_every))))
-    hist = np.zeros(nchk)
+    hist, ehist = np.zeros(nchk), np.zeros(nchk)
     ncyc, nck = ctypes.c_int(0), ctypes.c_int(0)
     c.check(c.lib.aggmg_multigrid_dev(c.handle, H.handle, x0.ptr, b.ptr, int(maxiter), float(tol), int(check_every),
                                       int(nPre), int(nPost), float(alpha), x.ptr, _pd(hist),
-                                      ctypes.byref(ncyc), ctypes.byref(nck)))
-    return x, ncyc.value, hist[:nck.value].tolist()
+                                      ctypes.byref(ncyc), ctypes.byref(nck), _ptr(u_exact),
+                                      _pd(ehist) if u_exact is not None else None))
+    if u_exact is None:
+        return x, ncyc.value, hist[:nck.value].tolist()
+    return x, ncyc.value, hist[:nck.value].tolist(), ehist[:nck.value].tolist()
 
 
-def multigrid(H, x0, b, maxiter, tol, exact=True, check_every=1):
+def multigrid(H, x0, b, maxiter, tol, exact=True, check_every=1, nPre=3, nPost=3, alpha=2.0 / 3.0):
     """multigrid(H, x0, b, maxiter, tol) -> (x, iter, res, err)  (src/solvers.jl:116-139).
-    The reference solves the fine system directly for the error history (:120); with exact=True
-    that is reproduced (host direct solve, the iterate comes back after every cycle).  exact=False
-    skips it -- err is then empty and the whole loop, residual norms included, stays on the device
-    (aggmg_multigrid_dev).  check_every = c > 1 runs c cycles per residual check in one fused
-    device call; res / err then have one entry per check and `iter` counts cycles."""
-    x0 = _f64(x0)
-    b = _f64(b)
+    The whole loop runs on the device (aggmg_multigrid_dev): x0 and b go up once, x comes back once.  exact=True (the
+    reference's contract, the default): `u_exact = H.mStiffness[1] \\ b` (:120) is solved once -- on the device where the
+    fine operator is block-tridiagonal (DirectSolver) -- and err[i] = ||x_i - u_exact||_2 (:128) is formed on the device;
+    exact=False skips the direct solve and returns err empty.  check_every = c > 1 runs c cycles per residual check in
+    one fused device call; res / err then have one entry per check and `iter` counts cycles.  x0, b may be DeviceVectors,
+    x then is one too.  nPre / nPost / alpha: multigrid_v_cycle's defaults, which the reference's loop uses (:125)."""
     c = H.ctx
-    if not exact:
-        dx, ncyc, res = multigrid_dev(H, c.to_device(x0), c.to_device(b), maxiter, tol, check_every)
-        return dx.download(), (ncyc if check_every > 1 else len(res)), res, []
-    x = np.zeros(len(x0))
-    A0 = H.mStiffness[0]
-    u_exact = spla.spsolve(sp.csc_matrix(A0.to_scipy() if isinstance(A0, DeviceOperator) else A0), b)
-    err, res = [], []
-    nb = np.linalg.norm(b, 2)
-    if check_every <= 1:
-        for i in range(int(maxiter)):
-            x = multigrid_v_cycle(H, x0, b)
-            x0 = x
-            err.append(np.linalg.norm(x - u_exact, 2))
-            res.append(_device_residual_norm(H._ops[0], x, b))
-            if res[i] < tol * nb:
-                break
-        return x, len(res), res, err
-    db, dx, dy = c.to_device(b), c.to_device(x0), c.alloc(len(b))
-    done = 0
-    while done < int(maxiter):
-        k = min(int(check_every), int(maxiter) - done)
-        H.vcycles_dev(dx, db, dy, k)
-        dx, dy = dy, dx
-        done += k
-        x = dx.download()
-        err.append(np.linalg.norm(x - u_exact, 2))
-        res.append(_device_residual_norm(H._ops[0], x, b))
-        if res[-1] < tol * nb:
-            break
-    return x, done, res, err
+    on_device = isinstance(x0, DeviceVector) and isinstance(b, DeviceVector)
+    dx0 = x0 if isinstance(x0, DeviceVector) else c.to_device(_f64(x0))
+    db = b if isinstance(b, DeviceVector) else c.to_device(_f64(b))
+    u_exact = None
+    if exact:
+        A0 = H.mStiffness[0]
+        u_exact = _direct_solver(H, H._ops[0], None if isinstance(A0, DeviceOperator) else A0).solve_dev(db)
+    out = multigrid_dev(H, dx0, db, maxiter, tol, check_every, nPre, nPost, alpha, u_exact)
+    dx, ncyc, res = out[:3]
+    err = out[3] if exact else []
+    if int(maxiter) == 0:
+        res, err = [], []
+    return (dx if on_device else dx.download()), (ncyc if check_every > 1 else len(res)), res, err
 
 
 def pcg(H, b, x0=None, maxiter=50, tol=1e-10, nPre=3, nPost=3, alpha=2.0 / 3.0):
@@ -997,36 +1045,26 @@ def pcg(H, b, x0=None, maxiter=50, tol=1e-10, nPre=3, nPost=3, alpha=2.0 / 3.0):
 def iterative_smoother_solve(A, smoother, x0, b, maxiter=1000, tol=1e-6, alpha=1.0, exact=True, check_every=1):
     """iterative_smoother_solve(A, smoother, x0, b; maxiter=1000, tol=1e-6, alpha=1.0)
     -> (x, iter, res, err)  (src/solvers.jl:189-213).  Each iteration is one fused device sweep
-    x = x0 + apply_smoother(S, b - A*x0; alpha).  exact=False skips the direct solve of :194 and
-    keeps the loop and the residual norms on the device (aggmg_smoother_solve_dev)."""
+    x = x0 + apply_smoother(S, b - A*x0; alpha); the loop, the residual norms and -- exact=True, the reference's contract
+    and the default -- the error history err[i] = ||x_i - A \\ b||_2 (:194, :202) stay on the device
+    (aggmg_smoother_solve_dev; the direct solve once, DirectSolver).  exact=False: err comes back empty."""
     op = smoother.A if not isinstance(A, DeviceOperator) else A
-    x0 = _f64(x0).copy()
-    b = _f64(b)
     c = op.ctx
-    if not exact or isinstance(A, DeviceOperator):
-        N = op.shape[0]
-        dx0, db, dx = c.to_device(x0), c.to_device(b), c.alloc(N)
-        nchk = max(1, -(-int(maxiter) // max(1, int(check_every))))
-        hist = np.zeros(nchk)
-        nit, nck = ctypes.c_int(0), ctypes.c_int(0)
-        c.check(c.lib.aggmg_smoother_solve_dev(c.handle, op.handle, smoother.handle, dx0.ptr, db.ptr, int(maxiter),
-                                               float(tol), float(alpha), int(check_every), dx.ptr, _pd(hist),
-                                               ctypes.byref(nit), ctypes.byref(nck)))
-        res = hist[:nck.value].tolist()
-        return dx.download(), (nit.value if check_every > 1 else len(res)), res, []
-    uExact = spla.spsolve(sp.csc_matrix(A), b)
-    err, res = [], []
-    nb = np.linalg.norm(b, 2)
-    x = np.zeros(len(x0))
-    for i in range(int(maxiter)):
-        x = x0.copy()
-        c.check(c.lib.aggmg_smooth(c.handle, op.handle, smoother.handle, _pd(x), _pd(b), float(alpha), 1))
-        x0 = x
-        err.append(np.linalg.norm(x - uExact, 2))
-        res.append(_device_residual_norm(op, x, b))
-        if res[i] < tol * nb:
-            break
-    return x, len(res), res, err
+    N = op.shape[0]
+    dx0, db, dx = c.to_device(_f64(x0)), c.to_device(_f64(b)), c.alloc(N)
+    u_exact = None
+    if exact:
+        u_exact = _direct_solver(smoother, op, None if isinstance(A, DeviceOperator) else A).solve_dev(db)
+    nchk = max(1, -(-int(maxiter) // max(1, int(check_every))))
+    hist, ehist = np.zeros(nchk), np.zeros(nchk)
+    nit, nck = ctypes.c_int(0), ctypes.c_int(0)
+    c.check(c.lib.aggmg_smoother_solve_dev(c.handle, op.handle, smoother.handle, dx0.ptr, db.ptr, int(maxiter),
+                                           float(tol), float(alpha), int(check_every), dx.ptr, _pd(hist),
+                                           ctypes.byref(nit), ctypes.byref(nck), _ptr(u_exact),
+                                           _pd(ehist) if exact else None))
+    res = hist[:nck.value].tolist()
+    err = ehist[:nck.value].tolist() if exact else []
+    return dx.download(), (nit.value if check_every > 1 else len(res)), res, err
 
 
 # stand-alone fused operations on host arrays (C ABI `aggmg_smooth`, `aggmg_residual`, ...)

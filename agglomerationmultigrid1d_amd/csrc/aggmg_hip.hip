@@ -2013,6 +2013,16 @@ static int residual_norm(aggmg_ctx* ctx, aggmg_op* A, const double* x, const dou
   return read_scalar(ctx, ctx->solv_sc + 14, out);
 }
 
+// ||x - y||_2 on the device: one entry of the `err` history (src/solvers.jl:128, :202)
+static int diff_norm(aggmg_ctx* ctx, int64_t n, const double* x, const double* y, double* out) {
+  CHECK(solv_scalars(ctx));
+  hipLaunchKernelGGL(diff2_partial_kernel, dim3(kDotBlocks), dim3(kThreads), 0, ctx->stream, n, x, y, ctx->solv_part);
+  hipLaunchKernelGGL(dot_final_kernel, dim3(1), dim3(kThreads), 0, ctx->stream, kDotBlocks,
+                     (const double*)ctx->solv_part, ctx->solv_sc + 12, 1);
+  HIPCHK(hipGetLastError());
+  return read_scalar(ctx, ctx->solv_sc + 12, out);
+}
+
 extern "C" int aggmg_residual_norm_dev(aggmg_ctx* ctx, aggmg_op* A, const double* x, const double* b, double* out) {
   if (!ctx) return AGGMG_ERR_ARGUMENT;
   if (!A || !x || !b || !out) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_residual_norm_dev: NULL argument");
@@ -2023,11 +2033,14 @@ extern "C" int aggmg_residual_norm_dev(aggmg_ctx* ctx, aggmg_op* A, const double
 
 extern "C" int aggmg_multigrid_dev(aggmg_ctx* ctx, aggmg_hier* h, const double* x0, const double* b, int maxiter,
                                    double tol, int check_every, int nPre, int nPost, double alpha, double* x_out,
-                                   double* res_hist, int* n_cycles, int* n_checks) {
+                                   double* res_hist, int* n_cycles, int* n_checks, const double* u_exact,
+                                   double* err_hist) {
   CHECK(vcycle_args(ctx, h, x0, b, nPre, nPost));
   if (!x_out || !res_hist || !n_cycles || !n_checks || maxiter < 0 || check_every < 1)
     return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_multigrid_dev: bad argument");
   if (x_out == x0 || x_out == b) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_multigrid_dev: x_out must not alias x0 or b");
+  if ((u_exact == nullptr) != (err_hist == nullptr))
+    return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_multigrid_dev: u_exact and err_hist come together (or both NULL)");
   HIPCHK(hipSetDevice(ctx->device));
   CHECK(solv_scalars(ctx));
   aggmg_op* A = h->lv[0].A;
@@ -2054,6 +2067,7 @@ extern "C" int aggmg_multigrid_dev(aggmg_ctx* ctx, aggmg_hier* h, const double* 
     cur = dst;
     done += k;
     double res = 0.0;
+    if (u_exact) CHECK(diff_norm(ctx, N, cur, u_exact, &err_hist[checks]));  // err[i] = ||x - u_exact||, src/solvers.jl:128
     CHECK(residual_norm(ctx, A, cur, b, &res));
     res_hist[checks++] = res;
     if (res < tol * nb) break;  // src/solvers.jl:131
@@ -2067,11 +2081,14 @@ extern "C" int aggmg_multigrid_dev(aggmg_ctx* ctx, aggmg_hier* h, const double* 
 
 extern "C" int aggmg_smoother_solve_dev(aggmg_ctx* ctx, aggmg_op* A, aggmg_smoother* sm, const double* x0,
                                         const double* b, int maxiter, double tol, double alpha, int check_every,
-                                        double* x_out, double* res_hist, int* n_iters, int* n_checks) {
+                                        double* x_out, double* res_hist, int* n_iters, int* n_checks,
+                                        const double* u_exact, double* err_hist) {
   CHECK(check_pair(ctx, A, sm, "aggmg_smoother_solve_dev"));
   if (!x0 || !b || !x_out || !res_hist || !n_iters || !n_checks || maxiter < 0 || check_every < 1)
     return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_smoother_solve_dev: bad argument");
   if (x_out == x0 || x_out == b) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_smoother_solve_dev: x_out must not alias x0 or b");
+  if ((u_exact == nullptr) != (err_hist == nullptr))
+    return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_smoother_solve_dev: u_exact and err_hist come together (or both NULL)");
   HIPCHK(hipSetDevice(ctx->device));
   CHECK(solv_scalars(ctx));
   const int64_t N = A->m;
@@ -2091,6 +2108,7 @@ extern "C" int aggmg_smoother_solve_dev(aggmg_ctx* ctx, aggmg_op* A, aggmg_smoot
     cur = dst;
     done += k;
     double res = 0.0;
+    if (u_exact) CHECK(diff_norm(ctx, N, cur, u_exact, &err_hist[checks]));  // err[i] = ||x - uExact||, src/solvers.jl:202
     CHECK(residual_norm(ctx, A, cur, b, &res));
     res_hist[checks++] = res;
     if (res < tol * nb) break;  // src/solvers.jl:206
@@ -2185,3 +2203,62 @@ extern "C" int aggmg_copy_segments_dev(aggmg_ctx* ctx, int nseg, const double* c
   return AGGMG_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Measurement aid (tools/exp_coarse.py --calibrate): what a plain streaming kernel reaches on a given grid,
+// as the ceiling the coarsest solve's streaming steps are held against.  mode 0: 16-byte copy src -> dst
+// (nbytes read + nbytes written), mode 1: read only (nbytes read, one 16-byte store per thread that the
+// compiler cannot prove dead).  Grid-stride over `workgroups` workgroups of 256 threads, four independent
+// loads in flight per thread and pass.  Timed here with HIP events on the context stream (synchronous).
+// ---------------------------------------------------------------------------------------------
+template <int MODE>
+static __global__ __launch_bounds__(kThreads) void stream_copy_kernel(const double2* __restrict__ src, double2* __restrict__ dst,
+                                                                     int64_t n16) {
+  const int64_t stride = (int64_t)gridDim.x * kThreads;
+  int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  double2 acc = make_double2(0.0, 0.0);
+  for (; i + 3 * stride < n16; i += 4 * stride) {
+    const double2 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+    if (MODE == 0) {
+      dst[i] = a, dst[i + stride] = b, dst[i + 2 * stride] = c, dst[i + 3 * stride] = d;
+    } else {
+      acc.x += (a.x + b.x) + (c.x + d.x);
+      acc.y += (a.y + b.y) + (c.y + d.y);
+    }
+  }
+  for (; i < n16; i += stride) {
+    const double2 a = src[i];
+    if (MODE == 0) dst[i] = a;
+    else acc.x += a.x, acc.y += a.y;
+  }
+  if (MODE == 1 && acc.x == 0.12345 && acc.y == 0.54321) dst[threadIdx.x] = acc;   // (never: keeps the loads alive)
+}
+
+extern "C" int aggmg_debug_stream_copy(aggmg_ctx* ctx, void* dst, const void* src, int64_t nbytes, int workgroups, int mode,
+                                       double* ms_out) {
+  if (!ctx) return AGGMG_ERR_ARGUMENT;
+  if (!dst || !src || nbytes < 16 || workgroups < 1 || (mode != 0 && mode != 1) || !ms_out)
+    return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_debug_stream_copy: bad argument");
+  HIPCHK(hipSetDevice(ctx->device));
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  HIPCHK(hipEventCreate(&e0));
+  HIPCHK(hipEventCreate(&e1));
+  HIPCHK(hipEventRecord(e0, ctx->stream));
+  if (mode == 0)
+    hipLaunchKernelGGL(stream_copy_kernel<0>, dim3((unsigned)workgroups), dim3(kThreads), 0, ctx->stream, (const double2*)src,
+                       (double2*)dst, nbytes / 16);
+  else
+    hipLaunchKernelGGL(stream_copy_kernel<1>, dim3((unsigned)workgroups), dim3(kThreads), 0, ctx->stream, (const double2*)src,
+                       (double2*)dst, nbytes / 16);
+  hipError_t le = hipGetLastError();
+  (void)hipEventRecord(e1, ctx->stream);
+  hipError_t se = hipEventSynchronize(e1);
+  float ms = 0.f;
+  if (le == hipSuccess && se == hipSuccess) (void)hipEventElapsedTime(&ms, e0, e1);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  if (le != hipSuccess) return fail(ctx, AGGMG_ERR_HIP, std::string("stream_copy_kernel: ") + hipGetErrorString(le));
+  if (se != hipSuccess) return fail(ctx, AGGMG_ERR_HIP, std::string("stream_copy_kernel: ") + hipGetErrorString(se));
+  *ms_out = ms;
+  return AGGMG_OK;
+}

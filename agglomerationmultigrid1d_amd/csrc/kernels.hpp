@@ -290,6 +290,28 @@ static __global__ __launch_bounds__(kThreads) void dot_partial_kernel(int64_t n,
   if (threadIdx.x == 0) partial[blockIdx.x] = sh[0];
 }
 
+// partial[b] = sum_{i in slice b} (x_i - y_i)^2   -- ||x - u_exact||_2 of the `err` histories (src/solvers.jl:128,202)
+static __global__ __launch_bounds__(kThreads) void diff2_partial_kernel(int64_t n, const double* __restrict__ x,
+                                                                 const double* __restrict__ y,
+                                                                 double* __restrict__ partial) {
+  __shared__ double sh[kThreads];
+  const int64_t per = (n + gridDim.x - 1) / gridDim.x;
+  const int64_t lo = (int64_t)blockIdx.x * per;
+  const int64_t hi = lo + per < n ? lo + per : n;
+  double acc = 0.0;
+  for (int64_t i = lo + threadIdx.x; i < hi; i += kThreads) {
+    const double d = x[i] - y[i];
+    acc += d * d;
+  }
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = kThreads / 2; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = sh[0];
+}
+
 // out[0] = sum of the partials (one workgroup), optionally its square root
 static __global__ __launch_bounds__(kThreads) void dot_final_kernel(int nparts, const double* __restrict__ partial,
                                                              double* __restrict__ out, int take_sqrt) {

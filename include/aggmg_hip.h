@@ -181,6 +181,12 @@ int aggmg_smoother_download_blocks(aggmg_ctx* ctx, const aggmg_smoother* sm, dou
  * int32 counts (host array).  The total is formed in 64 bits before anything is scanned or allocated; a result of
  * 2^31 or more entries is refused with AGGMG_ERR_UNSUPPORTED (int32 device indices), *total still set. */
 int aggmg_debug_scan_counts(aggmg_ctx* ctx, const int32_t* counts_host, int64_t n, int64_t* total);
+/* Measurement aid (tools/exp_coarse.py --calibrate; no reference counterpart): a plain 16-byte streaming kernel on
+ * `workgroups` workgroups of 256 threads over device buffers of nbytes -- mode 0 copies src to dst, mode 1 only reads
+ * src -- timed with HIP events on the context stream (synchronous); *ms_out = its duration.  The ceiling the
+ * coarsest solve's streaming steps (src/solvers.jl:39) are held against in DESIGN.md section 5. */
+int aggmg_debug_stream_copy(aggmg_ctx* ctx, void* dst, const void* src, int64_t nbytes, int workgroups, int mode,
+                            double* ms_out);
 
 /* ---- fused hot-path operations -------------------------------------------------------------- */
 /* nsweeps x  `u += apply_smoother(S, b - A*u; alpha)`   src/solvers.jl:32-35,43-46, :199 */
@@ -426,20 +432,25 @@ int aggmg_dot_dev(aggmg_ctx* ctx, const double* x, const double* y, int64_t n, d
 int aggmg_norm2_dev(aggmg_ctx* ctx, const double* x, int64_t n, double* out);
 /* ||b - A x||_2: the `la.norm( A * x - b, 2 )` of src/solvers.jl:129 and :204. */
 int aggmg_residual_norm_dev(aggmg_ctx* ctx, aggmg_op* A, const double* x, const double* b, double* out);
-/* multigrid(H, x0, b, maxiter, tol) -> x, iter, res       src/solvers.jl:116-139, without the
- * fine-level direct solve of :120 (no `err` history): x <- multigrid_v_cycle(H, x, b) until
- * ||A x - b|| < tol ||b|| (:131) or maxiter cycles.  The residual is checked every `check_every`
- * cycles (1 = the reference's loop; c > 1 runs c cycles per check through aggmg_vcycles_dev);
- * res_hist (host, >= ceil(maxiter / check_every) entries) receives one norm per check.  All
- * vectors are device pointers; x_out may alias neither x0 nor b. */
+/* multigrid(H, x0, b, maxiter, tol) -> x, iter, res, err       src/solvers.jl:116-139:
+ * x <- multigrid_v_cycle(H, x, b) until ||A x - b|| < tol ||b|| (:131) or maxiter cycles.  The residual is checked
+ * every `check_every` cycles (1 = the reference's loop; c > 1 runs c cycles per check through aggmg_vcycles_dev);
+ * res_hist (host, >= ceil(maxiter / check_every) entries) receives one norm per check.
+ * The reference's `err` history -- err[i] = ||x_i - u_exact||_2 with u_exact = H.mStiffness[1] \ b (:120, :128) --
+ * is formed on the device when u_exact (device vector) and err_hist (host, as long as res_hist) are given: the
+ * caller solves the fine system ONCE (a one-level hierarchy of the fine operator is the direct solve: block cyclic
+ * reduction when the operator is block-tridiagonal, host banded LU otherwise -- aggmg_hier_create with nlevels = 1)
+ * and no iterate crosses PCIe.  Both NULL: no error history.  All vectors are device pointers; x_out may alias
+ * neither x0 nor b. */
 int aggmg_multigrid_dev(aggmg_ctx* ctx, aggmg_hier* h, const double* x0, const double* b, int maxiter,
                         double tol, int check_every, int nPre, int nPost, double alpha, double* x_out,
-                        double* res_hist, int* n_cycles, int* n_checks);
-/* iterative_smoother_solve(A, smoother, x0, b; maxiter, tol, alpha) -> x, iter, res
- * src/solvers.jl:189-213 without the direct solve of :194; same conventions as above. */
+                        double* res_hist, int* n_cycles, int* n_checks, const double* u_exact, double* err_hist);
+/* iterative_smoother_solve(A, smoother, x0, b; maxiter, tol, alpha) -> x, iter, res, err
+ * src/solvers.jl:189-213; same conventions as above (u_exact = A \ b of :194, err[i] of :202). */
 int aggmg_smoother_solve_dev(aggmg_ctx* ctx, aggmg_op* A, aggmg_smoother* sm, const double* x0,
                              const double* b, int maxiter, double tol, double alpha, int check_every,
-                             double* x_out, double* res_hist, int* n_iters, int* n_checks);
+                             double* x_out, double* res_hist, int* n_iters, int* n_checks, const double* u_exact,
+                             double* err_hist);
 /* Conjugate gradients on A x = b with ldiv!(y, H, r) (one V-cycle from a zero guess,
  * src/solvers.jl:84-92) as the preconditioner; x_inout holds the initial guess and the result.
  * EXTENSION: the reference provides ldiv! so that a hierarchy can be used as a preconditioner but

@@ -9,10 +9,10 @@
 #     include("AggMGHip.jl")
 #     Hd = AggMGHip.DeviceHierarchy(H)                 # H::MeshHierarchy, built as usual
 #     x  = multigrid_v_cycle(Hd, x0, b)                # same signature / defaults / return
-#     x, iter, res, err = multigrid(Hd, x0, b, 100, 1e-10)          # device loop; err only with exact = true
+#     x, iter, res, err = multigrid(Hd, x0, b, 100, 1e-10)          # device loop, res AND err histories formed on the device
 #     xd = multigrid_v_cycle(Hd, DeviceVector(Hd.ctx, x0), DeviceVector(Hd.ctx, b))   # vectors stay in HBM
 # Host arrays cross PCIe on every call (measured: 17 ms per config-3 cycle that computes in 0.7 ms); callers
-# that loop hand over DeviceVectors, and `multigrid` / `iterative_smoother_solve` loop on the device by default.
+# that loop hand over DeviceVectors; `multigrid` / `iterative_smoother_solve` always loop on the device.
 #
 # Every function of the reference that this file gives a device method is IMPORTED and EXTENDED
 # (a `function f(...)` on an imported name adds a method; on a non-imported name it would define
@@ -294,6 +294,11 @@ end
 
 # device vector: aggmg_dev_alloc (zeroed) / aggmg_memcpy_h2d / aggmg_memcpy_d2h.  What a caller keeps between
 # calls so that nothing but the handles crosses PCIe: multigrid_v_cycle, ldiv! and multigrid take and return them.
+# LIFETIME RULE (the use-after-free of round 3, api.DeviceVector.ptr in the Python mirror): `v.p` is a bare address --
+# the GC may finalise `v` (aggmg_dev_free) as soon as no Julia reference to it is live, even while a ccall that was
+# handed `v.p` is still being set up.  Every ccall that passes `v.p` therefore stands under `GC.@preserve v`
+# (tests/test_julia_shim_lint.py checks it); once the call has enqueued its launches the free is safe, because
+# aggmg_dev_free synchronises the context's stream first.
 mutable struct DeviceVector
     ctx::Context               # strong reference: the context outlives the vector
     p::Ptr{Cvoid}
@@ -316,7 +321,7 @@ end
 function DeviceVector(ctx::Context, x::AbstractVector)
     x = Vector{Float64}(x)
     v = DeviceVector(ctx, length(x))
-    GC.@preserve x check(ctx.h, ccall((:aggmg_memcpy_h2d, LIB), Cint, (Handle, Ptr{Cvoid}, Ptr{Float64}, Int64),
+    GC.@preserve v x check(ctx.h, ccall((:aggmg_memcpy_h2d, LIB), Cint, (Handle, Ptr{Cvoid}, Ptr{Float64}, Int64),
         ctx.h, v.p, x, 8length(x)))
     return v
 end
@@ -324,7 +329,7 @@ Base.length(v::DeviceVector) = v.n
 Base.size(v::DeviceVector) = (v.n,)
 function download(v::DeviceVector)
     out = Vector{Float64}(undef, v.n)
-    GC.@preserve out check(v.ctx.h, ccall((:aggmg_memcpy_d2h, LIB), Cint, (Handle, Ptr{Float64}, Ptr{Cvoid}, Int64),
+    GC.@preserve v out check(v.ctx.h, ccall((:aggmg_memcpy_d2h, LIB), Cint, (Handle, Ptr{Float64}, Ptr{Cvoid}, Int64),
         v.ctx.h, out, v.p, 8v.n))
     return out
 end
@@ -349,7 +354,7 @@ function multigrid_v_cycle(Hd::DeviceHierarchy, x0::DeviceVector, b::DeviceVecto
         nPre::Integer = 3, nPost::Integer = 3, alpha::AbstractFloat = 2.0 / 3.0)
     (x0.n == b.n) || throw(DimensionMismatch("multigrid_v_cycle: x0 and b differ in length"))
     out = DeviceVector(Hd.ctx, b.n)
-    check(Hd.ctx.h, ccall((:aggmg_vcycle_dev, LIB), Cint,
+    GC.@preserve x0 b out check(Hd.ctx.h, ccall((:aggmg_vcycle_dev, LIB), Cint,
         (Handle, Handle, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Cint, Float64, Ptr{Cvoid}),
         Hd.ctx.h, Hd.h, x0.p, b.p, nPre, nPost, Float64(alpha), out.p))
     return out
@@ -359,7 +364,7 @@ end
 # refuses aliased output; ldiv!(H, b) for a DeviceVector goes through a fresh vector and swaps the storage)
 function la.ldiv!(y::DeviceVector, Hd::DeviceHierarchy, b::DeviceVector)
     z = DeviceVector(Hd.ctx, b.n)                       # zeroed by aggmg_dev_alloc
-    check(Hd.ctx.h, ccall((:aggmg_vcycle_dev, LIB), Cint,
+    GC.@preserve z b y check(Hd.ctx.h, ccall((:aggmg_vcycle_dev, LIB), Cint,
         (Handle, Handle, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Cint, Float64, Ptr{Cvoid}),
         Hd.ctx.h, Hd.h, z.p, b.p, 3, 3, 2.0 / 3.0, y.p))
     return
@@ -379,66 +384,107 @@ function la.ldiv!(y::AbstractVector, Hd::DeviceHierarchy, b::AbstractVector)
     y[:] = multigrid_v_cycle(Hd, zeros(size(Hd.H.mStiffness[1], 1)), b); return
 end
 
+# `A \\ b` of a device operator -- the fine-level direct solve behind the reference's `err` histories
+# (u_exact = H.mStiffness[1] \\ b, src/solvers.jl:120; uExact = A \\ b, :194).  A one-level hierarchy of the operator IS
+# the direct solve (:39): block cyclic reduction on the device when the operator is block-tridiagonal (every DG /
+# agglomerated operator), the library's host banded LU otherwise (coarse_mode 2 = AGGMG_COARSE_AUTO).  Operators that
+# neither takes (status -5: CG operators in the vertices-first numbering have no band) are solved on the host with the
+# reference's own `\\` and uploaded -- once per call, never per cycle.
+mutable struct DirectSolver
+    ctx::Context
+    op::DeviceOperator
+    h::Handle                                  # one-level hierarchy, or C_NULL: host fallback
+end
+function free!(ds::DirectSolver)
+    if ds.h != C_NULL && ds.ctx.h != C_NULL
+        ccall((:aggmg_hier_free, LIB), Cint, (Handle, Handle), ds.ctx.h, ds.h)
+    end
+    ds.h = C_NULL
+    return nothing
+end
+function DirectSolver(op::DeviceOperator)
+    r = Ref{Handle}(C_NULL)
+    oph = Handle[op.h]
+    st = GC.@preserve oph ccall((:aggmg_hier_create, LIB), Cint,
+        (Handle, Cint, Ptr{Handle}, Ptr{Handle}, Ptr{Handle}, Cint, Ref{Handle}),
+        op.ctx.h, 1, oph, C_NULL, C_NULL, 2, r)
+    st == -5 || check(op.ctx.h, st)             # -5: neither block-tridiagonal nor banded -> host `\\`
+    ds = DirectSolver(op.ctx, op, st == 0 ? r[] : C_NULL)
+    finalizer(free!, ds)
+    return ds
+end
+# u = A \\ b as a DeviceVector; A_host: the reference's SparseMatrixCSC of the same operator (host fallback only)
+function solve(ds::DirectSolver, A_host, b::DeviceVector)
+    ds.h == C_NULL && return DeviceVector(ds.ctx, A_host \\ download(b))
+    u = DeviceVector(ds.ctx, b.n); z = DeviceVector(ds.ctx, b.n)      # z: zero guess (aggmg_dev_alloc zeroes)
+    GC.@preserve z b u check(ds.ctx.h, ccall((:aggmg_vcycle_dev, LIB), Cint,
+        (Handle, Handle, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Cint, Float64, Ptr{Cvoid}),
+        ds.ctx.h, ds.h, z.p, b.p, 0, 0, 1.0, u.p))
+    return u
+end
+const DIRECT_SOLVERS = IdDict{Any,DirectSolver}()        # factored once per hierarchy / smoother, reused by every call
+direct_solver(owner, op::DeviceOperator) = get!(() -> DirectSolver(op), DIRECT_SOLVERS, owner)
+
 # multigrid(H, x0, b, maxiter, tol) -> x, iter, res, err   (src/solvers.jl:116-139): a METHOD OF THE
-# REFERENCE'S FUNCTION for DeviceHierarchy.  The loop, the residual norms and the stopping test (:131) run on the
-# device (aggmg_multigrid_dev): x0 and b go up once, x comes back once.  The reference's `err` history needs the
-# fine-level sparse direct solve of :120 and every iterate on the host; it is computed only on request
-# (exact = true: the reference's loop, one PCIe round trip per cycle) -- by default `err` comes back empty.
-# nPre / nPost / alpha: the defaults of multigrid_v_cycle, as the reference's loop uses.  x0, b may be
-# DeviceVectors, in which case x is one too and nothing but the residual norms leaves the device.
+# REFERENCE'S FUNCTION for DeviceHierarchy, returning the reference's full 4-tuple.  The loop, the residual norms, the
+# stopping test (:131) AND the error history err[i] = ||x_i - u_exact||_2 (:128) run on the device
+# (aggmg_multigrid_dev): x0 and b go up once, x comes back once; u_exact = H.mStiffness[1] \\ b (:120) is solved once,
+# on the device where the fine operator is block-tridiagonal (DirectSolver).  exact = false skips the direct solve
+# and returns `err` empty.  nPre / nPost / alpha: the defaults of multigrid_v_cycle, as the reference's loop uses.
+# x0, b may be DeviceVectors, in which case x is one too and nothing but the two histories leaves the device.
 function multigrid(Hd::DeviceHierarchy, x0::Union{AbstractVector,DeviceVector}, b::Union{AbstractVector,DeviceVector},
         maxiter::Integer, tol::AbstractFloat; nPre::Integer = 3, nPost::Integer = 3,
-        alpha::AbstractFloat = 2.0 / 3.0, exact::Bool = false, check_every::Integer = 1)
-    if exact
-        x0h = x0 isa DeviceVector ? download(x0) : Vector{Float64}(x0)
-        bh = b isa DeviceVector ? download(b) : Vector{Float64}(b)
-        u_exact = Hd.H.mStiffness[1] \ bh
-        x = zeros(length(x0h))
-        err = zeros(maxiter); res = zeros(maxiter); iter = maxiter
-        for i in 1:maxiter
-            x = multigrid_v_cycle(Hd, x0h, bh; nPre = nPre, nPost = nPost, alpha = alpha)
-            x0h = x
-            err[i] = la.norm(x - u_exact, 2)
-            res[i] = la.norm(Hd.H.mStiffness[1] * x - bh, 2)
-            if res[i] < tol * la.norm(bh, 2)
-                iter = i
-                break
-            end
-        end
-        return x, iter, res[1:iter], err[1:iter]
-    end
+        alpha::AbstractFloat = 2.0 / 3.0, exact::Bool = true, check_every::Integer = 1)
     on_device = x0 isa DeviceVector && b isa DeviceVector
     dx0 = x0 isa DeviceVector ? x0 : DeviceVector(Hd.ctx, x0)
     db = b isa DeviceVector ? b : DeviceVector(Hd.ctx, b)
     dx = DeviceVector(Hd.ctx, db.n)
-    res = zeros(cld(max(maxiter, 1), check_every)); ncyc = Ref{Cint}(0); nchk = Ref{Cint}(0)
-    GC.@preserve res check(Hd.ctx.h, ccall((:aggmg_multigrid_dev, LIB), Cint,
-        (Handle, Handle, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Float64, Cint, Cint, Cint, Float64, Ptr{Cvoid},
-         Ptr{Float64}, Ref{Cint}, Ref{Cint}),
-        Hd.ctx.h, Hd.h, dx0.p, db.p, maxiter, Float64(tol), check_every, nPre, nPost, Float64(alpha), dx.p,
-        res, ncyc, nchk))
-    return (on_device ? dx : download(dx)), Int(ncyc[]), res[1:nchk[]], Float64[]
+    nchk = cld(max(maxiter, 1), check_every)
+    res = zeros(nchk); err = zeros(nchk); ncyc = Ref{Cint}(0); nck = Ref{Cint}(0)
+    if exact
+        ue = solve(direct_solver(Hd, Hd.ops[1]), Hd.H.mStiffness[1], db)
+        GC.@preserve dx0 db dx ue res err check(Hd.ctx.h, ccall((:aggmg_multigrid_dev, LIB), Cint,
+            (Handle, Handle, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Float64, Cint, Cint, Cint, Float64, Ptr{Cvoid},
+             Ptr{Float64}, Ref{Cint}, Ref{Cint}, Ptr{Cvoid}, Ptr{Float64}),
+            Hd.ctx.h, Hd.h, dx0.p, db.p, maxiter, Float64(tol), check_every, nPre, nPost, Float64(alpha), dx.p,
+            res, ncyc, nck, ue.p, err))
+    else
+        GC.@preserve dx0 db dx res check(Hd.ctx.h, ccall((:aggmg_multigrid_dev, LIB), Cint,
+            (Handle, Handle, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Float64, Cint, Cint, Cint, Float64, Ptr{Cvoid},
+             Ptr{Float64}, Ref{Cint}, Ref{Cint}, Ptr{Cvoid}, Ptr{Float64}),
+            Hd.ctx.h, Hd.h, dx0.p, db.p, maxiter, Float64(tol), check_every, nPre, nPost, Float64(alpha), dx.p,
+            res, ncyc, nck, C_NULL, C_NULL))
+    end
+    return (on_device ? dx : download(dx)), Int(ncyc[]), res[1:nck[]], (exact ? err[1:nck[]] : Float64[])
 end
 
 # iterative_smoother_solve(A, smoother, x0, b; maxiter = 1000, tol = 1e-6, alpha = 1.0) -> x, iter, res, err
-# (src/solvers.jl:189-213) for a device smoother; A is the host matrix the reference passes (used for the
-# direct solve of :194 when exact = true), the sweeps run on S.A
+# (src/solvers.jl:189-213) for a device smoother, the reference's full 4-tuple: A is the host matrix the reference
+# passes (only the host fallback of the direct solve of :194 reads it), the sweeps run on S.A, and
+# err[i] = ||x_i - A \\ b||_2 (:202) is formed on the device (aggmg_smoother_solve_dev).  exact = false: err empty.
 function iterative_smoother_solve(A::sp.SparseMatrixCSC{Float64,Int64}, S::DeviceSmoother, x0::AbstractVector,
         b::AbstractVector; maxiter::Integer = 1000, tol::AbstractFloat = 1e-6, alpha::AbstractFloat = 1.0,
-        exact::Bool = false)
+        exact::Bool = true, check_every::Integer = 1)
     N = length(b)
     dx0 = DeviceVector(S.ctx, x0); db = DeviceVector(S.ctx, b)
     dx = DeviceVector(S.ctx, N)
-    res = zeros(max(maxiter, 1)); nit = Ref{Cint}(0); nchk = Ref{Cint}(0)
-    GC.@preserve res check(S.ctx.h, ccall((:aggmg_smoother_solve_dev, LIB), Cint,
-        (Handle, Handle, Handle, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Float64, Float64, Cint, Ptr{Cvoid},
-         Ptr{Float64}, Ref{Cint}, Ref{Cint}),
-        S.ctx.h, S.A.h, S.h, dx0.p, db.p, maxiter, Float64(tol), Float64(alpha), 1, dx.p, res, nit, nchk))
-    x = download(dx)
-    # the reference records ||x_i - uExact|| per iteration; only the final error is available without
-    # bringing every iterate back, so `err` holds that one value when exact = true
-    err = exact ? [la.norm(x - A \ b, 2)] : Float64[]
-    return x, Int(nit[]), res[1:nchk[]], err
+    nchk = cld(max(maxiter, 1), check_every)
+    res = zeros(nchk); err = zeros(nchk); nit = Ref{Cint}(0); nck = Ref{Cint}(0)
+    if exact
+        ue = solve(direct_solver(S, S.A), A, db)
+        GC.@preserve dx0 db dx ue res err check(S.ctx.h, ccall((:aggmg_smoother_solve_dev, LIB), Cint,
+            (Handle, Handle, Handle, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Float64, Float64, Cint, Ptr{Cvoid},
+             Ptr{Float64}, Ref{Cint}, Ref{Cint}, Ptr{Cvoid}, Ptr{Float64}),
+            S.ctx.h, S.A.h, S.h, dx0.p, db.p, maxiter, Float64(tol), Float64(alpha), check_every, dx.p, res, nit, nck,
+            ue.p, err))
+    else
+        GC.@preserve dx0 db dx res check(S.ctx.h, ccall((:aggmg_smoother_solve_dev, LIB), Cint,
+            (Handle, Handle, Handle, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Float64, Float64, Cint, Ptr{Cvoid},
+             Ptr{Float64}, Ref{Cint}, Ref{Cint}, Ptr{Cvoid}, Ptr{Float64}),
+            S.ctx.h, S.A.h, S.h, dx0.p, db.p, maxiter, Float64(tol), Float64(alpha), check_every, dx.p, res, nit, nck,
+            C_NULL, C_NULL))
+    end
+    return download(dx), Int(nit[]), res[1:nck[]], (exact ? err[1:nck[]] : Float64[])
 end
 
 end # module

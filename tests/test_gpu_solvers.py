@@ -101,6 +101,52 @@ def test_smoother_solve_device_loop(oracle, mg):
     assert np.allclose(resg, reso, rtol=1e-10, atol=1e-12 * np.linalg.norm(bc))
 
 
+def test_err_histories_are_formed_on_the_device(oracle, mg):
+    """multigrid / iterative_smoother_solve return the reference's full 4-tuple (x, iter, res, err) with
+    err[i] = ||x_i - A \\ b||_2 (src/solvers.jl:120,128 and :194,202) -- exact=True, the default of both mirrors -- and the
+    direct solve behind it runs on the device where the fine operator is block-tridiagonal (block cyclic reduction:
+    DG p = 8 has 9 x 9 blocks, the largest instantiated; the CG hierarchy falls back to a host factorisation, once).
+    Against the oracle's histories on the tests/dg_heirarchy_test.jl shape (n = 128, DG p = 8 -> 4 -> 2 -> 1,
+    CDir = 1000 n): 1e-9 of the first error (the two direct solves agree to cond(A) eps ~ 1e-10 of ||u||)."""
+    o = oracle
+    Ho, b = o.build_dg_p_hierarchy(128, ps=(8, 4, 2, 1))
+    H = mg.MeshHierarchy.from_reference(Ho)
+    x0 = np.zeros(len(b))
+    xo, ito, reso, erro = o.multigrid(Ho, x0, b, 100, 1e-10)
+    xg, itg, resg, errg = mg.multigrid(H, x0, b, 100, 1e-10)
+    assert itg == ito and len(errg) == len(erro) == ito
+    assert np.allclose(errg, erro, rtol=1e-6, atol=1e-9 * erro[0])
+    assert np.allclose(resg, reso, rtol=1e-6, atol=1e-11 * np.linalg.norm(b))
+    assert H._direct_solver.where == "device"
+    # vectors that stay in HBM: same histories, a DeviceVector comes back
+    ctx = H.ctx
+    xd, itd, resd, errd = mg.multigrid(H, ctx.to_device(x0), ctx.to_device(b), 100, 1e-10)
+    assert isinstance(xd, mg.DeviceVector) and itd == itg and errd == errg and resd == resg
+    assert np.array_equal(xd.download(), xg)
+    # one error per check with check_every > 1
+    x3, it3, res3, err3 = mg.multigrid(H, x0, b, 100, 1e-10, check_every=3)
+    assert len(err3) == len(res3) == (it3 + 2) // 3
+    assert np.allclose(err3[:-1], np.asarray(errg)[2::3][:len(err3) - 1], rtol=1e-9)
+    # the stationary smoother loop (tests/dg_smoother_test.jl shape: n = 16, p = 2, CDir = 1000 n)
+    Hs, bs = o.build_dg_p_hierarchy(16, ps=(2, 1))
+    A, dg = Hs.mStiffness[0], Hs.mMeshes[0]
+    u0 = np.zeros(len(bs))
+    _, ito, reso, erro = o.iterative_smoother_solve(A, o.dg_smoother(dg, A, 'blockJac'), u0, bs, maxiter=60, tol=1e-30,
+                                                    alpha=2.0 / 3.0)
+    Sg = mg.dg_smoother(dg, A, 'blockJac')
+    _, itg, resg, errg = mg.iterative_smoother_solve(A, Sg, u0, bs, maxiter=60, tol=1e-30, alpha=2.0 / 3.0)
+    assert itg == ito == 60 and len(errg) == 60
+    assert np.allclose(errg, erro, rtol=1e-9, atol=1e-9 * erro[0])
+    assert Sg._direct_solver.where == "device"
+    # CG fine level (vertices-first numbering: no band): the direct solve falls back to a host factorisation, the
+    # error history is still formed on the device
+    Hc, bc = o.build_cg_hierarchy(32, ps=(4, 2, 1), nDG=1)
+    Hg = mg.MeshHierarchy.from_reference(Hc)
+    _, ito, _, erro = o.multigrid(Hc, np.zeros(len(bc)), bc, 60, 1e-9)
+    _, itg, _, errg = mg.multigrid(Hg, np.zeros(len(bc)), bc, 60, 1e-9)
+    assert itg == ito and np.allclose(errg, erro, rtol=1e-6, atol=1e-9 * erro[0])
+
+
 def test_pcg_with_ldiv_preconditioner(oracle, mg):
     """extension (no reference loop): device recurrence == the oracle's restatement of it"""
     o = oracle

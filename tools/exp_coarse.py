@@ -26,6 +26,34 @@ def block_tridiag(nb, m, seed=0):
     return sp.csc_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(nb * m, nb * m))
 
 
+def calibrate(ctx, args):
+    """cold streaming ceiling: for every (bytes, workgroups, mode) the median of `steps` launches, each after 2 GB
+    have been streamed through the caches (as --cold does before every solve)"""
+    import ctypes
+    nflush = 1 << 27
+    big = [ctx.alloc(nflush), ctx.alloc(nflush)]
+    P, I = ctypes.c_void_p * 1, ctypes.c_int64 * 1
+    srcs, dsts = P(big[0].ptr.value), P(big[1].ptr.value)
+    rows, cols, ld = I(1), I(nflush), I(nflush)
+    mbs = [int(v) for v in args.calib_mb.split(",")]
+    nmax = max(mbs) * 1000 * 1000 // 8 + 2
+    a, b = ctx.to_device(np.ones(nmax)), ctx.alloc(nmax)
+    ms = ctypes.c_double(0.0)
+    for mb in mbs:
+        for wgs in (int(v) for v in args.calib_wgs.split(",")):
+            for mode, name in ((1, "read"), (0, "copy")):
+                # mode 0 moves nbytes in and nbytes out: give it half, so that `mb` is the traffic of either mode
+                nbytes = (mb * 1000 * 1000 // (1 if mode else 2)) // 16 * 16
+                t = []
+                for _ in range(max(5, args.steps // 5)):
+                    ctx.check(ctx.lib.aggmg_copy_segments_dev(ctx.handle, 1, srcs, dsts, rows, cols, ld, ld))
+                    ctx.check(ctx.lib.aggmg_debug_stream_copy(ctx.handle, b.ptr, a.ptr, nbytes, wgs, mode, ctypes.byref(ms)))
+                    t.append(ms.value)
+                med = float(np.median(t))
+                print(json.dumps({"calibrate": name, "traffic_MB": mb, "workgroups": wgs, "us": round(1e3 * med, 2),
+                                  "TBps": round(mb * 1e6 / (med * 1e-3) / 1e12, 3), "min_us": round(1e3 * min(t), 2)}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=str, default="24:1,20:2,21:1,17:2,18:2,14:1")
@@ -33,10 +61,19 @@ def main():
     ap.add_argument("--cold", action="store_true",
                     help="stream 2 GB through the caches before every solve and time the solve with HIP events: "
                          "inside a V-cycle the factors come from HBM, not from the Infinity Cache")
+    ap.add_argument("--calibrate", action="store_true",
+                    help="instead of solves: a plain cold 16-byte streaming kernel (aggmg_debug_stream_copy) of the byte counts "
+                         "the solve's streaming steps move, on the same grid (256 workgroups x 256 threads) and on larger "
+                         "ones -- the ceiling those steps are held against")
+    ap.add_argument("--calib-mb", type=str, default="82,135,256,1024")
+    ap.add_argument("--calib-wgs", type=str, default="256,512,1024,4096")
     args = ap.parse_args()
     import agglomerationmultigrid1d_amd as mg
     from agglomerationmultigrid1d_amd import _lib
     ctx = mg.Context(0)
+    if args.calibrate:
+        calibrate(ctx, args)
+        return
     for case in args.cases.split(","):
         lg, m = (int(v) for v in case.split(":"))
         nb = 1 << lg
