@@ -131,6 +131,8 @@ SYMBOLS = {
     "aggmg_coarse_boundary_solve_dev": (c_int, [_P, _P, _P, _P, _P]),
     "aggmg_coarse_chunk_backward_dev": (c_int, [_P, _P, _P, c_int64, c_int64, _P, _P]),
     "aggmg_hier_level_kind": (c_int, [_P, _P, c_int, POINTER(c_int)]),
+    "aggmg_hier_launch_bytes": (c_int, [_P, _P, c_int, c_int, c_int, POINTER(c_int64), POINTER(c_int64)]),
+    "aggmg_smoother_launch_bytes": (c_int, [_P, _P, _P, c_int, POINTER(c_int64), POINTER(c_int64)]),
     "aggmg_hier_coarse_info": (c_int, [_P, _P, POINTER(c_int), POINTER(c_int), POINTER(c_double)]),
     "aggmg_hier_coarse_probe": (c_int, [_P, _P, POINTER(c_double)]),
     "aggmg_hier_coarse_tail": (c_int, [_P, _P, POINTER(c_int), POINTER(c_int64)]),

@@ -782,6 +782,16 @@ class MeshHierarchy:
             out.append(_lib.LEVEL_KIND_NAMES[v.value])
         return out
 
+    def launch_bytes(self, level, kind, has_x0=None):
+        """(read, write) compulsory HBM bytes of the fused launch of `level`: kind 'down' / 'up' / 'mid'
+        (C ABI aggmg_hier_launch_bytes) -- every array of the launch counted once, as stored."""
+        kk = {"down": _lib.KIND_FUSED_DOWN, "up": _lib.KIND_FUSED_UP, "mid": _lib.KIND_FUSED_MID}[kind]
+        r, w = ctypes.c_int64(0), ctypes.c_int64(0)
+        x0 = (level == 0) if has_x0 is None else bool(has_x0)
+        self.ctx.check(self.ctx.lib.aggmg_hier_launch_bytes(self.ctx.handle, self.handle, int(level), kk, int(x0),
+                                                            ctypes.byref(r), ctypes.byref(w)))
+        return r.value, w.value
+
     def vcycle_dev(self, x0, b, x_out, nPre=3, nPost=3, alpha=2.0 / 3.0):
         """Device-resident V-cycle: x0, b, x_out are DeviceVector / torch tensors / raw pointers;
         asynchronous on the context stream."""
@@ -1099,3 +1109,13 @@ def prolong_add(L_op, uc, u):
     c = L_op.ctx
     c.check(c.lib.aggmg_prolong_add(c.handle, L_op.handle, _pd(_f64(uc)), _pd(u)))
     return u
+
+
+def smoother_launch_bytes(op, smoother=None, what="sweeps"):
+    """(read, write) compulsory HBM bytes of one aggmg_smooth_dev launch (what='sweeps') or one aggmg_residual_dev
+    launch (what='residual') on operator `op` (C ABI aggmg_smoother_launch_bytes): every array counted once."""
+    ctx = op.ctx
+    r, w = ctypes.c_int64(0), ctypes.c_int64(0)
+    ctx.check(ctx.lib.aggmg_smoother_launch_bytes(ctx.handle, op.handle, smoother.handle if smoother is not None else None,
+                                                  {"sweeps": 0, "residual": 1}[what], ctypes.byref(r), ctypes.byref(w)))
+    return r.value, w.value

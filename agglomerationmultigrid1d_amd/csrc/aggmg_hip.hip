@@ -1855,6 +1855,95 @@ extern "C" int aggmg_hier_level_kind(aggmg_ctx* ctx, const aggmg_hier* h, int le
   return AGGMG_OK;
 }
 
+// ---- compulsory bytes of a launch: what its arrays hold, each read or written once -------------
+// (the denominator-free side of the roofline fraction: no halo re-reads, no cache effects, no CSR
+// model -- the arrays in the format the level stores them)
+static void btd_launch_bytes(const BtdDev& b, bool sweeps, bool u_in, bool residual, bool r_out, const TransferBtd* tin,
+                             const TransferBtd* tout, bool preconditioned, int64_t* rd, int64_t* wr) {
+  const int64_t m = b.m, ne = b.ne, N = ne * m, D = sizeof(double);
+  const bool need_g = sweeps || (tout && preconditioned);
+  const bool grp = (b.cmp && (m == 2 || m == 4 || m == 8)) || (!b.cmp && (m == 2 || m == 4));
+  const bool sym = grp && b.bsym;
+  int64_t r = N * D, w = 0;                                                 // b
+  if (u_in) r += N * D;
+  if (need_g) {
+    r += sym ? ne * (m * (m + 1) / 2) * D : N * m * D;                       // B^{-1}: packed or full rows
+    if (b.cmp) r += sym ? 0 : N * D;                                         // pcol (rebuilt from qrow when packed)
+    else r += sym ? N * m * D : 2 * N * m * D;                               // sup, or P and Q
+  }
+  if (b.cmp) r += N * D;                                                     // qrow
+  const bool explicit_res = residual && (r_out || (tout && !preconditioned));
+  if (explicit_res) {
+    r += N * m * D;                                                          // diagonal blocks
+    if (b.cmp) r += N * D;                                                   // scol
+    else r += (sym && need_g ? 1 : 2) * N * m * D;                           // sub (+ sup unless the sweeps read it already)
+  }
+  if (tin) {
+    r += tin->lf1 ? N * D : N * tin->mc * D;                                 // rows of L
+    r += tin->nec * tin->mc * D;                                             // coarse iterate
+    if (!tin->rho) r += ne * 4;                                              // parent map
+  }
+  if (sweeps || tin) w += N * D;                                             // iterate
+  if (r_out) w += N * D;
+  if (residual && tout) {
+    r += preconditioned ? N * tout->mc * D : (tout->lf1 ? N * D : N * tout->mc * D);
+    if (!tout->rho) r += ne * 4 + (tout->nec + 1) * 4;
+    w += tout->nec * tout->mc * D;
+  }
+  *rd = r;
+  *wr = w;
+}
+
+extern "C" int aggmg_hier_launch_bytes(aggmg_ctx* ctx, const aggmg_hier* h, int level, int kind, int has_x0,
+                                       int64_t* read_bytes, int64_t* write_bytes) {
+  if (!ctx || !h || !read_bytes || !write_bytes) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_hier_launch_bytes: NULL argument");
+  if (level < 0 || level + 1 >= (int)h->lv.size())
+    return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_hier_launch_bytes: level out of range (the coarsest level has no fused launch)");
+  if (kind != AGGMG_KIND_FUSED_DOWN && kind != AGGMG_KIND_FUSED_UP && kind != AGGMG_KIND_FUSED_MID)
+    return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_hier_launch_bytes: kind must be AGGMG_KIND_FUSED_DOWN / _UP / _MID");
+  const Level& l = h->lv[level];
+  const bool down = kind != AGGMG_KIND_FUSED_UP, up = kind != AGGMG_KIND_FUSED_DOWN;
+  if (l.cgt_fused) return cgt_launch_bytes(ctx, h, level, down, up, has_x0 != 0, read_bytes, write_bytes);
+  if (!(l.S && l.S->btd && l.S->A == l.A && l.tb))
+    return fail(ctx, AGGMG_ERR_UNSUPPORTED, "aggmg_hier_launch_bytes: the level runs the generic kernels (several launches)");
+  const bool pre = l.tb->ld && h->restriction == AGGMG_RESTRICT_PRECONDITIONED;
+  btd_launch_bytes(*l.S->btd, true, up || has_x0, down, false, up ? l.tb.get() : nullptr, down ? l.tb.get() : nullptr, pre,
+                   read_bytes, write_bytes);
+  return AGGMG_OK;
+}
+
+extern "C" int aggmg_smoother_launch_bytes(aggmg_ctx* ctx, aggmg_op* A, aggmg_smoother* sm, int what, int64_t* read_bytes,
+                                           int64_t* write_bytes) {
+  if (!ctx || !A || !read_bytes || !write_bytes) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_smoother_launch_bytes: NULL argument");
+  if (what != 0 && what != 1) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_smoother_launch_bytes: what must be 0 (sweeps) or 1 (residual)");
+  if (what == 0 && !sm) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_smoother_launch_bytes: sweeps need the smoother");
+  const int64_t N = A->m, D = sizeof(double);
+  if (what == 0 && sm->cgt && sm->A == A) return cgt_op_launch_bytes(*sm->cgt, true, read_bytes, write_bytes);
+  if (what == 1 && A->cgt) return cgt_op_launch_bytes(*A->cgt, false, read_bytes, write_bytes);
+  if (what == 0 && sm->btd && sm->A == A) {
+    btd_launch_bytes(*sm->btd, true, true, false, false, nullptr, nullptr, false, read_bytes, write_bytes);
+    return AGGMG_OK;
+  }
+  if (what == 1 && A->btd) {
+    btd_launch_bytes(*A->btd, false, true, true, true, nullptr, nullptr, false, read_bytes, write_bytes);
+    return AGGMG_OK;
+  }
+  // generic CSR: int32 column indices + fp64 entries + row pointers, the vectors once each
+  int64_t r = A->nnz * (4 + D) + (N + 1) * 4 + 2 * N * D;   // entries, row pointers, u and b
+  int64_t w = N * D;
+  if (what == 0) {
+    if (sm->kind == 0) {
+      r += N * D;                                             // diagonal
+    } else {
+      r += sm->nb * sm->m * sm->m * D + sm->nb * sm->m * 4;   // block inverses and their index lists
+      if (sm->kind == 2) r += N * D;                          // overlap counts
+    }
+  }
+  *read_bytes = r;
+  *write_bytes = w;
+  return AGGMG_OK;
+}
+
 extern "C" int aggmg_hier_coarse_probe(aggmg_ctx* ctx, const aggmg_hier* h, double* backward_error) {
   if (!ctx || !h || !backward_error) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_hier_coarse_probe: NULL argument");
   *backward_error = h->cr_probe_backward_error;

@@ -320,6 +320,48 @@ int cgt_mid(aggmg_ctx* ctx, aggmg_hier* h, const double* cur, double* alt, const
   return cgt_run(ctx, g, ch, alpha, nsweeps, first, last, AGGMG_KIND_FUSED_MID, 0);
 }
 
+// ---- compulsory bytes: what the arrays of a launch hold, each read or written once -------------
+static int64_t cgt_operator_bytes(const CgtDev& g, bool sweeps) {
+  const int64_t D = sizeof(double), rows = g.ne * g.m;
+  int64_t r = rows * g.m * D + g.ne * g.m * D + rows * D;    // dblk, subrow, supcol
+  if (sweeps && g.sw) r += rows * (g.m + 1) * D + g.ne * (g.m + 1) * D;   // element inverses (Schwarz / element Gauss-Seidel)
+  return r;
+}
+static int64_t cgt_xfer_bytes(const TransferCgt& t, const CgtDev& g) {
+  const int64_t D = sizeof(double), rows = g.ne * g.m;
+  return t.type == kTrChain ? rows * (t.mc + 1) * D : rows * t.mc * D + g.ne * t.mc * D;
+}
+
+int cgt_op_launch_bytes(const CgtDev& g, bool sweeps, int64_t* rd, int64_t* wr) {
+  const int64_t D = sizeof(double);
+  *rd = cgt_operator_bytes(g, sweeps) + 2 * g.N * D + (g.affine ? 0 : g.ne * g.m * 4);   // u and b in the caller's numbering
+  *wr = g.N * D;
+  return AGGMG_OK;
+}
+
+int cgt_launch_bytes(aggmg_ctx* ctx, const aggmg_hier* h, int level, bool down, bool up, bool has_x0, int64_t* rd, int64_t* wr) {
+  const Level& l = h->lv[level];
+  const Level& c = h->lv[level + 1];
+  if (!l.S || !l.S->cgt || !l.tc) return fail(ctx, AGGMG_ERR_UNSUPPORTED, "aggmg_hier_launch_bytes: not a fused chain level");
+  const CgtDev& g = *l.S->cgt;
+  const int64_t D = sizeof(double), rows = g.ne * g.m;
+  const bool ext = (level == 0) || !l.native_io;
+  const int64_t vec = ext ? g.N : rows;
+  int64_t r = cgt_operator_bytes(g, true) + vec * D, w = 0;            // operator, right-hand side
+  if (up || has_x0) r += (up ? rows : g.N) * D;                        // iterate in (block order inside the hierarchy)
+  if (ext && !g.affine) r += rows * 4;                                 // block order -> caller's numbering
+  r += cgt_xfer_bytes(*l.tc, g);                                       // rows of L (either direction; once when both)
+  const int64_t nc = l.tc->nec * l.tc->mc;
+  const bool cp = l.tc->type == kTrChain && !c.native_io && l.tc->cperm;
+  if (up) r += nc * D + (cp ? nc * 4 : 0);                             // coarse iterate
+  if (down) w += nc * D;                                               // restricted residual
+  if (down && !up && cp) r += nc * 4;
+  w += (up && !down ? vec : rows) * D;                                 // iterate out
+  *rd = r;
+  *wr = w;
+  return AGGMG_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------------

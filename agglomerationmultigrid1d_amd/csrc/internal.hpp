@@ -423,6 +423,9 @@ int cgt_down(aggmg_ctx* ctx, aggmg_hier* h, int k, const double* uin, const doub
 int cgt_up(aggmg_ctx* ctx, aggmg_hier* h, int k, const double* rhs, int nPost, double alpha, double* dst,
            const double* src = nullptr);
 int cgt_mid(aggmg_ctx* ctx, aggmg_hier* h, const double* cur, double* alt, const double* b, int nsweeps, double alpha);
+// compulsory bytes (every array of the launch once) of a chain level's fused launches / of a stand-alone sweep or residual launch
+int cgt_launch_bytes(aggmg_ctx* ctx, const aggmg_hier* h, int level, bool down, bool up, bool has_x0, int64_t* rd, int64_t* wr);
+int cgt_op_launch_bytes(const CgtDev& g, bool sweeps, int64_t* rd, int64_t* wr);
 
 // ---------------------------------------------------------------------------------------------
 // device-side set-up (setup.hip)

@@ -18,17 +18,20 @@ metric  fine-level DoF-updates/s per V-cycle = N_fine * (nPre + nPost) / t_vcycl
         cycle timed (the coarsest direct solve included; its share is reported beside it).  `value`
         comes from the K-step bracket the driver contract prescribes; `median_ms_per_step` (K more
         steps, each timed on its own) rides along.
-roofline  dominant kernel = the fused fine-level descent launch.  achieved / frac follow SURVEY.md
-        8(d): ALGORITHMIC bytes per launch (CSR int32 + fp64 byte model, every sweep re-reading the
-        operator, from the actual nnz) / its mean HIP-event duration measured inside the timed region
-        on the launch stream -- `frac_basis` says so: the fused kernel reads the operator once per
-        launch for 3 sweeps + residual + restriction, so this figure exceeds 1.  `traffic` = PMC bytes
-        per launch of exactly this launch role (profiles/traffic.json, written by
-        tools/summarize_profiles.py from a profile that runs only default-mode cycles);
-        physical_frac = traffic / duration / 8 TB/s is the fraction of the HBM roofline actually used.
-cpu_baseline  the plain-C restatement (oracle/aggmg_oracle_c.c, kind "port") on the config-3 hierarchy at
-        its literal size (2^22 fine elements): 1 thread, and the OpenMP variant on all host cores of
-        this box (count stated), rank 0, N = 1 only.
+roofline  dominant kernel = the fused fine-level descent launch.  achieved / frac: COMPULSORY bytes of
+        the launch -- the arrays it has to read and to write, each once, in the format the level stores
+        them (aggmg_hier_launch_bytes: index-free block rows, packed symmetric inverses, transfer rows,
+        vectors) -- / its mean HIP-event duration measured inside the timed region on the launch
+        stream, over 8 TB/s: a fraction, <= 1 by construction.  `traffic` = PMC bytes per launch of
+        exactly this launch role (2*FETCH_SIZE + WRITE_SIZE, profiles/traffic.json, written by
+        tools/summarize_profiles.py from a profile that runs only default-mode cycles); physical_frac =
+        traffic / duration / 8 TB/s (what the memory system moved, halo re-reads included: a few per cent
+        above frac).  frac_survey_model keeps the SURVEY.md 8(d) figure (CSR int32 + fp64 byte model with
+        every sweep re-reading the operator): the fused kernel reads the operator once per launch for
+        3 sweeps + residual + restriction, so that one exceeds 1 and is not a bound.
+cpu_baseline  the plain-C restatement (oracle/aggmg_oracle_c.c, kind "port") on the SAME hierarchy at the
+        SAME size as `value` (2^24 fine elements by default): 1 thread, and the OpenMP variant on the host
+        cores of this box (count stated), rank 0, N = 1 only.
 """
 import argparse
 import json
@@ -54,8 +57,9 @@ def parse():
     ap.add_argument("--also-log2-elems", type=int, default=22,
                     help="N = 1 only: second, untimed-region run at this size (config 3 literal: 22); 0 = off")
     ap.add_argument("--p", type=int, default=3)
-    ap.add_argument("--cpu-log2-elems", type=int, default=22, help="size of the CPU-baseline run (config 3 literal: 22)")
-    ap.add_argument("--cpu-cycles", type=int, default=4)
+    ap.add_argument("--cpu-log2-elems", type=int, default=0,
+                    help="size of the CPU-baseline run; 0 (default) = the size of `value` (--log2-elems)")
+    ap.add_argument("--cpu-cycles", type=int, default=3)
     ap.add_argument("--cg-log2-elems", type=int, default=24,
                     help="N = 1 only: V-cycle on the CG p=4,2,1 -> DG p=0 hierarchy (config 5 shape) at 2^E elements; 0 = off")
     ap.add_argument("--ragged-log2-elems", type=int, default=20,
@@ -81,7 +85,8 @@ def cpu_baseline(args, nPre, nPost, alpha):
 
     import c_oracle
     from agglomerationmultigrid1d_amd.uniform import UniformDgAggHierarchy
-    n = 2 ** args.cpu_log2_elems
+    E = args.cpu_log2_elems or args.log2_elems
+    n = 2 ** E
     U = UniformDgAggHierarchy(n, p=args.p, pAgg=1, ratios=(4, 2, 2))
     As = [U.stiffness_csc(k) for k in range(U.nlevels)]
     Ls = [U.interpolation_csc(k) for k in range(U.nlevels - 1)]
@@ -98,16 +103,27 @@ def cpu_baseline(args, nPre, nPost, alpha):
     try:
         omp = ctypes.CDLL("libgomp.so.1")
         C.enable_omp(As, Ls)
-        # the box may grant this job fewer CPUs than the host has (a CPU quota does not show in
-        # os.cpu_count()): one cycle per candidate thread count, all host cores first, keep the fastest
-        cand = sorted({t for t in (ncores, ncores // 2, ncores // 4, ncores // 8, 32, 16, 8) if 1 <= t <= ncores}, reverse=True)
+        # the box may grant this job fewer CPUs than the host has (a CPU quota does not show in os.cpu_count()):
+        # thread counts ascending from 8, one warm cycle each, until a count is clearly slower than the best so far
+        # (oversubscribed counts cost seconds per cycle at this size and are never reached)
+        share = ncores
+        try:
+            share = min(share, len(os.sched_getaffinity(0)))
+            q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+            if q != "max":
+                share = min(share, max(1, int(int(q) / int(per))))
+        except Exception:
+            pass
+        cand = sorted({t for t in (4, 8, 16, 32, 64, 128, 256, share, ncores) if 1 <= t <= ncores})
         sweep = {}
+        xo = np.zeros(N)
         for t in cand:
             omp.omp_set_num_threads(t)
-            xo, _, _ = C.vcycle_omp(np.zeros(N), b, nPre, nPost, alpha)
+            if not sweep:
+                xo, _, _ = C.vcycle_omp(xo, b, nPre, nPost, alpha)   # (first touch of the OpenMP variant's arrays)
             xo, dto, _ = C.vcycle_omp(xo, b, nPre, nPost, alpha)
             sweep[t] = dto
-            if dto > 4.0 * min(sweep.values()) and len(sweep) >= 3:
+            if dto > 1.3 * min(sweep.values()) and len(sweep) >= 3:
                 break
         best = min(sweep, key=sweep.get)
         omp.omp_set_num_threads(best)
@@ -120,8 +136,8 @@ def cpu_baseline(args, nPre, nPost, alpha):
                     "kind": "port", "ms_per_cycle": 1e3 * statistics.median(to), "host_cores": ncores,
                     "ms_per_cycle_by_threads": {str(t): round(1e3 * v, 1) for t, v in sweep.items()},
                     "sample": f"same hierarchy and size, OpenMP row-gather variant of the C restatement; host has {ncores} "
-                              f"cores, thread counts {sorted(sweep)} tried with one cycle each and the fastest ({best}) "
-                              f"kept (the job's CPU share can be smaller than the host), median of {len(to)} cycles"}
+                              f"cores (CPU share of this job: {share}), thread counts {sorted(sweep)} tried in ascending order with "
+                              f"one cycle each and the fastest ({best}) kept, median of {len(to)} cycles"}
     except Exception as exc:  # no libgomp: the serial line stands alone
         omp_line = {"error": str(exc)}
     return {
@@ -130,7 +146,7 @@ def cpu_baseline(args, nPre, nPost, alpha):
         "unit": "DoF-updates/s",
         "cores": 1,
         "kind": "port",
-        "sample": f"median of {args.cpu_cycles} V(3,3) cycles, config-3 hierarchy at 2^{args.cpu_log2_elems} fine elements "
+        "sample": f"median of {args.cpu_cycles} V(3,3) cycles, config-3/4 hierarchy at 2^{E} fine elements "
                   f"(N_fine={N}), plain-C restatement in the reference's operation order, 1 thread of {ncores} host cores "
                   f"(the Julia reference adds ~6 heap allocations and one LAPACK call per block per sweep and "
                   f"re-factorises the coarsest level every cycle); coarsest solve {1e3 * coarse / args.cpu_cycles:.1f} ms "
@@ -207,7 +223,16 @@ def smoother_bench(mg, ctx, args, alpha):
                 ctx.check(lib.aggmg_residual_dev(ctx.handle, o_.handle, _ptr(uu), _ptr(bb), _ptr(rr)))
         return run
 
+    def comp_frac(entry, o_, s_, what, ms_per_launch):
+        """`frac`: compulsory bytes of ONE launch (every array once, as stored) / its duration / 8 TB/s"""
+        rw = mg.smoother_launch_bytes(o_, s_, what)
+        entry["compulsory_bytes_per_launch"] = sum(rw)
+        entry["frac"] = sum(rw) / (ms_per_launch * 1e-3) / 1e9 / HBM_PEAK_GBS
+        return entry
+
     def with_traffic(entry, key, ms_per_launch):
+        comp_frac(entry, op, S if key.startswith("sweeps") else None, "sweeps" if key.startswith("sweeps") else "residual",
+                  ms_per_launch)
         t = _traffic(f"smoother_{key}", "")
         if isinstance(t, dict):
             entry["traffic"] = t["hbm_bytes"]
@@ -253,13 +278,14 @@ def smoother_bench(mg, ctx, args, alpha):
         fn(2)
         dt = _time_loop(ctx, fn, reps)
         nsw = reps * per_launch
-        out[key] = {"us_per_sweep": 1e6 * dt / nsw, "algorithmic_GBs": Sj_bytes * nsw / dt / 1e9,
-                    "frac_of_8TBs": Sj_bytes * nsw / dt / 1e9 / HBM_PEAK_GBS}
+        out[key] = comp_frac({"us_per_sweep": 1e6 * dt / nsw, "algorithmic_GBs": Sj_bytes * nsw / dt / 1e9,
+                              "frac_of_8TBs": Sj_bytes * nsw / dt / 1e9 / HBM_PEAK_GBS}, op2, J, "sweeps", 1e3 * dt / reps)
     fn = resid(op2.handle, u, b, r)
     fn(1)
     dt = _time_loop(ctx, fn, 100)
-    out["generic_csr_residual"] = {"us_per_residual": 1e6 * dt / 100, "algorithmic_GBs": R_bytes * 100 / dt / 1e9,
-                                   "frac_of_8TBs": R_bytes * 100 / dt / 1e9 / HBM_PEAK_GBS}
+    out["generic_csr_residual"] = comp_frac({"us_per_residual": 1e6 * dt / 100, "algorithmic_GBs": R_bytes * 100 / dt / 1e9,
+                                             "frac_of_8TBs": R_bytes * 100 / dt / 1e9 / HBM_PEAK_GBS}, op2, None, "residual",
+                                            1e3 * dt / 100)
     del op, op2, S, J, U
     # CG p=4, n=2^20 (config 5's fine-level operator at 1/16 size): point-Jacobi through the chain kernel
     # (element lists given) and through the generic CSR kernel (operator only), smoother + residual
@@ -279,14 +305,15 @@ def smoother_bench(mg, ctx, args, alpha):
             fn(2)
             dt = _time_loop(ctx, fn, reps)
             nsw = reps * per_launch
-            cg[f"{label}_sweeps_{per_launch}_per_launch"] = {
+            cg[f"{label}_sweeps_{per_launch}_per_launch"] = comp_frac({
                 "us_per_sweep": 1e6 * dt / nsw, "algorithmic_GBs": Sc * nsw / dt / 1e9,
-                "frac_of_8TBs": Sc * nsw / dt / 1e9 / HBM_PEAK_GBS}
+                "frac_of_8TBs": Sc * nsw / dt / 1e9 / HBM_PEAK_GBS}, opc, Jc, "sweeps",
+                1e3 * dt / (reps if label == "chain" else nsw))
         fn = resid(opc.handle, uc, bc, rc)
         fn(1)
         dt = _time_loop(ctx, fn, 100)
-        cg[f"{label}_residual"] = {"us_per_residual": 1e6 * dt / 100, "algorithmic_GBs": Rc * 100 / dt / 1e9,
-                                   "frac_of_8TBs": Rc * 100 / dt / 1e9 / HBM_PEAK_GBS}
+        cg[f"{label}_residual"] = comp_frac({"us_per_residual": 1e6 * dt / 100, "algorithmic_GBs": Rc * 100 / dt / 1e9,
+                                             "frac_of_8TBs": Rc * 100 / dt / 1e9 / HBM_PEAK_GBS}, opc, None, "residual", 1e3 * dt / 100)
         del opc, Jc
     out["cg_p4_point_jacobi"] = cg
     # the element Schwarz smoothers of cg_smoother (src/smoother.jl:104-134) on the same operator: fused chain kernel
@@ -308,9 +335,10 @@ def smoother_bench(mg, ctx, args, alpha):
                 fn(2)
                 dt = _time_loop(ctx, fn, reps)
                 nsw = reps * per_launch
-                sw[f"{kind}_{label}_sweeps_{per_launch}_per_launch"] = {
+                sw[f"{kind}_{label}_sweeps_{per_launch}_per_launch"] = comp_frac({
                     "us_per_sweep": 1e6 * dt / nsw, "algorithmic_GBs": Ssw * nsw / dt / 1e9,
-                    "frac_of_8TBs": Ssw * nsw / dt / 1e9 / HBM_PEAK_GBS}
+                    "frac_of_8TBs": Ssw * nsw / dt / 1e9 / HBM_PEAK_GBS}, opc, Sw, "sweeps",
+                    1e3 * dt / (reps if label == "chain" else nsw))
             del opc, Sw
     out["cg_p4_element_schwarz"] = sw
     return out
@@ -358,6 +386,28 @@ def ragged_bench(mg, ctx, args, nPre, nPost, alpha):
     except Exception as e:
         out["error"] = repr(e)
     return out
+
+
+def _roofline(kernel, comp_rw, ms_per_launch, launches, survey_bytes, traffic, prof_ms, note):
+    """the bench line's roofline object: `achieved` / `frac` from the COMPULSORY bytes of the launch (every array it reads or
+    writes counted once, as stored: aggmg_hier_launch_bytes) over the launch's HIP-event duration -- a fraction of the
+    8 TB/s HBM roofline, <= 1 by construction; physical_frac from the PMC traffic of the same launch role (what the memory
+    system moved, halo re-reads included); frac_survey_model from the SURVEY 8(d) CSR byte model (not a bound)."""
+    sec = ms_per_launch * 1e-3
+    comp = comp_rw[0] + comp_rw[1]
+    achieved = comp / sec / 1e9
+    return {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "frac_basis": "compulsory bytes (arrays of the launch, each once) / HIP-event time / peak",
+            "compulsory_bytes_per_launch": comp, "compulsory_read_bytes": comp_rw[0], "compulsory_write_bytes": comp_rw[1],
+            "traffic": traffic,
+            "physical_GBs": (traffic / sec / 1e9) if traffic else None,
+            "physical_frac": (traffic / sec / 1e9 / HBM_PEAK_GBS) if traffic else None,
+            # the same bytes over the profile's own mean duration of this launch role (profiles/*_roles.md): the figure a
+            # reader of profiles/ recomputes
+            "physical_frac_profile_mean": (traffic / (prof_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic and prof_ms else None,
+            "traffic_over_compulsory": (traffic / comp) if traffic else None,
+            "frac_survey_model": survey_bytes / sec / 1e9 / HBM_PEAK_GBS, "survey_model_bytes_per_launch": survey_bytes,
+            "ms_per_launch": ms_per_launch, "launches_timed": launches, "note": note}
 
 
 def _coarse_roofline(tag, coarse_ms):
@@ -458,7 +508,7 @@ def cg_bench(mg, ctx, args, nPre, nPost, alpha):
     (dkind, dlevel), (dms, dcnt) = list(dom.items())[0]
     lm = bm[0]
     per_launch = nPre * lm['sweep'] + lm['residual'] + lm['restrict']
-    achieved = per_launch / (dms / dcnt * 1e-3) / 1e9
+    comp_rw = H.launch_bytes(dlevel, "down")
     traffic = _traffic("chain_down_L0", f"cg_log2n{E}")
     prof_ms = _traffic("chain_down_L0", f"cg_log2n{E}_ms_profile_mean")
     coarse_ms = kern.get("coarse_L3", {}).get("ms_per_launch", 0.0)
@@ -476,13 +526,9 @@ def cg_bench(mg, ctx, args, nPre, nPost, alpha):
             "median_ms_per_step": 1e3 * statistics.median(per),
             "vcycles_loop_ms_per_cycle": 1e3 * dt_loop / steps,
             "achieved_algorithmic_GBs_vcycle": vb * steps / dt / 1e9, "frac_of_8TBs_vcycle": vb * steps / dt / 1e9 / HBM_PEAK_GBS,
-            "roofline": {"bound": "hbm", "kernel": "cgt_fused_kernel<4> fused_down level 1 (3 sweeps + residual + restriction)",
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "frac_basis": "algorithmic", "traffic": traffic, "algorithmic_bytes_per_launch": per_launch,
-                         "physical_GBs": (traffic / (dms / dcnt * 1e-3) / 1e9) if traffic else None,
-                         "physical_frac": (traffic / (dms / dcnt * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
-                         "physical_frac_profile_mean": (traffic / (prof_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic and prof_ms else None,
-                         "ms_per_launch": dms / dcnt, "launches_timed": dcnt},
+            "roofline": _roofline("cgt_fused_kernel<4> fused_down level 1 (3 sweeps + residual + restriction)", comp_rw,
+                                  dms / dcnt, dcnt, per_launch, traffic, prof_ms,
+                                  "compulsory bytes: chain-form operator rows, transfer rows, vectors, each once"),
             "kernels": kern, "coarse_solve_ms_per_step": coarse_ms, "coarse_solve": _coarse_roofline(f"cg_log2n{E}", coarse_ms),
             "outer_solvers_to_1e-8": outer,
             "block_gs_extension": gs,
@@ -591,6 +637,8 @@ def main():
         H.vcycles_dev(state[0], b, state[1], steps, nPre, nPost, alpha)
         dt_loop = _time_loop(ctx, lambda reps: H.vcycles_dev(state[0], b, state[1], reps, nPre, nPost, alpha), steps)
         info = H.coarse_info()
+        comp_rw = H.launch_bytes(0, "down")
+        comp_all = {f"fused_{kd}_L{k}": sum(H.launch_bytes(k, kd)) for k in range(len(level_sizes) - 1) for kd in ("down", "up")}
         # the device-resident outer loops, outside the timed region: multigrid()
         # (src/solvers.jl:116-139, residual check every 8 cycles) and CG preconditioned with
         # ldiv! to ||A x - b|| < 1e-8 ||b|| from a zero guess
@@ -626,7 +674,7 @@ def main():
         H.free()
         return dict(N=N, dt=dt, per=per, dt_loop=dt_loop, prof=prof, prof_dom=prof_dom,
                     bytes_model=bytes_model, level_sizes=level_sizes, t_gen=t_gen, t_lib=t_lib,
-                    coarse_info=info, outer=outer, pcie=pcie)
+                    coarse_info=info, outer=outer, pcie=pcie, comp_rw=comp_rw, comp_all=comp_all)
 
     R = run_size(args.log2_elems, args.steps, args.warmup, True)
     N, dt, dt_loop, prof, bytes_model = R["N"], R["dt"], R["dt_loop"], R["prof"], R["bytes_model"]
@@ -640,10 +688,13 @@ def main():
     lm = bytes_model[dlevel]
     per_launch = {"fused_down": nPre * lm['sweep'] + lm['residual'] + lm['restrict'],
                   "fused_up": nPost * lm['sweep'] + lm['prolong']}.get(dkind, lm['sweep'])
-    achieved = per_launch / (dms / dcnt * 1e-3) / 1e9
     traffic = _traffic(f"{dkind}_L{dlevel}", f"dg_log2n{args.log2_elems}")
     prof_ms = _traffic(f"{dkind}_L{dlevel}", f"dg_log2n{args.log2_elems}_ms_profile_mean")
     kern_ms = {f"{k}_L{l}": {"ms_per_launch": v[0] / v[1], "launches": v[1]} for (k, l), v in sorted(prof.items())}
+    for k_, v_ in kern_ms.items():      # every fused launch of the cycle against the roofline (compulsory bytes, as `roofline.frac`)
+        if k_ in R["comp_all"]:
+            v_["compulsory_bytes"] = R["comp_all"][k_]
+            v_["frac"] = R["comp_all"][k_] / (v_["ms_per_launch"] * 1e-3) / 1e9 / HBM_PEAK_GBS
     coarse_dev = [v["ms_per_launch"] for k, v in kern_ms.items() if k.startswith("coarse_")]
     coarse_step_ms = coarse_dev[0] if coarse_dev else 0.0
     out = {
@@ -668,7 +719,7 @@ def main():
                    "parallelism": "single GPU",
                    "sizes_by_leg": {"value / roofline": f"2^{args.log2_elems} fine elements",
                                     "config3_2p22": f"2^{args.also_log2_elems}" if args.also_log2_elems else None,
-                                    "cpu_baseline": None if args.no_cpu_baseline else f"2^{args.cpu_log2_elems} fine elements (rate-normalised: DoF-updates/s)",
+                                    "cpu_baseline": None if args.no_cpu_baseline else f"2^{args.cpu_log2_elems or args.log2_elems} fine elements",
                                     "config5": f"2^{args.cg_log2_elems}" if args.cg_log2_elems else None,
                                     "smoother_only (config 2)": "2^20", "ragged": f"2^{args.ragged_log2_elems}" if args.ragged_log2_elems else None}},
         "achieved_algorithmic_GBs_vcycle": vcycle_bytes * args.steps / dt / 1e9,
@@ -683,21 +734,14 @@ def main():
         # (HIP events, untimed second pass)
         "coarse_solve_ms_per_step": coarse_step_ms,
         "value_excl_coarse_solve": N * (nPre + nPost) / max(1e-3 * (ms_per_step - coarse_step_ms), 1e-12),
-        "roofline": {"bound": "hbm", "kernel": f"btd_fused_kernel<{args.p + 1},cmp> {dkind} level {dlevel + 1}",
-                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "frac_basis": "algorithmic",
-                     "traffic": traffic, "algorithmic_bytes_per_launch": per_launch,
-                     "physical_GBs": (traffic / (dms / dcnt * 1e-3) / 1e9) if traffic else None,
-                     "physical_frac": (traffic / (dms / dcnt * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
-                     # the same bytes over the profile's own mean duration of this launch role (profiles/*_roles.md):
-                     # the figure a reader of profiles/ recomputes
-                     "physical_frac_profile_mean": (traffic / (prof_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic and prof_ms else None,
-                     "ms_per_launch": dms / dcnt, "launches_timed": dcnt,
-                     "note": "achieved / frac: ALGORITHMIC bytes per launch (SURVEY 8d model: CSR int32 + fp64, every "
-                             "sweep re-reading the operator) / HIP-event duration; the fused kernel reads the operator "
-                             "once per launch, so this exceeds 1.  traffic = PMC bytes per launch of this launch role "
-                             "(2*FETCH_SIZE + WRITE_SIZE, profiles/), physical_frac = traffic / duration / peak: the "
-                             "fraction of the HBM roofline the launch actually uses"},
+        "roofline": _roofline(f"btd_fused_kernel<{args.p + 1},cmp> {dkind} level {dlevel + 1}", R["comp_rw"], dms / dcnt, dcnt,
+                              per_launch, traffic, prof_ms,
+                              "frac: compulsory bytes of the launch (packed symmetric block inverses, coupling rows / columns, "
+                              "diagonal blocks for the residual, transfer rows, vectors; each array once) / HIP-event duration "
+                              "/ 8 TB/s.  physical_frac: PMC bytes of this launch role (2*FETCH_SIZE + WRITE_SIZE, profiles/) "
+                              "over the same duration.  frac_survey_model: SURVEY 8d CSR model with every sweep re-reading the "
+                              "operator -- exceeds 1 because the fused kernel reads the operator once for 3 sweeps + residual "
+                              "+ restriction; kept for continuity with r01-r03, not a bound"),
         "kernels": kern_ms,
         "setup_s": R["t_gen"] + R["t_lib"], "setup_generator_s": R["t_gen"], "setup_library_s": R["t_lib"],
     }

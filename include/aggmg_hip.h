@@ -480,6 +480,19 @@ int aggmg_pcg_dev(aggmg_ctx* ctx, aggmg_hier* h, const double* b, double* x_inou
  * costs ~7 us of stream time on MI355X). */
 int aggmg_profile_enable(aggmg_ctx* ctx, int on);
 int aggmg_profile_collect(aggmg_ctx* ctx, double* total_ms, int64_t* counts);
+/* Compulsory HBM bytes of one launch: the sizes of the arrays the launch has to read and to write, each counted
+ * once, in the format the level stores them (index-free block rows, packed symmetric inverses, transfer rows) --
+ * no halo re-reads, no cache effects, no CSR model.  bytes / launch duration / 8 TB/s is the launch's roofline
+ * fraction (<= 1 by construction; measurement aid, no reference counterpart).
+ * aggmg_hier_launch_bytes: the fused launch of `level` (not the coarsest) that aggmg_vcycle_dev enqueues, kind =
+ * AGGMG_KIND_FUSED_DOWN (src/solvers.jl:28-37), _UP (:41-47) or _MID (both, between the cycles of aggmg_vcycles_dev);
+ * has_x0: the descent reads an initial guess (level 0).  AGGMG_ERR_UNSUPPORTED on a level that runs the generic kernels.
+ * aggmg_smoother_launch_bytes: what = 0 one launch of aggmg_smooth_dev (any number of sweeps that fit one launch),
+ * what = 1 aggmg_residual_dev (sm may be NULL). */
+int aggmg_hier_launch_bytes(aggmg_ctx* ctx, const aggmg_hier* h, int level, int kind, int has_x0, int64_t* read_bytes,
+                            int64_t* write_bytes);
+int aggmg_smoother_launch_bytes(aggmg_ctx* ctx, aggmg_op* A, aggmg_smoother* sm, int what, int64_t* read_bytes,
+                                int64_t* write_bytes);
 
 /* Library / build identification ("aggmg_hip gfx950 ..."). */
 const char* aggmg_version(void);

@@ -104,8 +104,9 @@ def test_smoother_solve_device_loop(oracle, mg):
 def test_err_histories_are_formed_on_the_device(oracle, mg):
     """multigrid / iterative_smoother_solve return the reference's full 4-tuple (x, iter, res, err) with
     err[i] = ||x_i - A \\ b||_2 (src/solvers.jl:120,128 and :194,202) -- exact=True, the default of both mirrors -- and the
-    direct solve behind it runs on the device where the fine operator is block-tridiagonal (block cyclic reduction:
-    DG p = 8 has 9 x 9 blocks, the largest instantiated; the CG hierarchy falls back to a host factorisation, once).
+    direct solve behind it runs on the device where the fine operator is block-tridiagonal with blocks of at most 8 x 8
+    (block cyclic reduction; DG p = 8 has 9 x 9 blocks: the library's host banded LU, factored once per hierarchy; the CG
+    hierarchy falls back to a host sparse factorisation, once).
     Against the oracle's histories on the tests/dg_heirarchy_test.jl shape (n = 128, DG p = 8 -> 4 -> 2 -> 1,
     CDir = 1000 n): 1e-9 of the first error (the two direct solves agree to cond(A) eps ~ 1e-10 of ||u||)."""
     o = oracle
@@ -117,7 +118,14 @@ def test_err_histories_are_formed_on_the_device(oracle, mg):
     assert itg == ito and len(errg) == len(erro) == ito
     assert np.allclose(errg, erro, rtol=1e-6, atol=1e-9 * erro[0])
     assert np.allclose(resg, reso, rtol=1e-6, atol=1e-11 * np.linalg.norm(b))
-    assert H._direct_solver.where == "device"
+    assert H._direct_solver.where == "host banded LU"
+    # DG p = 7 (8 x 8 blocks, the largest the cyclic reduction is instantiated for): the direct solve is the device's
+    H7o, b7 = o.build_dg_p_hierarchy(64, ps=(7, 3, 1))
+    H7 = mg.MeshHierarchy.from_reference(H7o)
+    _, it7o, _, err7o = o.multigrid(H7o, np.zeros(len(b7)), b7, 100, 1e-10)
+    _, it7, _, err7 = mg.multigrid(H7, np.zeros(len(b7)), b7, 100, 1e-10)
+    assert it7 == it7o and np.allclose(err7, err7o, rtol=1e-6, atol=1e-9 * err7o[0])
+    assert H7._direct_solver.where == "device"
     # vectors that stay in HBM: same histories, a DeviceVector comes back
     ctx = H.ctx
     xd, itd, resd, errd = mg.multigrid(H, ctx.to_device(x0), ctx.to_device(b), 100, 1e-10)
