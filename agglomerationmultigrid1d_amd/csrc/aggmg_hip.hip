@@ -484,23 +484,10 @@ static int launch_btd_t(aggmg_ctx* ctx, FusedArgs a, int halo, const TileSel& se
   if (owned <= 0) return fail(ctx, AGGMG_ERR_UNSUPPORTED, "fused tile too small for the requested halo");
   a.owned = owned;
   a.halo_left = halo + shift;
-  int64_t ntiles = (a.lv.ne + owned - 1) / owned;
-  a.tile_split = 0;
-  a.tile_skip = 0;
-  if (sel.mode != 0) {
-    const int64_t head = std::min(std::max<int64_t>(sel.head, 0), a.lv.ne);
-    const int64_t tail = std::min(std::max(sel.tail, head), a.lv.ne);
-    const int64_t tA = std::min(ntiles, (head + owned - 1) / owned);       // tiles [0, tA) hold [0, head)
-    const int64_t tB = std::min(ntiles - tA, ntiles - tail / owned);       // the last tB tiles hold [tail, ne)
-    if (sel.mode == 1) {
-      a.tile_split = (int)tA;
-      a.tile_skip = ntiles - tA - tB;
-      ntiles = tA + tB;
-    } else {
-      a.tile_skip = tA;
-      ntiles = ntiles - tA - tB;
-    }
-  }
+  const TileSubset sub = fused_tile_subset(a.lv.ne, owned, sel.mode, sel.head, sel.tail);   // host_plan.hpp
+  const int64_t ntiles = sub.ntiles;
+  a.tile_split = sub.split;
+  a.tile_skip = sub.skip;
   if (ntiles == 0) return AGGMG_OK;
   const size_t lds = (size_t)2 * (T::TE + 2) * M * sizeof(double);
   constexpr bool kGrp = (CMP && (M == 2 || M == 4 || M == 8)) || (!CMP && (M == 2 || M == 4));
@@ -1302,10 +1289,10 @@ extern "C" int aggmg_hier_create(aggmg_ctx* ctx, int nlevels, aggmg_op* const* s
           double nd = 0.0, nr = 0.0;
           CHECK(setup_probe_vector(ctx, Nc, lc.u[1]));
           HIPCHK(hipMemsetAsync(lc.rhs, 0, (size_t)Nc * sizeof(double), ctx->stream));
-          CHECK(setup_csc_scatter(ctx, Ac, lc.u[1], 1.0, lc.rhs));                  // d = A w
+          CHECK(setup_band_matvec_add(ctx, Ac, h->cr.m, lc.u[1], 1.0, lc.rhs));     // d = A w (deterministic gather)
           CHECK(cr_solve(ctx, h->cr, lc.rhs, lc.u[0], nlevels - 1));                // x = CR(d)
           HIPCHK(hipMemcpyAsync(lc.tmp, lc.rhs, (size_t)Nc * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
-          CHECK(setup_csc_scatter(ctx, Ac, lc.u[0], -1.0, lc.tmp));                 // r = d - A x
+          CHECK(setup_band_matvec_add(ctx, Ac, h->cr.m, lc.u[0], -1.0, lc.tmp));    // r = d - A x
           CHECK(aggmg_norm2_dev(ctx, lc.rhs, Nc, &nd));
           CHECK(aggmg_norm2_dev(ctx, lc.tmp, Nc, &nr));
           h->cr_probe_backward_error = nd > 0.0 ? nr / nd : 0.0;
@@ -1334,7 +1321,7 @@ extern "C" int aggmg_hier_create(aggmg_ctx* ctx, int nlevels, aggmg_op* const* s
             CHECK(setup_smooth_vector(ctx, Nc, lc.rhs));
             CHECK(cr_solve(ctx, h->cr, lc.rhs, lc.u[0], nlevels - 1));
             HIPCHK(hipMemcpyAsync(lc.tmp, lc.rhs, (size_t)Nc * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
-            CHECK(setup_csc_scatter(ctx, Ac, lc.u[0], -1.0, lc.tmp));
+            CHECK(setup_band_matvec_add(ctx, Ac, h->cr.m, lc.u[0], -1.0, lc.tmp));
             CHECK(aggmg_norm2_dev(ctx, lc.rhs, Nc, &nd));
             CHECK(aggmg_norm2_dev(ctx, lc.tmp, Nc, &nr));
             *res = nd > 0.0 ? nr / nd : 0.0;
@@ -1732,18 +1719,36 @@ constexpr int kStageMaxLanes = 8;
 
 int stage_lanes(aggmg_ctx* ctx) {
   if (!ctx->stage.empty()) return (int)ctx->stage.size();
+  if (ctx->stage_failed) return -1;  // an earlier attempt could not get its streams / pinned chunks: plain copies from then on
   // (measured on the MI355X box, three 134 MB vectors: 28.5 ms through hipMemcpy, 20.5 ms with 8 lanes, 16.8 ms with 4)
   int n = std::min(4, (int)std::thread::hardware_concurrency());
   if (const char* e = std::getenv("AGGMG_STAGE_THREADS")) n = std::atoi(e);
   n = std::min(std::max(n, 1), kStageMaxLanes);
-  ctx->stage.resize(n);
-  for (auto& L : ctx->stage) {
-    if (hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking) != hipSuccess) return -1;
-    for (int k = 0; k < 2; ++k) {
-      if (hipHostMalloc(&L.pin[k], kStageChunk, hipHostMallocDefault) != hipSuccess) return -1;
-      if (hipEventCreateWithFlags(&L.ev[k], hipEventDisableTiming) != hipSuccess) return -1;
+  // built aside and handed to the context only when every lane is complete: a half-built set must never be seen by
+  // a later call (its workers would copy through null buffers)
+  std::vector<aggmg_ctx::StageLane> lanes(n);
+  bool ok = true;
+  for (auto& L : lanes) {
+    ok = ok && hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking) == hipSuccess;
+    for (int k = 0; k < 2 && ok; ++k) {
+      ok = ok && hipHostMalloc(&L.pin[k], kStageChunk, hipHostMallocDefault) == hipSuccess;
+      ok = ok && hipEventCreateWithFlags(&L.ev[k], hipEventDisableTiming) == hipSuccess;
     }
+    if (!ok) break;
   }
+  if (!ok) {
+    for (auto& L : lanes) {
+      for (int k = 0; k < 2; ++k) {
+        if (L.ev[k]) (void)hipEventDestroy(L.ev[k]);
+        if (L.pin[k]) (void)hipHostFree(L.pin[k]);
+      }
+      if (L.stream) (void)hipStreamDestroy(L.stream);
+    }
+    (void)hipGetLastError();
+    ctx->stage_failed = true;
+    return -1;
+  }
+  ctx->stage.swap(lanes);
   return n;
 }
 
@@ -1802,11 +1807,11 @@ int stage_copy(aggmg_ctx* ctx, bool to_device, int nvec, double* const* dev, dou
   std::vector<int> status(lanes, 0);
   std::vector<std::thread> th;
   th.reserve(lanes);
-  const size_t per = ((bytes / lanes) + 4095) & ~(size_t)4095;
   for (int t = 0; t < lanes; ++t)
     th.emplace_back([&, t] {
       for (int v = 0; v < nvec && !status[t]; ++v) {
-        const size_t lo = std::min(bytes, (size_t)t * per), hi = t == lanes - 1 ? bytes : std::min(bytes, (size_t)(t + 1) * per);
+        size_t lo = 0, hi = 0;
+        stage_lane_range(bytes, lanes, t, &lo, &hi);   // host_plan.hpp
         if (hi > lo) stage_slice(ctx->device, &ctx->stage[t], to_device, (char*)dev[v], (char*)host[v], lo, hi, &status[t]);
       }
     });

@@ -33,6 +33,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "host_plan.hpp"  // kCrTailRows, kCrMaxLevels, kCrMaxStageLevels, kCrMaxSteps and the step planner
+
 namespace aggmg {
 
 constexpr int kCrThreads = 256;
@@ -41,10 +43,6 @@ constexpr int kCrThreads = 256;
 #ifndef CR_WAVES_ATTR
 #define CR_WAVES_ATTR
 #endif
-constexpr int kCrTailRows = 4096;  // scalar rows (blocks * m) the single-workgroup tail takes
-constexpr int kCrMaxLevels = 40;
-constexpr int kCrMaxStageLevels = 12;
-constexpr int kCrMaxSteps = 8;
 
 struct CrLevel {
   const double* fe;    // [n_even][2][M][M]  forward multipliers (a_{2j} b_{2j-1}^-1, c_{2j} b_{2j+1}^-1)

@@ -440,15 +440,14 @@ extern "C" int aggmg_dist_create(aggmg_ctx* ctx, aggmg_hier* local, aggmg_hier* 
     const int64_t own_blk = own_hi[nc] - own_lo[nc];
     // every rank must own the same number of whole chunks, rank r the r-th run of them: the in-place all-gather
     // has equal counts and puts rank r's slice at r * count.  The decision must come out the same on every rank
-    // (mismatched collective counts hang): it depends only on the replicated operator's plan and on a partition
-    // that is even and in rank order -- anything else takes the gather-and-replicate route on ALL ranks, or is
-    // refused here when this rank alone breaks the pattern.
-    const bool plan_ok = q > 0 && mblk == m[nc] && nblk == ne[nc];
-    const bool even = own_blk * world == ne[nc];
-    const bool aligned = own_blk % ((int64_t)1 << std::max(q, 0)) == 0 && own_blk >= ((int64_t)1 << std::max(q, 0));
-    if (even && own_lo[nc] != (int64_t)rank * own_blk)
-      return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_dist_create: coarsest-level ranges must follow the rank order (own_lo = rank * blocks per rank)");
-    if (plan_ok && even && aligned) {
+    // (mismatched collective counts hang), so it is taken from GLOBAL quantities only -- the replicated operator's
+    // plan, the level's block count and the world size; a rank whose own range then breaks the pattern is refused
+    // here instead of taking another route than its peers.
+    const int route = dist_chunk_route(q, mblk, nblk, m[nc], ne[nc], world, rank, own_lo[nc], own_hi[nc]);   // host_plan.hpp
+    if (route < 0)
+      return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_dist_create: the coarsest level divides evenly into whole chunks per rank, so every "
+                                           "rank must own blocks [rank * n / world, (rank + 1) * n / world)");
+    if (route == 1) {
       d->chunked = true;
       d->q = q;
       d->nq = nq;

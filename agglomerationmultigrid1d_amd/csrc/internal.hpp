@@ -61,6 +61,7 @@ struct aggmg_ctx {
     hipEvent_t ev[2] = {nullptr, nullptr};
   };
   std::vector<StageLane> stage;
+  bool stage_failed = false;  // the lanes could not be allocated once: aggmg_vcycle keeps to plain hipMemcpy
 };
 
 struct CsrDev {
@@ -207,19 +208,10 @@ struct BandedLU {
 // block cyclic reduction of the coarsest operator, factored once (device-resident)
 // one launch of the cyclic reduction: levels [l0, l0 + q) in steps of up to three thread-local levels
 // (cr_kernels.hpp); chunk stages reduce 2^q-block chunks to their end blocks, the tail takes the rest
-struct CrStage {
-  int l0 = 0, q = 0;
-  int64_t n_in = 0, n_out = 0;  // blocks before / after
-  int nsteps = 0;
-  int step_a[kCrMaxSteps + 1] = {0};
-  int lds_off[kCrMaxSteps + 1] = {0}, lds_xoff[kCrMaxSteps + 1] = {0};
-  int lds_total = 0;            // doubles
+struct CrStage : CrStagePlan {    // the host-side plan (host_plan.hpp) + the stage's device buffers
   double *partR = nullptr, *partL = nullptr, *xq = nullptr;  // the stage's boundary system (n_out blocks)
   double* stack = nullptr;      // per chunk: summed inputs of the steps after the first
-  int stack_stride = 0;
   double* mid = nullptr;        // per step and sub-chunk: reduced right-hand sides of the inner sub-levels' odd rows
-  int64_t mid_off[kCrMaxSteps + 1] = {0};
-  int64_t mid_total = 0;        // doubles
 };
 
 struct CrDev {
@@ -254,41 +246,6 @@ struct CrDev {
   };
   std::vector<Raw> raw;
 };
-
-// step split and LDS layout of a stage of q levels with block size m
-inline void cr_plan_steps(CrStage* S, int m) {
-  const int Q = m <= 4 ? 3 : 2;
-  S->nsteps = 0;
-  S->step_a[0] = 0;
-  for (int a = 0; a < S->q;) {
-    const int qs = std::min(Q, S->q - a);
-    a += qs;
-    S->step_a[++S->nsteps] = a;
-  }
-  int o = 0;
-  for (int s = 1; s <= S->nsteps; ++s) {
-    const int cnt = ((1 << (S->q - S->step_a[s])) + 1) * m;
-    S->lds_off[s] = o;
-    o += 2 * cnt;
-  }
-  for (int s = 1; s <= S->nsteps; ++s) {
-    const int cnt = ((1 << (S->q - S->step_a[s])) + 1) * m;
-    S->lds_xoff[s] = o;
-    o += cnt;
-  }
-  S->lds_total = o;
-  S->stack_stride = 0;
-  for (int s = 1; s < S->nsteps; ++s) S->stack_stride += ((1 << (S->q - S->step_a[s])) + 1) * m;
-  // sub-chunk b of step s (a block index of the step's output level: at most (n_in >> a1) + 1 of them) keeps
-  // 2^(qs-1) - 1 blocks; every region 16-byte aligned
-  S->mid_total = 0;
-  for (int s = 0; s < S->nsteps; ++s) {
-    const int qs = S->step_a[s + 1] - S->step_a[s];
-    S->mid_off[s] = S->mid_total;
-    const int64_t cnt = ((S->n_in >> S->step_a[s + 1]) + 2) * (((int64_t)1 << (qs - 1)) - 1) * m;
-    S->mid_total += (cnt + 1) & ~(int64_t)1;
-  }
-}
 
 struct aggmg_hier {
   std::vector<Level> lv;
@@ -449,4 +406,4 @@ int coarse_boundary_solve_interleaved(aggmg_ctx* ctx, aggmg_hier* h, const doubl
 void cr_discard(CrDev* cr);                                                  // frees the factors, valid = false
 int setup_probe_vector(aggmg_ctx* ctx, int64_t n, double* w);                // hash-random entries in [-1, 1)
 int setup_smooth_vector(aggmg_ctx* ctx, int64_t n, double* w);               // 1 + cos(pi i / n) / 2
-int setup_csc_scatter(aggmg_ctx* ctx, const aggmg_op* A, const double* x, double sign, double* y);  // y += sign A x
+int setup_band_matvec_add(aggmg_ctx* ctx, const aggmg_op* A, int m, const double* x, double sign, double* y);  // y += sign A x, A block-tridiagonal (block size m), deterministic

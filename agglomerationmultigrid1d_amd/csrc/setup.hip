@@ -642,16 +642,32 @@ __global__ __launch_bounds__(kSetupThreads) void probe_vector_kernel(int64_t n, 
   w[i] = (double)(int64_t)(z >> 11) * (1.0 / 4503599627370496.0) - 1.0;
 }
 
-// y += sign * A x from the uploaded CSC arrays (column scatter, fp64 atomics): set-up checks only
-__global__ __launch_bounds__(kSetupThreads) void csc_scatter_kernel(int64_t ncols, const int32_t* __restrict__ cp,
-                                                                    const int32_t* __restrict__ rv,
-                                                                    const double* __restrict__ vv,
-                                                                    const double* __restrict__ x, double sign,
-                                                                    double* __restrict__ y) {
-  const int64_t j = (int64_t)blockIdx.x * kSetupThreads + threadIdx.x;
-  if (j >= ncols) return;
-  const double xj = sign * x[j];
-  for (int32_t p = cp[j]; p < cp[j + 1]; ++p) atomicAdd(&y[rv[p]], vv[p] * xj);
+// y += sign * A x from the uploaded CSC arrays, set-up checks only.  DETERMINISTIC: the acceptance decisions taken on
+// its result (probe backward error, parallel tail kept or not) must come out the same run to run and on every rank
+// of a partitioned job that holds a replica of the operator -- no atomics.  The operator is block-tridiagonal with
+// block size m (what the cyclic reduction it checks has established), so row i has its entries in the columns of
+// blocks i/m - 1 .. i/m + 1: one thread per row walks those <= 3m columns in ascending order and looks its row up in
+// each (rows ascend inside a column: validated at upload).
+__global__ __launch_bounds__(kSetupThreads) void csc_band_gather_kernel(int64_t n, int m, const int32_t* __restrict__ cp,
+                                                                        const int32_t* __restrict__ rv,
+                                                                        const double* __restrict__ vv,
+                                                                        const double* __restrict__ x, double sign,
+                                                                        double* __restrict__ y) {
+  const int64_t i = (int64_t)blockIdx.x * kSetupThreads + threadIdx.x;
+  if (i >= n) return;
+  const int64_t bi = i / m;
+  const int64_t j0 = bi > 0 ? (bi - 1) * m : 0;
+  const int64_t j1 = (bi + 2) * m < n ? (bi + 2) * m : n;
+  double acc = 0.0;
+  for (int64_t j = j0; j < j1; ++j) {
+    int32_t lo = cp[j], hi = cp[j + 1];
+    while (lo < hi) {  // first entry of column j with row >= i
+      const int32_t mid = lo + (hi - lo) / 2;
+      if (rv[mid] < (int32_t)i) lo = mid + 1; else hi = mid;
+    }
+    if (lo < cp[j + 1] && rv[lo] == (int32_t)i) acc += vv[lo] * x[j];
+  }
+  y[i] += sign * acc;
 }
 
 int setup_probe_vector(aggmg_ctx* ctx, int64_t n, double* w) {
@@ -672,8 +688,8 @@ int setup_smooth_vector(aggmg_ctx* ctx, int64_t n, double* w) {
   return AGGMG_OK;
 }
 
-int setup_csc_scatter(aggmg_ctx* ctx, const aggmg_op* A, const double* x, double sign, double* y) {
-  LAUNCH(csc_scatter_kernel, A->n, A->n, (const int32_t*)A->csc.rowptr, (const int32_t*)A->csc.colind,
+int setup_band_matvec_add(aggmg_ctx* ctx, const aggmg_op* A, int m, const double* x, double sign, double* y) {
+  LAUNCH(csc_band_gather_kernel, A->m, A->m, m, (const int32_t*)A->csc.rowptr, (const int32_t*)A->csc.colind,
          (const double*)A->csc.vals, x, sign, y);
   return AGGMG_OK;
 }
@@ -774,27 +790,24 @@ int setup_cr(aggmg_ctx* ctx, const aggmg_op* Ac, int hint_m, CrDev* cr) {
   };
   const int tail_rows = env_int("AGGMG_CR_TAIL_ROWS", kCrTailRows, 8, kCrTailRows);
   const int max_q = env_int("AGGMG_CR_MAX_Q", ctx->cr_max_q, 1, kCrMaxStageLevels);
-  int l0 = 0;
-  while (l0 < nl && level_n(l0) * m > tail_rows) {
-    int need = 0;
-    while (l0 + need < nl && level_n(l0 + need) * m > tail_rows) ++need;
-    // large chunks (every thread at least one sub-chunk of the streaming first step) as long as a few
-    // hundred workgroups remain
-    int fill = 0;
-    {
-      const char* e = std::getenv("AGGMG_CR_FILL");
-      const int fmax = e && *e ? std::atoi(e) : 12;
-      const char* w = std::getenv("AGGMG_CR_MINWG");
-      const int minwg = w && *w ? std::atoi(w) : 256;
-      while (fill < fmax && (level_n(l0) >> (fill + 1)) >= minwg) ++fill;
+  CrSolvePlan plan;
+  {
+    const char* e = std::getenv("AGGMG_CR_FILL");
+    const int fmax = e && *e ? std::atoi(e) : 12;
+    const char* w = std::getenv("AGGMG_CR_MINWG");
+    const int minwg = w && *w ? std::atoi(w) : 256;
+    std::vector<int64_t> ln(nl);
+    for (int l = 0; l < nl; ++l) ln[l] = cr->lv[l].n;
+    // (large chunks -- every thread at least one sub-chunk of the streaming first step -- as long as a few hundred
+    // workgroups remain; host_plan.hpp)
+    if (!cr_plan_solve(ln, m, tail_rows, max_q, fmax, minwg, &plan)) {
+      cr_release(cr);
+      return AGGMG_OK;
     }
+  }
+  for (const CrStagePlan& P : plan.stages) {
     CrStage S;
-    S.l0 = l0;
-    S.q = std::min({max_q, std::max(need, fill), nl - l0});
-    if (S.q < 1) break;
-    S.n_in = level_n(l0);
-    S.n_out = level_n(l0 + S.q);
-    cr_plan_steps(&S, m);
+    static_cast<CrStagePlan&>(S) = P;
     const int64_t nb = (S.n_out * m + 31) & ~(int64_t)31;  // the three boundary vectors in one allocation
     CHECK(dz(3 * nb, &S.partR));
     S.partL = S.partR + nb;  // partL[0] is never written: stays zero
@@ -802,17 +815,8 @@ int setup_cr(aggmg_ctx* ctx, const aggmg_op* Ac, int hint_m, CrDev* cr) {
     if (S.stack_stride > 0) CHECK(dz((S.n_out + 1) * (int64_t)S.stack_stride, &S.stack));
     if (S.mid_total > 0) CHECK(dz(S.mid_total, &S.mid));
     cr->st.push_back(S);
-    l0 += S.q;
   }
-  if (nl - l0 > kCrMaxStageLevels || level_n(l0) * m > tail_rows) {
-    cr_release(cr);
-    return AGGMG_OK;
-  }
-  cr->tail.l0 = l0;
-  cr->tail.q = nl - l0;
-  cr->tail.n_in = level_n(l0);
-  cr->tail.n_out = 1;
-  cr_plan_steps(&cr->tail, m);
+  static_cast<CrStagePlan&>(cr->tail) = plan.tail;
   if (cr->tail.mid_total > 0) CHECK(dz(cr->tail.mid_total, &cr->tail.mid));
   // The small levels (the tail and the last steps of the stage before it) are worked through by a
   // few threads, one dependent step after the other: their factors go into ONE allocation, so that a

@@ -275,6 +275,107 @@ class Comm:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 
+    def min_int(self, value, device=None):
+        """minimum over ranks of a small integer (agreement on a route before the first collective)"""
+        if self.world == 1:
+            return int(value)
+        on_dev = (not self.staged) and self.dist.get_backend() == "nccl"
+        t = self.torch.tensor([int(value)], dtype=self.torch.int32, device=device if on_dev else "cpu")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
+        return int(t.item())
+
+    # host-staged forms behind the library's collective callbacks (gloo rehearsals: ranks share a GPU)
+    def host_all_gather(self, s):
+        """NumPy vector -> concatenation over ranks"""
+        o = self.torch.empty(s.size * self.world, dtype=self.torch.float64)
+        self.dist.all_gather_into_tensor(o, self.torch.from_numpy(s))
+        return o.numpy()
+
+    def host_sendrecv(self, ops, bufs):
+        """ops: (peer, is_send, count) in issue order, bufs: one NumPy vector each (filled for sends, to be filled for
+        receives); messages of one pair and direction match in order"""
+        reqs, tags = [], {}
+        for (pr, snd, n), t in zip(ops, bufs):
+            tag = tags.get((pr, snd), 0)
+            tags[(pr, snd)] = tag + 1
+            tt = self.torch.from_numpy(t)
+            reqs.append(self.dist.isend(tt, pr, tag=tag) if snd else self.dist.irecv(tt, pr, tag=tag))
+        for r_ in reqs:
+            r_.wait()
+
+
+class ThreadGroup:
+    """shared state of `world` ranks run as THREADS of one process (ThreadComm)"""
+
+    def __init__(self, world):
+        import queue
+        import threading
+        self.world = world
+        self.barrier = threading.Barrier(world)
+        self.slots = [None] * world
+        self.lock = threading.Lock()
+        self.boxes = {}
+        self._queue = queue.Queue
+
+    def box(self, key):
+        with self.lock:
+            q = self.boxes.get(key)
+            if q is None:
+                q = self.boxes[key] = self._queue()
+            return q
+
+
+class ThreadComm(Comm):
+    """Comm over threads: `world` ranks inside ONE process, each with its own library context and stream on the same
+    GPU, collectives through shared memory and a barrier.  A rehearsal aid -- the partition layouts, the C++ schedule
+    of csrc/dist.hip and its callbacks at world sizes the box has neither GPUs nor process slots for (a one-GPU box
+    admits six GPU processes; the north-star job has eight ranks).  Host-staged like the gloo tests; nothing is timed
+    meaningfully through it."""
+
+    def __init__(self, group, rank):
+        import torch
+        self.torch, self.dist = torch, None
+        self.world, self.rank = group.world, rank
+        self.staged = True
+        self.g = group
+
+    def _exchange(self, mine):
+        g = self.g
+        g.slots[self.rank] = mine
+        g.barrier.wait()
+        allv = list(g.slots)
+        g.barrier.wait()
+        return allv
+
+    def all_gather(self, out, inp):
+        parts = self._exchange(inp.detach().cpu().clone())
+        out.copy_(self.torch.cat(parts))
+
+    def barrier(self):
+        self.g.barrier.wait()
+
+    def max(self, value):
+        return max(self._exchange(float(value)))
+
+    def min_int(self, value, device=None):
+        return min(self._exchange(int(value)))
+
+    def host_all_gather(self, s):
+        return np.concatenate(self._exchange(np.array(s, copy=True)))
+
+    def host_sendrecv(self, ops, bufs):
+        tags = {}
+        todo = []
+        for (pr, snd, n), t in zip(ops, bufs):
+            tag = tags.get((pr, snd), 0)
+            tags[(pr, snd)] = tag + 1
+            if snd:
+                self.g.box((self.rank, pr, tag)).put(np.array(t, copy=True))
+            else:
+                todo.append((pr, tag, t))
+        for pr, tag, t in todo:
+            t[:] = self.g.box((pr, self.rank, tag)).get(timeout=600)
+
 
 # ------------------------------------------------------------------------------------------
 # the schedule
@@ -558,9 +659,7 @@ class NativeDistributedVCycle:
                 ctx = self.ctx
                 s = np.empty(int(count))
                 ctx.check(ctx.lib.aggmg_memcpy_d2h(ctx.handle, s.ctypes.data, ctypes.c_void_p(send), int(count) * 8))   # syncs the stream
-                o = torch.empty(int(count) * c.world, dtype=torch.float64)
-                c.dist.all_gather_into_tensor(o, torch.from_numpy(s))
-                o = o.numpy()
+                o = np.ascontiguousarray(c.host_all_gather(s))
                 ctx.check(ctx.lib.aggmg_memcpy_h2d(ctx.handle, ctypes.c_void_p(recv), o.ctypes.data, o.size * 8))
             else:
                 ext = torch.cuda.ExternalStream(int(stream or 0), device=self.e.dev)
@@ -583,21 +682,16 @@ class NativeDistributedVCycle:
             ops = [(int(peer[i]), bool(is_send[i]), int(ptr[i]), int(count[i])) for i in range(int(nops))]
             if c.staged or c.dist.get_backend() != "nccl":
                 ctx = self.ctx
-                bufs, reqs = [], []
-                tags = {}
+                bufs = []
                 for pr, snd, p_, n in ops:
-                    t = torch.empty(n, dtype=torch.float64)
+                    t = np.empty(n)
                     if snd:
-                        ctx.check(ctx.lib.aggmg_memcpy_d2h(ctx.handle, t.numpy().ctypes.data, ctypes.c_void_p(p_), n * 8))
-                    tag = tags.get((pr, snd), 0)          # messages of one pair and direction match in order
-                    tags[(pr, snd)] = tag + 1
-                    reqs.append(c.dist.isend(t, pr, tag=tag) if snd else c.dist.irecv(t, pr, tag=tag))
+                        ctx.check(ctx.lib.aggmg_memcpy_d2h(ctx.handle, t.ctypes.data, ctypes.c_void_p(p_), n * 8))
                     bufs.append(t)
-                for r_ in reqs:
-                    r_.wait()
+                c.host_sendrecv([(pr, snd, n) for pr, snd, _, n in ops], bufs)
                 for (pr, snd, p_, n), t in zip(ops, bufs):
                     if not snd:
-                        ctx.check(ctx.lib.aggmg_memcpy_h2d(ctx.handle, ctypes.c_void_p(p_), t.numpy().ctypes.data, n * 8))
+                        ctx.check(ctx.lib.aggmg_memcpy_h2d(ctx.handle, ctypes.c_void_p(p_), t.ctypes.data, n * 8))
             else:
                 ext = torch.cuda.ExternalStream(int(stream or 0), device=self.e.dev)
                 with torch.cuda.stream(ext):
@@ -927,18 +1021,23 @@ def build_local_cg(n, ps, layout, ctx, comm, smoother=None):
 # ------------------------------------------------------------------------------------------
 # bench entry for N > 1 (called by bench.py)
 # ------------------------------------------------------------------------------------------
-def bench_main(args, rank, world, local_rank, nPre, nPost, alpha):
+def bench_main(args, rank, world, local_rank, nPre, nPost, alpha, group=None):
+    """group: a ThreadGroup -- this rank is one of `world` THREADS of a single process sharing one GPU (bench.py
+    --rehearse-threads: the N-rank code path end to end on a one-GPU box; its JSON line says so and is not a measurement)"""
     import torch
     import torch.distributed as dist
     from . import api as mg
     # AGGMG_DIST_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks
     # (host-staged collectives, ranks share devices); the driver's runs use nccl == RCCL.
-    backend = os.environ.get("AGGMG_DIST_BACKEND", "nccl")
+    backend = "threads" if group is not None else os.environ.get("AGGMG_DIST_BACKEND", "nccl")
     ndev = torch.cuda.device_count()
     device = local_rank % max(ndev, 1)
     torch.cuda.set_device(device)
-    dist.init_process_group(backend=backend, rank=rank, world_size=world)
-    comm = Comm(world, rank, staged=(backend != "nccl"))
+    if group is not None:
+        comm = ThreadComm(group, rank)
+    else:
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        comm = Comm(world, rank, staged=(backend != "nccl"))
     ctx = mg.Context(device)
     cfg5 = getattr(args, "dist_config", 4) == 5
     n = 2 ** (args.cg_log2_elems if cfg5 else args.log2_elems)
@@ -971,10 +1070,7 @@ def bench_main(args, rank, world, local_rank, nPre, nPost, alpha):
         if mode == "rccl":
             # every rank has to take the same route: agree on the outcome before the first collective, and fall
             # back together to the same schedule with its all-gathers issued through torch.distributed
-            ok = torch.tensor([0 if dv is None else 1], dtype=torch.int32,
-                              device=engine.dev if backend == "nccl" else "cpu")
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            if int(ok.item()) == 0:
+            if comm.min_int(0 if dv is None else 1, engine.dev) == 0:
                 rccl_note = f"in-library RCCL unavailable on at least one rank ({err!r}); collectives through torch.distributed"
                 dv = NativeDistributedVCycle(engine, layout, comm, collectives="torch")
     b = torch.from_numpy(U.rhs()).to(engine.dev)        # generated on the whole local domain
@@ -1003,11 +1099,7 @@ def bench_main(args, rank, world, local_rank, nPre, nPost, alpha):
                     p_, q_ = q_, p_
                 torch.cuda.synchronize()
                 outs.append(p_[layout.owned_slice(0)] if hasattr(layout, "owned_slice") else p_[torch.as_tensor(layout.owned_index(0), device=p_.device)])
-            same = torch.tensor([1 if torch.equal(outs[0], outs[1]) else 0], dtype=torch.int32,
-                                device=engine.dev if backend == "nccl" else "cpu")
-            if world > 1:
-                dist.all_reduce(same, op=dist.ReduceOp.MIN)
-            if int(same.item()) == 1:
+            if comm.min_int(1 if torch.equal(outs[0], outs[1]) else 0, engine.dev) == 1:
                 selfcheck = "owned values after two cycles bitwise equal to the torch.distributed-routed schedule"
                 dv_t.free()
             else:
@@ -1062,7 +1154,9 @@ def bench_main(args, rank, world, local_rank, nPre, nPost, alpha):
         lm = bytes_model[dlevel]
         per_launch = {"fused_down": nPre * lm['sweep'] + lm['residual'] + lm['restrict'],
                       "fused_up": nPost * lm['sweep'] + lm['prolong']}[dkind]
-        achieved = per_launch / (dms / dcnt * 1e-3) / 1e9
+        kd = {"fused_down": "down", "fused_up": "up"}[dkind]
+        comp = sum(engine.H.launch_bytes(dlevel, kd))       # compulsory bytes of rank 0's launch: every array once, as stored
+        achieved = comp / (dms / dcnt * 1e-3) / 1e9
         out = {
             "metric": "fine_level_dof_updates_per_s_per_vcycle",
             "value": N * (nPre + nPost) * args.steps / dt,
@@ -1091,10 +1185,16 @@ def bench_main(args, rank, world, local_rank, nPre, nPost, alpha):
             "roofline": {"bound": "hbm", "kernel": (f"cgt_fused_kernel<4> {dkind} level {dlevel + 1} (rank 0)" if cfg5 else
                                                     f"btd_fused_kernel<{args.p + 1},cmp> {dkind} level {dlevel + 1} (rank 0)"),
                          "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                         "frac_basis": "algorithmic", "traffic": None, "algorithmic_bytes_per_launch": per_launch,
+                         "frac_basis": "compulsory bytes (arrays of the launch, each once) / HIP-event time / peak",
+                         "traffic": None, "compulsory_bytes_per_launch": comp,
+                         "frac_survey_model": per_launch / (dms / dcnt * 1e-3) / 1e9 / 8000.0, "survey_model_bytes_per_launch": per_launch,
                          "ms_per_launch": dms / dcnt, "launches_timed": dcnt},
             "kernels": {f"{k}_L{l}": {"ms_per_launch": v[0] / v[1], "launches": v[1]} for (k, l), v in sorted(prof.items())},
             "setup_s": t_setup,
         }
+        if group is not None:
+            out["rehearsal"] = (f"{world} ranks as threads of ONE process on one GPU (host-staged collectives through shared "
+                                "memory): exercises the N-rank code path, NOT a multi-GPU measurement")
         print(json.dumps(out), flush=True)
-    dist.destroy_process_group()
+    if group is None:
+        dist.destroy_process_group()

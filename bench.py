@@ -71,6 +71,10 @@ def parse():
     ap.add_argument("--dist-smoother", default="jac", choices=("jac", "addSchwarz", "hybridSchwarz", "blockGS"),
                     help="N > 1, --dist-config 5 only: the CG levels' smoother (cg_smoother's kinds; blockGS = the labelled "
                          "red-black element Gauss-Seidel extension BASELINE config 5 names)")
+    ap.add_argument("--rehearse-threads", action="store_true",
+                    help="N > 1 on a box with fewer GPUs (or GPU process slots) than ranks: run the N ranks as THREADS of this one "
+                         "process on GPU 0 (host-staged collectives through shared memory) -- the N-rank code path end to end, "
+                         "one JSON line with n_gpus N and a `rehearsal` note; not a measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-smoother-bench", action="store_true")
     return ap.parse_args()
@@ -563,6 +567,27 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     nPre = nPost = 3
     alpha = 2.0 / 3.0
+    if args.gpus > 1 and args.rehearse_threads:
+        import threading
+        from agglomerationmultigrid1d_amd import distributed as dist_mg
+        group = dist_mg.ThreadGroup(args.gpus)
+        errs = []
+
+        def one(r):
+            try:
+                dist_mg.bench_main(args, r, args.gpus, 0, nPre, nPost, alpha, group=group)
+            except BaseException as exc:      # a rank that dies must not leave the others in a barrier
+                errs.append((r, exc))
+                group.barrier.abort()
+
+        ts = [threading.Thread(target=one, args=(r,)) for r in range(args.gpus)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        if errs:
+            raise SystemExit(f"rehearsal failed on ranks {[r for r, _ in errs]}: {errs[0][1]!r}")
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # bare `python bench.py --gpus N`: start the ranks ourselves, one process per GPU, as a CHILD
         # torch.distributed.run (this process has not touched HIP and never will; no exec), relay rank 0's

@@ -354,7 +354,11 @@ int aggmg_dist_free(aggmg_ctx* ctx, aggmg_dist* d);
  *    interface exchange issued under the fine-level ascent -- a communicator of its own: operations of one
  *    communicator in flight on two streams may start in a different order on different ranks and wait for each other.
  *  - a caller-supplied all-gather: recv_dev[r * count + i] = rank r's send_dev[i], ordered on hip_stream
- *    after everything enqueued there so far; returns 0 on success.
+ *    after everything enqueued there so far; returns 0 on success.  ALIASING: the chunk-boundary system is gathered
+ *    IN PLACE -- send_dev == recv_dev + rank * count (the caller's own slice of the receive buffer, already in its
+ *    final position) -- and the callback has to treat that as an in-place all-gather (ncclAllGather does by
+ *    definition; MPI needs MPI_IN_PLACE; a copy-based implementation must not clobber or re-copy that slice).  The
+ *    other gathers pass disjoint buffers.
  *  - a device-local loop-back (every slot receives the caller's own data): rehearsals of one rank's
  *    share on a single GPU, measurement only. */
 #define AGGMG_RCCL_ID_BYTES 128

@@ -171,3 +171,86 @@ def test_overlapped_interface_exchange_bookkeeping():
         assert e1 < 1e-12 and e2 < 1e-12, (rank, e1, e2)
         # replicated coarsest solve at this size: (x0 + rhs gather + prefetch) + (rhs gather + prefetch)
         assert n2 == 5 and n3 == 7
+
+
+def _thread_ranks(world, fn):
+    """run fn(rank, comm) on `world` ThreadComm ranks (threads of this process); -> list of results by rank"""
+    import threading
+    from agglomerationmultigrid1d_amd import distributed as D
+    g = D.ThreadGroup(world)
+    out, errs = [None] * world, []
+
+    def one(r):
+        try:
+            out[r] = fn(r, D.ThreadComm(g, r))
+        except BaseException as exc:
+            errs.append((r, exc))
+            g.barrier.abort()
+
+    ts = [threading.Thread(target=one, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(600)
+    assert not errs, errs
+    return out
+
+
+@pytest.mark.parametrize("world,n,p,ratios", [(8, 2048, 3, (4, 2, 2)), (8, 1024, 2, (2, 2)), (6, 6 * 256, 3, (4, 2, 2))])
+def test_eight_ranks_as_threads_match_single_domain(world, n, p, ratios):
+    """the partition at the north-star world size (8 ranks: first / last rank one-sided, six interior ranks with two
+    neighbours) with the Python schedule and the oracle's arithmetic, ranks as threads over ThreadComm: owned values equal
+    the single-domain oracle V-cycle to the last bits"""
+    sys.path[:0] = [os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]
+    import aggmg_oracle as o
+    from dist_helpers import LocalRef, NumpyEngine
+    from agglomerationmultigrid1d_amd import distributed as D
+    from agglomerationmultigrid1d_amd.uniform import UniformDgAggHierarchy
+    Ug = UniformDgAggHierarchy(n, p=p, pAgg=1, ratios=ratios)
+    x0g = o.splitmix_normal(n * (p + 1), 7)
+    xr = o.multigrid_v_cycle(LocalRef(o, Ug), x0g, Ug.rhs(), nPre=3, nPost=3, alpha=2.0 / 3.0)
+    Ac = Ug.stiffness_csc(Ug.nlevels - 1)
+
+    def rank_fn(rank, comm):
+        layout = D.RankLayout(n, ratios, [p + 1] + [2] * len(ratios), world, rank, 3, 3)
+        U = UniformDgAggHierarchy(n, p=p, pAgg=1, ratios=ratios, elem_range=layout.loc[0])
+        dv = D.DistributedVCycle(NumpyEngine(o, LocalRef(o, U), Ac), layout, comm)
+        lo, hi = layout.loc[0]
+        x0 = torch.from_numpy(x0g[lo * (p + 1):hi * (p + 1)].copy())
+        out = torch.zeros(layout.local_dofs(0), dtype=torch.float64)
+        dv.vcycle(x0, torch.from_numpy(U.rhs().copy()), out, 3, 3, 2.0 / 3.0)
+        a, b_ = layout.own[0]
+        ref = xr[a * (p + 1):b_ * (p + 1)]
+        return float(np.max(np.abs(out.numpy()[layout.owned_slice(0)] - ref)) / np.max(np.abs(ref)))
+
+    errs = _thread_ranks(world, rank_fn)
+    assert max(errs) < 1e-14, errs
+
+
+def test_thread_comm_collectives():
+    """ThreadComm's own pieces: all_gather, max / min, matched neighbour messages in issue order"""
+    def rank_fn(rank, comm):
+        w = comm.world
+        out = torch.empty(3 * w, dtype=torch.float64)
+        comm.all_gather(out, torch.full((3,), float(rank), dtype=torch.float64))
+        assert out.tolist() == [float(r) for r in range(w) for _ in range(3)]
+        assert comm.max(rank) == w - 1 and comm.min_int(rank + 5) == 5
+        assert np.array_equal(comm.host_all_gather(np.array([rank, -rank], dtype=float)),
+                              np.array([v for r in range(w) for v in (r, -r)], dtype=float))
+        ops, bufs = [], []
+        for peer in (rank - 1, rank + 1):
+            if 0 <= peer < w:
+                for k in range(2):      # two messages per neighbour and direction: matched in order
+                    ops.append((peer, True, 2)); bufs.append(np.array([rank, k], dtype=float))
+                    ops.append((peer, False, 2)); bufs.append(np.empty(2))
+        comm.host_sendrecv(ops, bufs)
+        seen = {}
+        for (peer, snd, _), t in zip(ops, bufs):
+            if not snd:
+                k = seen.get(peer, 0)
+                seen[peer] = k + 1
+                assert t.tolist() == [float(peer), float(k)]
+        comm.barrier()
+        return True
+
+    assert all(_thread_ranks(8, rank_fn))

@@ -447,3 +447,151 @@ def test_bench_two_ranks_under_torch_distributed_run(dist_config, launcher, smoo
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "strong"
     assert d["metric"] == "fine_level_dof_updates_per_s_per_vcycle" and d["value"] > 0 and d["vs_baseline"] is None
     assert d["config"]["backend"] == "gloo" and "roofline" in d
+
+
+def _thread_ranks(world, fn):
+    """fn(rank, comm) on `world` ThreadComm ranks: threads of THIS process, each with its own library context on GPU 0
+    (the box admits six GPU processes; the north-star job has eight ranks)"""
+    import threading
+    from agglomerationmultigrid1d_amd import distributed as D
+    g = D.ThreadGroup(world)
+    out, errs = [None] * world, []
+
+    def one(r):
+        try:
+            out[r] = fn(r, D.ThreadComm(g, r))
+        except BaseException as exc:
+            import traceback
+            errs.append((r, traceback.format_exc()))
+            g.barrier.abort()
+
+    ts = [threading.Thread(target=one, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(900)
+    assert not errs, errs[0][1]
+    return out
+
+
+@pytest.mark.parametrize("n,chunk_log2", [(2**16, None), (2**19, None), (2**16, 0)])
+def test_eight_ranks_config4_match_single_gpu(n, chunk_log2, monkeypatch):
+    """BASELINE config 4 at the north-star world size: the config-3 hierarchy element-partitioned over EIGHT ranks (threads
+    of one process sharing the GPU, the library's C++ schedule with host-staged collectives): first / last rank one-sided,
+    six interior ranks with two neighbours, chunk-interleaved boundary system gathered from eight ranks.  Owned values after
+    three cycles are bitwise those of the single-GPU cycle.  2^16 and 2^19 fine elements: 2^12 / 2^15 coarsest blocks, chunked
+    elimination with the default chunk size of a partitioned run; AGGMG_DIST_COARSE_CHUNK_LOG2 = 0 asks for the smallest
+    chunks the planner makes (two blocks): a gathered boundary system of thousands of rows through the register-blocked
+    tail."""
+    import torch
+    import agglomerationmultigrid1d_amd as mg
+    from agglomerationmultigrid1d_amd import distributed as D
+    from agglomerationmultigrid1d_amd.uniform import UniformDgAggHierarchy, build_device_hierarchy
+    if chunk_log2 is not None:
+        monkeypatch.setenv("AGGMG_DIST_COARSE_CHUNK_LOG2", str(chunk_log2))
+    world, ratios, p = 8, (4, 2, 2), 3
+    Ug = UniformDgAggHierarchy(n, p=p, pAgg=1, ratios=ratios)
+    ctx2 = mg.Context(0)
+    Hg = build_device_hierarchy(Ug, ctx2)
+    bg = ctx2.to_device(Ug.rhs())
+    xa, xb = ctx2.to_device(np.zeros(len(Ug.rhs()))), ctx2.alloc(len(Ug.rhs()))
+    for _ in range(3):
+        Hg.vcycle_dev(xa, bg, xb)
+        xa, xb = xb, xa
+    ref = xa.download()
+    Hg.free()
+
+    def rank_fn(rank, comm):
+        ctx = mg.Context(0)
+        layout = D.RankLayout(n, ratios, [p + 1, 2, 2, 2], world, rank)
+        engine, U = D.build_local_uniform(n, p, 1, ratios, layout, ctx, comm)
+        assert all(engine.H.structured_levels()) and engine.Hc.coarse_info()['on_device']
+        dv = D.NativeDistributedVCycle(engine, layout, comm, collectives="torch")
+        b = torch.from_numpy(U.rhs()).to(engine.dev)
+        x, y = engine.new(layout.local_dofs(0)), engine.new(layout.local_dofs(0))
+        for _ in range(3):
+            dv.vcycle(x, b, y, overlap_next=True)
+            x, y = y, x
+        torch.cuda.synchronize()
+        got = x.cpu().numpy()[layout.owned_slice(0)]
+        lo, hi = layout.own[0]
+        ref_own = ref[lo * (p + 1):hi * (p + 1)]
+        res = (float(np.max(np.abs(got - ref_own))), float(np.max(np.abs(ref_own))), dv.chunked, dv.exchanges)
+        comm.barrier()
+        dv.free()
+        return res
+
+    res = _thread_ranks(world, rank_fn)
+    for rank, (err, scale, chunked, nex) in enumerate(res):
+        assert chunked, rank                                    # 4096 coarsest blocks and more: every rank eliminates its own chunks
+        if chunk_log2 is None:
+            assert err == 0.0, (rank, err, scale)
+        else:       # the reference run plans its own chunks and tail: equal to the accuracy of the coarsest solves
+            assert err <= 1e-9 * scale, (rank, err, scale)
+
+
+@pytest.mark.parametrize("n,smoother", [(2**14, "jac"), (2**14, "blockGS")])
+def test_eight_ranks_config5_match_single_gpu(n, smoother):
+    """BASELINE config 5's shape (CG p = 4 -> 2 -> 1 -> DG p = 0) over EIGHT ranks (threads sharing the GPU): point-Jacobi
+    and the block-GS extension config 5 names, owned vertices and interior nodes bitwise those of the single-GPU cycle"""
+    import torch
+    import agglomerationmultigrid1d_amd as mg
+    from agglomerationmultigrid1d_amd import distributed as D
+    from agglomerationmultigrid1d_amd.uniform import UniformCgDgHierarchy, build_device_cg_hierarchy
+    world, ps = 8, (4, 2, 1)
+    alpha = 1.0 if smoother == "blockGS" else 2.0 / 3.0
+    Ug = UniformCgDgHierarchy(n, ps=ps)
+    ctx2 = mg.Context(0)
+    Hg = build_device_cg_hierarchy(Ug, ctx2, smoother=smoother)
+    N = len(Ug.rhs())
+    bg = ctx2.to_device(Ug.rhs())
+    xa, xb = ctx2.to_device(np.zeros(N)), ctx2.alloc(N)
+    for _ in range(3):
+        Hg.vcycle_dev(xa, bg, xb, 3, 3, alpha)
+        xa, xb = xb, xa
+    ref = xa.download()
+    Hg.free()
+
+    def rank_fn(rank, comm):
+        ctx = mg.Context(0)
+        layout = D.CgRankLayout(n, ps, world, rank, 3, 3, smoother=smoother)
+        engine, U = D.build_local_cg(n, ps, layout, ctx, comm)
+        assert engine.H.level_kinds() == ['fused_chain'] * len(ps) + ['coarsest']
+        dv = D.NativeDistributedVCycle(engine, layout, comm, collectives="torch")
+        b = torch.from_numpy(U.rhs()).to(engine.dev)
+        x, y = engine.new(layout.local_dofs(0)), engine.new(layout.local_dofs(0))
+        for _ in range(3):
+            dv.vcycle(x, b, y, 3, 3, alpha, overlap_next=True)
+            x, y = y, x
+        torch.cuda.synchronize()
+        got = x.cpu().numpy()[layout.owned_index(0)]
+        want = ref[layout.global_index(0)]
+        comm.barrier()
+        dv.free()
+        return float(np.max(np.abs(got - want))), float(np.max(np.abs(want)))
+
+    for rank, (err, scale) in enumerate(_thread_ranks(world, rank_fn)):
+        assert err == 0.0, (rank, err, scale)
+
+
+@pytest.mark.parametrize("dist_config", [4, 5])
+def test_bench_eight_ranks_rehearsal(dist_config):
+    """`python bench.py --gpus 8 --rehearse-threads`: bench_main's N-rank code path end to end with eight ranks (threads of
+    one process on this box's GPU) -- rank-local generators, library set-up, partitioned cycles, max-over-ranks timing, ONE
+    JSON line from rank 0 with n_gpus 8.  (The driver's `python -m torch.distributed.run --nproc-per-node 8 bench.py --gpus 8`
+    differs in the process group only: tested with two processes in test_bench_two_ranks_under_torch_distributed_run.)"""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--rehearse-threads", "--steps", "3", "--warmup", "1",
+           "--log2-elems", "18", "--cg-log2-elems", "16", "--dist-config", str(dist_config)]
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["steps"] == 3 and d["scaling"] == "strong" and d["value"] > 0
+    assert d["config"]["backend"] == "threads" and "rehearsal" in d and d["roofline"]["frac"] <= 1.0

@@ -59,6 +59,7 @@ CASES = [
     (513, 8, 0),                                                                                      # small stage
     (1 << 15, 1, 0), ((1 << 15) + 3, 2, 0), ((1 << 16) - 1, 1, 0), (40000, 3, 2), (33000, 4, 0),      # stage + stack
     ((1 << 17) + 5, 6, 0), (1 << 18, 2, 0), ((1 << 20) + 1, 1, 0), (1 << 21, 1, 0),                   # > 1 sub-chunk per thread
+    (1 << 16, 8, 0), (1 << 20, 5, 0),     # 2^20 blocks of 5: chunks capped at 2^11 blocks by the CU's LDS (2^12 would ask for 164 KB)
 ]
 
 
