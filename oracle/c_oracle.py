@@ -84,6 +84,7 @@ class COracleHierarchy:
         if st != 0:
             raise np.linalg.LinAlgError("coarsest operator singular / out of memory")
         self.N = [M.shape[0] for M in stiffness]
+        self.block_sizes = [int(m) for m in block_sizes]
         self.work = np.zeros(5 * sum(self.N))
 
     def _csc(self, M):
