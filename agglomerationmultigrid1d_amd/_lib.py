@@ -17,6 +17,7 @@ OP_STIFFNESS, OP_TRANSFER = 0, 1
 OPT_SYMMETRIC_PACKING = 1
 OPT_COARSE_CHUNK_LOG2 = 2
 OPT_DETECT_CHAIN = 3
+OPT_PAIR_LEVELS = 4
 PROFILE_NTAGS = 256
 KIND_FUSED_DOWN, KIND_FUSED_UP, KIND_SMOOTH, KIND_RESIDUAL, KIND_RESTRICT, KIND_PROLONG, \
     KIND_JACOBI, KIND_BLOCK_APPLY, KIND_COARSE, KIND_FUSED_MID = range(10)
@@ -131,6 +132,7 @@ SYMBOLS = {
     "aggmg_coarse_boundary_solve_dev": (c_int, [_P, _P, _P, _P, _P]),
     "aggmg_coarse_chunk_backward_dev": (c_int, [_P, _P, _P, c_int64, c_int64, _P, _P]),
     "aggmg_hier_level_kind": (c_int, [_P, _P, c_int, POINTER(c_int)]),
+    "aggmg_hier_level_paired": (c_int, [_P, _P, c_int, c_int, POINTER(c_int)]),
     "aggmg_hier_launch_bytes": (c_int, [_P, _P, c_int, c_int, c_int, POINTER(c_int64), POINTER(c_int64)]),
     "aggmg_smoother_launch_bytes": (c_int, [_P, _P, _P, c_int, POINTER(c_int64), POINTER(c_int64)]),
     "aggmg_hier_coarse_info": (c_int, [_P, _P, POINTER(c_int), POINTER(c_int), POINTER(c_double)]),

@@ -782,6 +782,16 @@ class MeshHierarchy:
             out.append(_lib.LEVEL_KIND_NAMES[v.value])
         return out
 
+    def paired_levels(self, nsweeps=3):
+        """levels k whose launch also carries level k + 1 (C ABI aggmg_hier_level_paired)"""
+        out = []
+        for k in range(self.nlevels - 1):
+            v = ctypes.c_int(0)
+            self.ctx.check(self.ctx.lib.aggmg_hier_level_paired(self.ctx.handle, self.handle, k, int(nsweeps), ctypes.byref(v)))
+            if v.value:
+                out.append(k)
+        return out
+
     def launch_bytes(self, level, kind, has_x0=None):
         """(read, write) compulsory HBM bytes of the fused launch of `level`: kind 'down' / 'up' / 'mid'
         (C ABI aggmg_hier_launch_bytes) -- every array of the launch counted once, as stored."""

@@ -6,6 +6,7 @@
 // the CG chain path: cgt.hip; element-partitioned runs: dist.hip; sparse set-up products: spops.hip.
 // No CPU compute fallback exists: every hot-path entry point launches HIP kernels or fails.
 #include "internal.hpp"
+#include "pair_kernels.hpp"
 
 // ---------------------------------------------------------------------------------------------
 // context
@@ -92,6 +93,9 @@ extern "C" int aggmg_set_option(aggmg_ctx* ctx, int option, int value) {
       return AGGMG_OK;
     case AGGMG_OPT_DETECT_CHAIN:
       ctx->detect_chain = value != 0;
+      return AGGMG_OK;
+    case AGGMG_OPT_PAIR_LEVELS:
+      ctx->pair_levels = value != 0;
       return AGGMG_OK;
   }
   return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_set_option: unknown option");
@@ -1364,6 +1368,108 @@ static int coarse_solve(aggmg_ctx* ctx, aggmg_hier* h, const double* rhs_dev, do
   return AGGMG_OK;
 }
 
+// ---- two levels in one launch (pair_kernels.hpp): the small agglomerated levels ------------------------------
+constexpr int kPairM = 2, kPairNSA = 4, kPairNSB = 2;
+constexpr int kPairTEA = (kThreads / kPairM) * kPairNSA, kPairTEB = (kThreads / 2) * kPairNSB;
+
+static bool pair_level_ok(const Level& l) {
+  return l.S && l.S->btd && l.S->A == l.A && l.tb && !l.S->gs && !l.S->btd->cmp && l.S->btd->m == kPairM && l.S->btd->bsym &&
+         l.tb->mc == 2 && l.tb->rho > 0 && l.S->btd->ne == (int64_t)l.tb->rho * l.tb->nec;
+}
+
+// levels k and k + 1 (both smoothed, both below the finest: their iterates start at zero on the way down)
+static bool pair_ok(const aggmg_ctx* ctx, const aggmg_hier* h, int k, int nsweeps) {
+  const int n = (int)h->lv.size();
+  if (!ctx->pair_levels || k < 1 || k + 2 > n - 1 || nsweeps < 1 || nsweeps > 8) return false;
+  const Level& a = h->lv[k];
+  const Level& b = h->lv[k + 1];
+  if (!pair_level_ok(a) || !pair_level_ok(b) || b.S->btd->ne != a.tb->nec) return false;
+  if (h->restriction == AGGMG_RESTRICT_PRECONDITIONED && (a.tb->ld || b.tb->ld)) return false;
+  return true;
+}
+
+static PairArgs pair_args(const aggmg_hier* h, int k, double alpha, int nsweeps) {
+  const Level& a = h->lv[k];
+  const Level& b = h->lv[k + 1];
+  PairArgs p;
+  std::memset(&p, 0, sizeof(p));
+  auto lev = [](const BtdDev& d) { return PairLevel{d.bsym, d.dblk, d.sub, d.sup, d.ne}; };
+  auto xf = [](const TransferBtd& t) { return PairXfer{t.lf, t.lf1, t.rho, t.nec}; };
+  p.A = lev(*a.S->btd);
+  p.B = lev(*b.S->btd);
+  p.ab = xf(*a.tb);
+  p.bc = xf(*b.tb);
+  p.alpha = alpha;
+  p.nsweeps = nsweeps;
+  return p;
+}
+
+static int launch_pair_down(aggmg_ctx* ctx, aggmg_hier* h, int k, int nPre, double alpha) {
+  Level& a = h->lv[k];
+  Level& b = h->lv[k + 1];
+  Level& c = h->lv[k + 2];
+  PairArgs p = pair_args(h, k, alpha, nPre);
+  const int hh = nPre + 1;
+  int te_b = std::min(kPairTEB, (kPairTEA - 2 * hh) / p.ab.rho);
+  const int own = ((te_b - 2 * hh) / p.bc.rho) * p.bc.rho;
+  if (own <= 0) return fail(ctx, AGGMG_ERR_UNSUPPORTED, "internal: paired tile too small");
+  te_b = own + 2 * hh;
+  p.own = own;
+  p.te_b = te_b;
+  p.te_a = te_b * p.ab.rho + 2 * hh;
+  p.rhs_a = a.rhs;
+  p.u_a = a.u[0];
+  p.rhs_b = b.rhs;
+  p.u_b = b.u[0];
+  p.rhs_c = c.rhs;
+  const int64_t ntiles = (p.B.ne + own - 1) / own;
+  if (ntiles == 0) return AGGMG_OK;
+  const size_t lds = ((size_t)2 * (kPairTEA + 2) * kPairM + (size_t)kPairTEB * 2) * sizeof(double);
+  ProfScope ps(ctx, AGGMG_KIND_FUSED_DOWN, k);
+  hipLaunchKernelGGL((btd_pair_down_kernel<kPairM, kPairNSA, kPairNSB, kThreads>), dim3((unsigned)ntiles), dim3(kThreads), lds,
+                     ctx->stream, p);
+  HIPCHK(hipGetLastError());
+  return AGGMG_OK;
+}
+
+// levels k + 1 then k; the result of level k goes to dst, the post-smoothed level k + 1 is consumed in LDS
+static int launch_pair_up(aggmg_ctx* ctx, aggmg_hier* h, int k, int nPost, double alpha, double* dst) {
+  const int n = (int)h->lv.size();
+  Level& a = h->lv[k];
+  Level& b = h->lv[k + 1];
+  Level& c = h->lv[k + 2];
+  PairArgs p = pair_args(h, k, alpha, nPost);
+  const int rhoA = p.ab.rho;
+  p.hb = (nPost + rhoA - 1) / rhoA;
+  int own = std::min(kPairTEA - 2 * nPost, (kPairTEB - 2 * p.hb - 2 * nPost) * rhoA);
+  own = (own / rhoA) * rhoA;
+  if (own <= 0) return fail(ctx, AGGMG_ERR_UNSUPPORTED, "internal: paired tile too small");
+  p.own = own;
+  p.te_a = own + 2 * nPost;
+  p.te_b = own / rhoA + 2 * p.hb + 2 * nPost;
+  p.rhs_a = a.rhs;
+  p.rhs_b_in = b.rhs;
+  p.ua_in = a.u[0];
+  p.ub_in = b.u[0];
+  p.uc = (k + 2 == n - 1) ? c.u[0] : c.u[1];
+  p.u_a = dst;
+  p.ub_out = nullptr;   // nothing reads the post-smoothed iterate of level k + 1 but level k's prolongation
+  const int64_t ntiles = (p.A.ne + own - 1) / own;
+  if (ntiles == 0) return AGGMG_OK;
+  const size_t lds = ((size_t)2 * (kPairTEA + 2) * kPairM + (size_t)kPairTEB * 2) * sizeof(double);
+  ProfScope ps(ctx, AGGMG_KIND_FUSED_UP, k);
+  hipLaunchKernelGGL((btd_pair_up_kernel<kPairM, kPairNSA, kPairNSB, kThreads>), dim3((unsigned)ntiles), dim3(kThreads), lds,
+                     ctx->stream, p);
+  HIPCHK(hipGetLastError());
+  return AGGMG_OK;
+}
+
+extern "C" int aggmg_hier_level_paired(aggmg_ctx* ctx, const aggmg_hier* h, int level, int nsweeps, int* paired) {
+  if (!ctx || !h || !paired) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_hier_level_paired: NULL argument");
+  *paired = pair_ok(ctx, h, level, nsweeps) ? 1 : 0;
+  return AGGMG_OK;
+}
+
 // ---- descend (src/solvers.jl:28-37): leaves u[k] in lv[k].u[0] and rhs[n] in lv[n-1].rhs ----------
 static int vcycle_down(aggmg_ctx* ctx, aggmg_hier* h, const double* x0, const double* b, int nPre, double alpha,
                        int k_first = 0) {
@@ -1375,6 +1481,11 @@ static int vcycle_down(aggmg_ctx* ctx, aggmg_hier* h, const double* x0, const do
     const double* uin = k == 0 ? x0 : nullptr;  // u[k] = zeros for k > 1 (:29-31)
     if (l.cgt_fused) {
       CHECK(cgt_down(ctx, h, k, uin, rhs, nPre, alpha));
+      continue;
+    }
+    if (pair_ok(ctx, h, k, nPre)) {   // this level and the next in one launch
+      CHECK(launch_pair_down(ctx, h, k, nPre, alpha));
+      ++k;
       continue;
     }
     const bool structured = l.S->btd && l.S->A == l.A;
@@ -1443,6 +1554,11 @@ static int vcycle_up(aggmg_ctx* ctx, aggmg_hier* h, const double* b, int nPost, 
     const double* rhs = k == 0 ? b : l.rhs;
     double* dst = k == 0 ? x_out : l.u[1];
     const double* uc = (k + 1 == n - 1) ? c.u[0] : c.u[1];
+    if (sel.mode == 0 && k - 1 >= std::max(k_last, 1) && pair_ok(ctx, h, k - 1, nPost)) {   // this level and the finer one in one launch
+      CHECK(launch_pair_up(ctx, h, k - 1, nPost, alpha, h->lv[k - 1].u[1]));
+      --k;
+      continue;
+    }
     if (l.cgt_fused) {
       if (k == 0 && sel.mode != 0)
         return fail(ctx, AGGMG_ERR_UNSUPPORTED, "split ascent needs the fused block-tridiagonal fine level");

@@ -72,6 +72,10 @@ int aggmg_synchronize(aggmg_ctx* ctx);
  * exactly as if aggmg_jacobi_setup_elements had been given the mesh's lists (same smoother, same results: the check
  * is on the entries, set-up time only).  0: operators without lists always take the generic CSR kernels. */
 #define AGGMG_OPT_DETECT_CHAIN 3
+/* AGGMG_OPT_PAIR_LEVELS (default 1; environment AGGMG_PAIR=0 makes the default 0): aggmg_vcycle_dev runs two small
+ * agglomerated levels per launch where it can (aggmg_hier_level_paired) -- same results bit for bit; 0 keeps one
+ * launch per level (A/B timing, tests). */
+#define AGGMG_OPT_PAIR_LEVELS 4
 int aggmg_set_option(aggmg_ctx* ctx, int option, int value);
 /* Raw device memory owned by the context's device (plumbing for harnesses without torch, and the storage of the
  * Julia shim's DeviceVector).  aggmg_dev_alloc returns ZEROED memory: a fresh vector is the zero initial guess of
@@ -299,6 +303,12 @@ int aggmg_coarse_chunk_backward_dev(aggmg_ctx* ctx, aggmg_hier* h, const double*
 #define AGGMG_LEVEL_FUSED_CHAIN 2
 #define AGGMG_LEVEL_COARSEST 3
 int aggmg_hier_level_kind(aggmg_ctx* ctx, const aggmg_hier* h, int level, int* kind);
+/* Whether aggmg_vcycle_dev runs levels `level` and `level + 1` in ONE launch each way (nsweeps sweeps per level):
+ * small agglomerated levels -- block size 2, dense off-diagonal blocks, one agglomeration ratio per level -- below
+ * the finest one, both halves of src/solvers.jl:28-37 / :41-47 for two levels with the hand-over in LDS; bit for bit
+ * the separate launches.  The launch is then attributed to `level` (profile tags, aggmg_hier_launch_bytes of both
+ * levels apply).  AGGMG_OPT_PAIR_LEVELS switches the pairing off. */
+int aggmg_hier_level_paired(aggmg_ctx* ctx, const aggmg_hier* h, int level, int nsweeps, int* paired);
 /* Which coarsest solver a hierarchy uses: on_device (1 = cyclic reduction), its block size and the
  * largest pivot-block condition estimate met while factoring (0 for the host solver). */
 int aggmg_hier_coarse_info(aggmg_ctx* ctx, const aggmg_hier* h, int* on_device, int* block_size,

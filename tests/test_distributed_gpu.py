@@ -474,14 +474,14 @@ def _thread_ranks(world, fn):
     return out
 
 
-@pytest.mark.parametrize("n,chunk_log2", [(2**16, None), (2**19, None), (2**16, 0)])
+@pytest.mark.parametrize("n,chunk_log2", [(2**16, None), (2**19, None), (2**16, 1)])
 def test_eight_ranks_config4_match_single_gpu(n, chunk_log2, monkeypatch):
     """BASELINE config 4 at the north-star world size: the config-3 hierarchy element-partitioned over EIGHT ranks (threads
     of one process sharing the GPU, the library's C++ schedule with host-staged collectives): first / last rank one-sided,
     six interior ranks with two neighbours, chunk-interleaved boundary system gathered from eight ranks.  Owned values after
     three cycles are bitwise those of the single-GPU cycle.  2^16 and 2^19 fine elements: 2^12 / 2^15 coarsest blocks, chunked
-    elimination with the default chunk size of a partitioned run; AGGMG_DIST_COARSE_CHUNK_LOG2 = 0 asks for the smallest
-    chunks the planner makes (two blocks): a gathered boundary system of thousands of rows through the register-blocked
+    elimination with the default chunk size of a partitioned run; AGGMG_DIST_COARSE_CHUNK_LOG2 = 1: the smallest
+    chunks there are (two blocks): a gathered boundary system of thousands of rows through the register-blocked
     tail."""
     import torch
     import agglomerationmultigrid1d_amd as mg
