@@ -782,15 +782,29 @@ class MeshHierarchy:
             out.append(_lib.LEVEL_KIND_NAMES[v.value])
         return out
 
-    def paired_levels(self, nsweeps=3):
-        """levels k whose launch also carries level k + 1 (C ABI aggmg_hier_level_paired)"""
-        out = []
-        for k in range(self.nlevels - 1):
+    def paired_levels(self, nsweeps=3, direction="down"):
+        """levels k whose launch also carries level k + 1 (C ABI aggmg_hier_level_paired), as the descent walks the
+        hierarchy (pairs taken from the fine side) or, direction='up', as the ascent does (from the coarse side)"""
+        def ok(k):
             v = ctypes.c_int(0)
             self.ctx.check(self.ctx.lib.aggmg_hier_level_paired(self.ctx.handle, self.handle, k, int(nsweeps), ctypes.byref(v)))
-            if v.value:
-                out.append(k)
-        return out
+            return bool(v.value)
+        out = []
+        if direction == "down":
+            k = 0
+            while k < self.nlevels - 1:
+                if ok(k):
+                    out.append(k)
+                    k += 1
+                k += 1
+        else:
+            k = self.nlevels - 2
+            while k >= 1:
+                if ok(k - 1):
+                    out.append(k - 1)
+                    k -= 1
+                k -= 1
+        return sorted(out)
 
     def launch_bytes(self, level, kind, has_x0=None):
         """(read, write) compulsory HBM bytes of the fused launch of `level`: kind 'down' / 'up' / 'mid'

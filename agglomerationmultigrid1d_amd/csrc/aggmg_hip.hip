@@ -1369,7 +1369,13 @@ static int coarse_solve(aggmg_ctx* ctx, aggmg_hier* h, const double* rhs_dev, do
 }
 
 // ---- two levels in one launch (pair_kernels.hpp): the small agglomerated levels ------------------------------
-constexpr int kPairM = 2, kPairNSA = 4, kPairNSB = 2;
+#ifndef AGGMG_PAIR_NSA
+#define AGGMG_PAIR_NSA 2   // measured (tools/exp_pair_tiles.sh): 2 / 1 slabs 0.356 ms per cycle of a rank's share, 3 / 2: 0.362, 4 / 2: 0.371
+#endif
+#ifndef AGGMG_PAIR_NSB
+#define AGGMG_PAIR_NSB 1
+#endif
+constexpr int kPairM = 2, kPairNSA = AGGMG_PAIR_NSA, kPairNSB = AGGMG_PAIR_NSB;   // slabs per thread (tuning: tools/exp_pair_tiles.sh)
 constexpr int kPairTEA = (kThreads / kPairM) * kPairNSA, kPairTEB = (kThreads / 2) * kPairNSB;
 
 static bool pair_level_ok(const Level& l) {
@@ -2007,7 +2013,10 @@ static void btd_launch_bytes(const BtdDev& b, bool sweeps, bool u_in, bool resid
   if (sweeps || tin) w += N * D;                                             // iterate
   if (r_out) w += N * D;
   if (residual && tout) {
-    r += preconditioned ? N * tout->mc * D : (tout->lf1 ? N * D : N * tout->mc * D);
+    if (preconditioned)
+      r += N * tout->mc * D;                                                 // rows of (L'D)'
+    else if (tout != tin)
+      r += tout->lf1 ? N * D : N * tout->mc * D;                             // rows of L (once when the launch prolongs with them too)
     if (!tout->rho) r += ne * 4 + (tout->nec + 1) * 4;
     w += tout->nec * tout->mc * D;
   }
