@@ -352,6 +352,11 @@ extern "C" int aggmg_smoother_is_structured(aggmg_ctx* ctx, const aggmg_smoother
   return AGGMG_OK;
 }
 
+static int cr_env_int_early(const char* name, int dflt) {
+  const char* e = std::getenv(name);
+  return e && *e ? std::atoi(e) : dflt;
+}
+
 // ---------------------------------------------------------------------------------------------
 // launches
 // ---------------------------------------------------------------------------------------------
@@ -361,6 +366,14 @@ static int launch_csr(aggmg_ctx* ctx, const CsrDev& A, const double* x, const do
   if (A.nrows == 0) return AGGMG_OK;
   // (single passes stay on the stream kernel also for banded operators: measured on the config-2 matrix, the window
   // kernel's extra LDS and barrier make one sweep 121 us against 105 us; it pays from two sweeps per launch on)
+  // every row short: one thread per row, no LDS staging (AGGMG_CSR_ROWTHREAD=0: the stream kernel, A/B runs)
+  static const bool rowthread = cr_env_int_early("AGGMG_CSR_ROWTHREAD", 1) != 0;
+  if (rowthread && A.maxrow >= 0 && A.maxrow <= kRowThreadMax && A.nrows < ((int64_t)1 << 31) * kThreads) {
+    const unsigned nb = (unsigned)((A.nrows + kThreads - 1) / kThreads);
+    hipLaunchKernelGGL((csr_rowthread_kernel<MODE>), dim3(nb), dim3(kThreads), 0, ctx->stream, A.view(), x, b, dg, alpha, y);
+    HIPCHK(hipGetLastError());
+    return AGGMG_OK;
+  }
   if (A.rowblk) {
     hipLaunchKernelGGL((csr_stream_kernel<MODE>), dim3((unsigned)A.nblk), dim3(kThreads), 0, ctx->stream, A.view(),
                        (const int32_t*)A.rowblk, x, b, dg, alpha, y);
@@ -441,11 +454,6 @@ struct TileSel {
   int mode = 0;  // 0 all, 1 ends, 2 middle
   int64_t head = 0, tail = 0;
 };
-
-static int cr_env_int_early(const char* name, int dflt) {
-  const char* e = std::getenv(name);
-  return e && *e ? std::atoi(e) : dflt;
-}
 
 // the structured transfer of a level as the fused kernel's prolongation input / restriction output
 static void xfer_in(FusedArgs& a, const TransferBtd& t) {
@@ -626,12 +634,43 @@ static int generic_sweep(aggmg_ctx* ctx, aggmg_op* A, aggmg_smoother* sm, const 
     CHECK(op_ensure_csr(ctx, A));
     return launch_csr<kJacobi>(ctx, A->csr, u_in, rhs, sm->diag, alpha, u_out);
   }
+  CHECK(op_ensure_csr(ctx, A));
+  // (AGGMG_BLOCK_SWEEP=0: the earlier form -- CSR residual, zeroed vector, batched block apply with atomic adds where the
+  // lists overlap, update: four launches -- for A/B runs)
+  static const bool onepass = cr_env_int_early("AGGMG_BLOCK_SWEEP", 1) != 0;
+  if (onepass && A->csr.maxrow >= 0 && A->csr.maxrow <= 4 * kRowThreadMax && sm->m <= kThreads) {
+    // residual rows and block solves in ONE pass (block_sweep_kernel): the residual never reaches HBM
+    const int bpw = kThreads / (int)sm->m;
+    const unsigned nwg = (unsigned)((sm->nb + bpw - 1) / bpw);
+    const bool partition = !sm->overlapping && sm->nb * sm->m == N && sm->kind == 1;   // every row in exactly one block
+    ProfScope ps(ctx, AGGMG_KIND_BLOCK_APPLY, level);
+    if (partition && u_out != u_in) {
+      CHECK(setup_block_order(ctx, sm));
+      if (nwg)
+        hipLaunchKernelGGL((block_sweep_kernel<true>), dim3(nwg), dim3(kThreads), 0, ctx->stream, A->csr.view(), sm->binv, sm->inds,
+                           (int)sm->m, sm->nb, u_in, rhs, alpha, u_out);
+      HIPCHK(hipGetLastError());
+      return AGGMG_OK;
+    }
+    CHECK(setup_block_cover(ctx, sm));
+    double* Y = nullptr;
+    CHECK(scratch(ctx, 1, std::max<int64_t>(N, sm->nb * sm->m), &Y));
+    if (nwg)
+      hipLaunchKernelGGL((block_sweep_kernel<false>), dim3(nwg), dim3(kThreads), 0, ctx->stream, A->csr.view(), sm->binv, sm->inds,
+                         (int)sm->m, sm->nb, u_in, rhs, alpha, Y);
+    HIPCHK(hipGetLastError());
+    const unsigned nb2 = (unsigned)((N + kThreads - 1) / kThreads);
+    if (nb2)
+      hipLaunchKernelGGL(block_combine_kernel, dim3(nb2), dim3(kThreads), 0, ctx->stream, N, (const int32_t*)sm->cover_ptr,
+                         (const uint32_t*)sm->cover_idx, (const double*)Y, u_in, sm->kind == 2 ? sm->counts : nullptr, alpha, u_out);
+    HIPCHK(hipGetLastError());
+    return AGGMG_OK;
+  }
   double *r = nullptr, *y = nullptr;
   CHECK(scratch(ctx, 1, N, &r));
   CHECK(scratch(ctx, 2, N, &y));
   {
     ProfScope ps(ctx, AGGMG_KIND_RESIDUAL, level);
-    CHECK(op_ensure_csr(ctx, A));
     CHECK(launch_csr<kResidual>(ctx, A->csr, u_in, rhs, nullptr, 0.0, r));
   }
   ProfScope ps(ctx, AGGMG_KIND_BLOCK_APPLY, level);

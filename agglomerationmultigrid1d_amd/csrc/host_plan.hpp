@@ -122,6 +122,48 @@ inline bool cr_plan_solve(const std::vector<int64_t>& level_n, int m, int tail_r
   return true;
 }
 
+// ---- generic CSR kernels: row blocks -------------------------------------------------------------------------------
+// csr_stream_kernel: runs of consecutive rows holding at most max_nnz entries and at most max_rows rows; a row longer
+// than max_nnz stands alone (the kernel reduces it across the workgroup).  -> block boundaries, blocks + 1 entries
+inline std::vector<int32_t> stream_row_blocks(const int32_t* rowptr, int64_t nrows, int max_nnz, int max_rows) {
+  std::vector<int32_t> blk;
+  blk.push_back(0);
+  int64_t r = 0;
+  while (r < nrows) {
+    int64_t e = r + 1;  // a block always takes at least one row
+    const int64_t b0 = rowptr[r];
+    while (e < nrows && e - r < max_rows && rowptr[e + 1] - b0 <= max_nnz) ++e;
+    if (rowptr[r + 1] - b0 > max_nnz) e = r + 1;
+    blk.push_back((int32_t)e);
+    r = e;
+  }
+  return blk;
+}
+
+// csr_band_kernel (entries within bw of the diagonal, up to `sweeps` point-Jacobi sweeps per launch): a block's rows plus
+// (sweeps - 1) * bw halo rows on either side hold at most max_nnz entries, and its window of x -- the rows plus
+// sweeps * bw on either side -- fits `window` doubles.  -> false when some row is too long for its halo to fit
+inline bool band_row_blocks(const int32_t* rowptr, int64_t nrows, int bw, int sweeps, int max_nnz, int window, int max_rows,
+                            std::vector<int32_t>* out) {
+  const int64_t H = (int64_t)(sweeps - 1) * bw;
+  out->clear();
+  out->push_back(0);
+  int64_t r = 0;
+  while (r < nrows) {
+    const int64_t lo = std::max<int64_t>(0, r - H);
+    auto fits = [&](int64_t e) {
+      const int64_t hi = std::min(nrows, e + H);
+      return rowptr[hi] - rowptr[lo] <= max_nnz && (e - r) + 2 * (int64_t)sweeps * bw <= window;
+    };
+    int64_t e = r + 1;
+    if (!fits(e)) return false;
+    while (e < nrows && e - r < max_rows && fits(e + 1)) ++e;
+    out->push_back((int32_t)e);
+    r = e;
+  }
+  return true;
+}
+
 // ---- fused level launches: which tiles a launch runs ------------------------------------------------------------
 // A level of ne elements in tiles of `owned` elements.  mode 0: all tiles; 1: the tiles holding [0, head) and
 // [tail, ne) (element-partitioned runs produce the interface elements first); 2: the ones in between.

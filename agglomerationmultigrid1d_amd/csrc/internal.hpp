@@ -76,6 +76,7 @@ struct CsrDev {
   int32_t* bandblk = nullptr; // CSR-band row blocks (square, entries within bw of the diagonal), nbandblk + 1 entries
   int64_t nbandblk = 0;
   int bw = -1;                // band half-width, -1: not banded / not examined
+  int maxrow = -1;            // entries of the longest row (-1: not examined); <= kRowThreadMax: csr_rowthread_kernel
   CsrView view() const { return CsrView{rowptr, colind, vals, nrows}; }
 };
 
@@ -146,12 +147,17 @@ struct aggmg_smoother {
   double* counts = nullptr;    // hybrid Schwarz
   bool overlapping = false;
   bool contiguous = false;
+  // which (block, local row) entries cover each row, flat index block * m + i ascending inside a row: built on first use
+  // by the generic one-pass sweep (block_sweep_kernel + block_combine_kernel)
+  int32_t* cover_ptr = nullptr;   // [N + 1]
+  uint32_t* cover_idx = nullptr;  // [nb * m]
+  bool ordered = false;           // the blocks have been put in ascending order of their smallest index (one-pass sweep)
   bool gs = false;  // red-black block Gauss-Seidel (extension): needs the structured form
   std::shared_ptr<BtdDev> btd;  // structured fused form, or null
   std::shared_ptr<CgtDev> cgt;  // CG chain form (point Jacobi with the element lists), or null
   // owns its device arrays: every early return of a set-up routine releases what was uploaded
   ~aggmg_smoother() {
-    for (void* p : {(void*)diag, (void*)binv, (void*)inds, (void*)counts})
+    for (void* p : {(void*)diag, (void*)binv, (void*)inds, (void*)counts, (void*)cover_ptr, (void*)cover_idx})
       if (p) (void)hipFree(p);
   }
 };
@@ -391,6 +397,8 @@ int cgt_op_launch_bytes(const CgtDev& g, bool sweeps, int64_t* rd, int64_t* wr);
 int setup_csc_upload(aggmg_ctx* ctx, int64_t m, int64_t n, const int64_t* colptr, const int64_t* rowval,
                      const double* nzval, int one_based, CsrDev* out);
 int op_ensure_csr(aggmg_ctx* ctx, aggmg_op* op);         // row-gather CSR + its CSR-stream row blocks
+int setup_block_order(aggmg_ctx* ctx, aggmg_smoother* sm);   // blocks in ascending order of their smallest index, in place
+int setup_block_cover(aggmg_ctx* ctx, aggmg_smoother* sm);   // row -> covering (block, local row) entries, on the device
 int op_ensure_csc_blocks(aggmg_ctx* ctx, aggmg_op* op);  // CSR-stream row blocks of the transposed orientation
 int op_host_csr(aggmg_ctx* ctx, aggmg_op* op, HostCsr* h);
 int setup_jacobi_diag(aggmg_ctx* ctx, const aggmg_op* A, double** diag);

@@ -129,6 +129,49 @@ __global__ __launch_bounds__(kThreads) void csr_stream_kernel(CsrView A, const i
   }
 }
 
+// "CSR-row-thread" variant for matrices whose rows are ALL short (at most kRowThreadMax entries: DG / CG stiffness
+// matrices, transfers): one thread per row walks its entries in ascending column order -- products rounded, then added,
+// exactly the (product into LDS, sum from LDS) arithmetic of csr_stream_kernel and of SparseArrays' CSC scatter, so the
+// two kernels agree bit for bit.  No LDS, no barrier, no row-block table: consecutive threads read consecutive short
+// runs of the entry streams, every fetched line is used in full within a few iterations (from L1), four entries in
+// flight per thread.
+constexpr int kRowThreadMax = 32;
+template <int MODE>
+__global__ __launch_bounds__(kThreads) void csr_rowthread_kernel(CsrView A, const double* __restrict__ x,
+                                                                 const double* __restrict__ b,
+                                                                 const double* __restrict__ dg, double alpha,
+                                                                 double* __restrict__ y) {
+  const int64_t row = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (row >= A.nrows) return;
+  const int p0 = A.rowptr[row], p1 = A.rowptr[row + 1];
+  double acc = 0.0;
+  {
+#pragma clang fp contract(off)   // a product and its addition stay two roundings (the stream kernel's, the reference's)
+    int p = p0;
+    for (; p + 3 < p1; p += 4) {
+      const int c0 = A.colind[p], c1 = A.colind[p + 1], c2 = A.colind[p + 2], c3 = A.colind[p + 3];
+      const double v0 = A.vals[p], v1 = A.vals[p + 1], v2 = A.vals[p + 2], v3 = A.vals[p + 3];
+      const double t0 = v0 * x[c0], t1 = v1 * x[c1], t2 = v2 * x[c2], t3 = v3 * x[c3];
+      acc = acc + t0;
+      acc = acc + t1;
+      acc = acc + t2;
+      acc = acc + t3;
+    }
+    for (; p < p1; ++p) {
+      const double t = A.vals[p] * x[A.colind[p]];
+      acc = acc + t;
+    }
+  }
+  if (MODE == kSpmvSet) y[row] = acc;
+  if (MODE == kSpmvAdd) y[row] += acc;
+  if (MODE == kResidual) y[row] = b[row] - acc;
+  if (MODE == kJacobi) {
+    const double r = b[row] - acc;
+    const double yy = r / dg[row];
+    y[row] = x[row] + alpha * yy;
+  }
+}
+
 // "CSR-band" variant: the same streaming pattern for square operators whose entries all lie within `bw` of the
 // diagonal (every DG / agglomerated operator of the reference in its own numbering; detected on the device at
 // upload).  A workgroup owns a run of rows plus S * bw rows of halo on either side and
@@ -231,6 +274,81 @@ __global__ __launch_bounds__(kThreads) void block_apply_kernel(const double* __r
     atomicAdd(&y[id[i]], acc);
   else
     y[id[i]] = acc;
+}
+
+// One damped sweep of a block smoother on arbitrary index lists, u <- u + alpha * sum_k scatter(B_k^{-1} (b - A u)[inds_k])
+// (apply_smoother of BlockJacobi / AdditiveSchwarzSmoother / HybridSchwarzSmoother inside the sweep loop,
+// src/smoother.jl:6-46,69-81, src/solvers.jl:32-34), without the residual vector ever reaching HBM: a workgroup takes
+// kThreads / m whole blocks, thread (block, i) forms residual row inds[block][i] straight from the CSR (its entries in
+// ascending column order, product and sum rounded apart: csr_rowthread_kernel's arithmetic), the block's residual goes
+// through LDS, and the thread applies row i of the block inverse.
+//   DIRECT: the lists partition the rows (every row in exactly one block): out[row] = u[row] + alpha * y, one launch;
+//           out must not alias u (rows of other blocks are still being read).
+//   else:   Y[block * m + i] = y, and block_combine_kernel adds up the entries covering each row -- in list order, no
+//           atomics, no zeroing: the same bits run to run.
+template <bool DIRECT>
+__global__ __launch_bounds__(kThreads) void block_sweep_kernel(CsrView A, const double* __restrict__ binv,
+                                                               const int32_t* __restrict__ inds, int m, int64_t nb,
+                                                               const double* __restrict__ u, const double* __restrict__ b,
+                                                               double alpha, double* __restrict__ out) {
+  __shared__ double rl[kThreads];
+  const int bpw = kThreads / m;            // blocks per workgroup
+  const int tid = threadIdx.x;
+  const int lb = tid / m, i = tid - lb * m;
+  const int64_t blk = (int64_t)blockIdx.x * bpw + lb;
+  const bool act = lb < bpw && blk < nb;
+  int32_t id = 0;
+  if (act) {
+    id = inds[blk * m + i];
+    const int p0 = A.rowptr[id], p1 = A.rowptr[id + 1];
+    double acc = 0.0;
+    {
+#pragma clang fp contract(off)
+      int p = p0;
+      for (; p + 3 < p1; p += 4) {
+        const int c0 = A.colind[p], c1 = A.colind[p + 1], c2 = A.colind[p + 2], c3 = A.colind[p + 3];
+        const double v0 = A.vals[p], v1 = A.vals[p + 1], v2 = A.vals[p + 2], v3 = A.vals[p + 3];
+        const double t0 = v0 * u[c0], t1 = v1 * u[c1], t2 = v2 * u[c2], t3 = v3 * u[c3];
+        acc = acc + t0;
+        acc = acc + t1;
+        acc = acc + t2;
+        acc = acc + t3;
+      }
+      for (; p < p1; ++p) {
+        const double t = A.vals[p] * u[A.colind[p]];
+        acc = acc + t;
+      }
+    }
+    rl[tid] = b[id] - acc;
+  }
+  __syncthreads();
+  if (!act) return;
+  const double* Bi = binv + (blk * m + i) * m;
+  const double* rb = rl + lb * m;
+  double y = 0.0;
+  for (int j = 0; j < m; ++j) y += Bi[j] * rb[j];
+  if (DIRECT) {
+    const double v = alpha * y;
+    out[id] = u[id] + v;
+  } else {
+    out[blk * m + i] = y;
+  }
+}
+
+// out[row] = u[row] + alpha * (sum of the Y entries covering the row) / (cnt ? cnt[row] : 1); the covering entries of a
+// row (cover_ptr / cover_idx: flat indices block * m + i, ascending) come from the smoother's index lists, rows in no
+// block keep their value.  out may alias u.
+static __global__ __launch_bounds__(kThreads) void block_combine_kernel(int64_t n, const int32_t* __restrict__ cover_ptr,
+                                                                        const uint32_t* __restrict__ cover_idx,
+                                                                        const double* __restrict__ Y, const double* u,
+                                                                        const double* __restrict__ cnt, double alpha, double* out) {
+  const int64_t row = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (row >= n) return;
+  double v = 0.0;
+  for (int q = cover_ptr[row]; q < cover_ptr[row + 1]; ++q) v += Y[cover_idx[q]];
+  if (cnt) v = v / cnt[row];
+  v = alpha * v;
+  out[row] = u[row] + v;
 }
 
 // out = (u ? u : 0) + alpha * (y / (cnt ? cnt : 1)); out may alias u (block smoothers update in place)

@@ -124,6 +124,34 @@ __global__ __launch_bounds__(kSetupThreads) void inds_convert_kernel(int64_t tot
   if (before > 0.0) flags[2] = 1;
 }
 
+// smallest index of every block's list; *unsorted set when the keys do not ascend with the block number
+__global__ __launch_bounds__(kSetupThreads) void block_minkey_kernel(int64_t nb, int m, const int32_t* __restrict__ inds,
+                                                                     uint32_t* __restrict__ keys, int* __restrict__ unsorted) {
+  const int64_t k = (int64_t)blockIdx.x * kSetupThreads + threadIdx.x;
+  if (k >= nb) return;
+  int32_t mn = inds[k * m];
+  for (int i = 1; i < m; ++i) mn = min(mn, inds[k * m + i]);
+  keys[k] = (uint32_t)mn;
+  if (k > 0) {
+    int32_t pm = inds[(k - 1) * m];
+    for (int i = 1; i < m; ++i) pm = min(pm, inds[(k - 1) * m + i]);
+    if (pm > mn) *unsorted = 1;
+  }
+}
+
+// blocks in a new order: new block k is old block order[k] (index lists and inverses)
+__global__ __launch_bounds__(kSetupThreads) void block_permute_kernel(int64_t total, int m, const uint32_t* __restrict__ order,
+                                                                      const int32_t* __restrict__ inds, const double* __restrict__ binv,
+                                                                      int32_t* __restrict__ inds_out, double* __restrict__ binv_out) {
+  const int64_t t = (int64_t)blockIdx.x * kSetupThreads + threadIdx.x;   // one thread per (block, row)
+  if (t >= total) return;
+  const int64_t k = t / m;
+  const int i = (int)(t - k * m);
+  const int64_t src = (int64_t)order[k] * m + i;
+  inds_out[t] = inds[src];
+  for (int j = 0; j < m; ++j) binv_out[t * m + j] = binv[src * m + j];
+}
+
 // rows [a, b] of a two-mode transfer: *flag != 0 unless every a is exactly 1.0; the b column on its own
 __global__ __launch_bounds__(kSetupThreads) void transfer_unit_check_kernel(int64_t n, const double* __restrict__ lf, int* flag) {
   const int64_t i = (int64_t)blockIdx.x * kSetupThreads + threadIdx.x;

@@ -96,6 +96,52 @@ static void test_lds_cap() {
   }
 }
 
+static void test_row_blocks() {
+  // row-length patterns: uniform short rows (DG / CG operators), one long row among short ones, empty rows, growing rows
+  unsigned seed = 12345u;
+  auto rnd = [&](unsigned mod) { seed = seed * 1664525u + 1013904223u; return (seed >> 8) % mod; };
+  for (int pattern = 0; pattern < 6; ++pattern)
+    for (int64_t nrows : {(int64_t)1, (int64_t)7, (int64_t)1000, (int64_t)5000, (int64_t)70000}) {
+      std::vector<int32_t> rp((size_t)nrows + 1, 0);
+      for (int64_t i = 0; i < nrows; ++i) {
+        int len = 0;
+        switch (pattern) {
+          case 0: len = 6; break;
+          case 1: len = (i == nrows / 2) ? 10000 : 5; break;
+          case 2: len = (int)rnd(3) == 0 ? 0 : 9; break;
+          case 3: len = 1 + (int)(i % 40); break;
+          case 4: len = (int)rnd(30); break;
+          default: len = (i % 97 == 0) ? 5000 : 12; break;
+        }
+        rp[(size_t)i + 1] = rp[(size_t)i] + len;
+      }
+      const int max_nnz = 4096, max_rows = 1024;
+      const std::vector<int32_t> blk = stream_row_blocks(rp.data(), nrows, max_nnz, max_rows);
+      EXPECT(blk.front() == 0 && blk.back() == nrows);
+      for (size_t k = 0; k + 1 < blk.size(); ++k) {
+        const int r0 = blk[k], r1 = blk[k + 1];
+        EXPECT(r1 > r0 && r1 - r0 <= max_rows);                                    // a partition into non-empty runs
+        EXPECT(rp[(size_t)r1] - rp[(size_t)r0] <= max_nnz || r1 == r0 + 1);        // that fit the LDS stage, or one long row
+      }
+      for (int bw : {1, 5, 32})
+        for (int sweeps : {1, 4}) {
+          const int window = 4 * 256 + 2 * 4 * 32;
+          std::vector<int32_t> bb;
+          const bool ok = band_row_blocks(rp.data(), nrows, bw, sweeps, max_nnz, window, max_rows, &bb);
+          if (!ok) continue;
+          EXPECT(bb.front() == 0 && bb.back() == nrows);
+          const int64_t H = (int64_t)(sweeps - 1) * bw;
+          for (size_t k = 0; k + 1 < bb.size(); ++k) {
+            const int64_t r0 = bb[k], r1 = bb[k + 1];
+            EXPECT(r1 > r0 && r1 - r0 <= max_rows);
+            const int64_t lo = std::max<int64_t>(0, r0 - H), hi = std::min<int64_t>(nrows, r1 + H);
+            EXPECT(rp[(size_t)hi] - rp[(size_t)lo] <= max_nnz);                     // block + halo rows fit the product stage
+            EXPECT((r1 - r0) + 2 * (int64_t)sweeps * bw <= window);                 // and the window of x its LDS array
+          }
+        }
+    }
+}
+
 static void test_tile_subsets() {
   for (int64_t ne : {1, 7, 100, 101, 1000, 4096, 100000})
     for (int owned : {1, 3, 64, 100, 122})
@@ -162,6 +208,7 @@ static void test_chunk_route() {
 int main() {
   test_cr_plans();
   test_lds_cap();
+  test_row_blocks();
   test_tile_subsets();
   test_lane_ranges();
   test_chunk_route();
