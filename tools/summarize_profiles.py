@@ -45,17 +45,27 @@ def period(seq, windows=5):
 
 def roles_of(window):
     """window: list of short kernel names of one cycle"""
-    fused = [i for i, k in enumerate(window) if "fused_kernel" in k]
+    fused = [i for i, k in enumerate(window) if "fused_kernel" in k or "btd_pair_" in k]
     coarse = [i for i, k in enumerate(window) if "cr_" in k]
     first_c = coarse[0] if coarse else len(window)
     names = []
     down = [i for i in fused if i < first_c]
     up = [i for i in fused if i > first_c]
+    # a two-level launch (btd_pair_*_kernel, r04) carries its level and the next coarser one: levels are counted
+    # through it
+    lev, lv = {}, 0
+    for i in down:
+        lev[i] = lv
+        lv += 2 if "btd_pair_" in window[i] else 1
+    lv = 0
+    for i in reversed(up):
+        lev[i] = lv
+        lv += 2 if "btd_pair_" in window[i] else 1
     for i, k in enumerate(window):
         if i in down:
-            names.append(f"fused_down_L{down.index(i)}")
+            names.append(f"pair_down_L{lev[i]}" if "btd_pair_" in k else f"fused_down_L{lev[i]}")
         elif i in up:
-            names.append(f"fused_up_L{len(up) - 1 - up.index(i)}")
+            names.append(f"pair_up_L{lev[i]}" if "btd_pair_" in k else f"fused_up_L{lev[i]}")
         elif i in coarse:
             names.append(f"coarse_{coarse.index(i)}:{k.split('<')[0]}")
         else:
