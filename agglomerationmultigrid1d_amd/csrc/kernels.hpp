@@ -566,17 +566,45 @@ __device__ __forceinline__ int64_t fused_tile(const FusedArgs& a) {
 #define AGGMG_ST(p, v) ((p) = (v))
 #endif
 
-// sum / broadcast inside the group of W consecutive lanes holding one element's rows (W = 2^k):
-// DPP / permute cross-lane moves, no LDS traffic, no barrier
+// sum / broadcast inside the group of W consecutive lanes holding one element's rows (W = 2^k), no LDS traffic, no
+// barrier.  W = 2, 4: the group lies inside a quad of lanes, so the exchange is a DPP quad permutation -- a VALU move
+// modifier -- instead of ds_bpermute, which goes through the LDS pipe and costs its latency twice per sweep in the
+// dependent chain (AGGMG_DPP=0 at compile time: the permute form, for A/B runs).  Same values, same order of additions.
+#ifndef AGGMG_DPP
+#define AGGMG_DPP 1
+#endif
+template <int CTRL>
+__device__ __forceinline__ double quad_perm(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
 template <int W>
 __device__ __forceinline__ double group_sum(double v) {
+  if constexpr (AGGMG_DPP && (W == 2 || W == 4)) {
+    if constexpr (W == 4) v += quad_perm<0x4E>(v);   // lanes [2, 3, 0, 1]: xor 2
+    v += quad_perm<0xB1>(v);                         // lanes [1, 0, 3, 2]: xor 1
+    return v;
+  } else {
 #pragma unroll
-  for (int off = W / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, W);
-  return v;
+    for (int off = W / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, W);
+    return v;
+  }
 }
 template <int W>
 __device__ __forceinline__ double group_bcast(double v, int j) {
-  return __shfl(v, j, W);
+  if constexpr (AGGMG_DPP && W == 4) {
+    switch (j) {   // (j is a constant after unrolling: one quad permutation [j, j, j, j])
+      case 0: return quad_perm<0x00>(v);
+      case 1: return quad_perm<0x55>(v);
+      case 2: return quad_perm<0xAA>(v);
+      default: return quad_perm<0xFF>(v);
+    }
+  } else if constexpr (AGGMG_DPP && W == 2) {
+    return j == 0 ? quad_perm<0xA0>(v) : quad_perm<0xF5>(v);   // [0, 0, 2, 2] / [1, 1, 3, 3]
+  } else {
+    return __shfl(v, j, W);
+  }
 }
 
 // GS: red-black block Gauss-Seidel sweeps (FusedArgs::gs gives the colour order) instead of

@@ -79,9 +79,10 @@ def test_cr_solve_matches_sparse_lu(mg, nb, m, ragged):
     bd, xd, z = ctx.to_device(b), ctx.alloc(N), ctx.to_device(np.zeros(N))
     H.vcycle_dev(z, bd, xd, 0, 0, 1.0)
     x = xd.download()
-    ref = spla.splu(A).solve(b)
     assert np.linalg.norm(A @ x - b) <= 1e-12 * np.linalg.norm(b)
-    assert np.linalg.norm(x - ref) <= 1e-11 * np.linalg.norm(ref)
+    if N <= 3_000_000:      # (SuperLU runs out of memory beyond: the residual above stands alone there)
+        ref = spla.splu(A).solve(b)
+        assert np.linalg.norm(x - ref) <= 1e-11 * np.linalg.norm(ref)
     # further solves with the same handle (ticket counter / stack reuse)
     b2 = rng.standard_normal(N)
     y = ctx.alloc(N)
@@ -110,9 +111,10 @@ def test_cr_with_row_pivoting_inside_the_blocks(mg, nb, m):
     xd, z = ctx.alloc(N), ctx.to_device(np.zeros(N))
     H.vcycle_dev(z, ctx.to_device(b), xd, 0, 0, 1.0)
     x = xd.download()
-    ref = spla.splu(A).solve(b)
     assert np.linalg.norm(A @ x - b) <= 1e-12 * np.linalg.norm(b)
-    assert np.linalg.norm(x - ref) <= 1e-11 * np.linalg.norm(ref)
+    if N <= 3_000_000:      # (SuperLU runs out of memory beyond: the residual above stands alone there)
+        ref = spla.splu(A).solve(b)
+        assert np.linalg.norm(x - ref) <= 1e-11 * np.linalg.norm(ref)
     H.free()
 
 
