@@ -664,6 +664,10 @@ def main():
         info = H.coarse_info()
         comp_rw = H.launch_bytes(0, "down")
         comp_all = {f"fused_{kd}_L{k}": sum(H.launch_bytes(k, kd)) for k in range(len(level_sizes) - 1) for kd in ("down", "up")}
+        paired = {kd: H.paired_levels(nPre if kd == "down" else nPost, kd) for kd in ("down", "up")}
+        for kd in ("down", "up"):     # a two-level launch carries the arrays of both levels (attributed to the finer one)
+            for k in paired[kd]:
+                comp_all[f"fused_{kd}_L{k}"] += comp_all.pop(f"fused_{kd}_L{k + 1}")
         # the device-resident outer loops, outside the timed region: multigrid()
         # (src/solvers.jl:116-139, residual check every 8 cycles) and CG preconditioned with
         # ldiv! to ||A x - b|| < 1e-8 ||b|| from a zero guess
@@ -699,7 +703,7 @@ def main():
         H.free()
         return dict(N=N, dt=dt, per=per, dt_loop=dt_loop, prof=prof, prof_dom=prof_dom,
                     bytes_model=bytes_model, level_sizes=level_sizes, t_gen=t_gen, t_lib=t_lib,
-                    coarse_info=info, outer=outer, pcie=pcie, comp_rw=comp_rw, comp_all=comp_all)
+                    coarse_info=info, outer=outer, pcie=pcie, comp_rw=comp_rw, comp_all=comp_all, paired=paired)
 
     R = run_size(args.log2_elems, args.steps, args.warmup, True)
     N, dt, dt_loop, prof, bytes_model = R["N"], R["dt"], R["dt_loop"], R["prof"], R["bytes_model"]
@@ -768,6 +772,7 @@ def main():
                               "operator -- exceeds 1 because the fused kernel reads the operator once for 3 sweeps + residual "
                               "+ restriction; kept for continuity with r01-r03, not a bound"),
         "kernels": kern_ms,
+        "two_level_launches": {kd: [f"levels {k + 1}+{k + 2}" for k in v] for kd, v in R["paired"].items()},
         "setup_s": R["t_gen"] + R["t_lib"], "setup_generator_s": R["t_gen"], "setup_library_s": R["t_lib"],
     }
     if args.also_log2_elems and args.also_log2_elems != args.log2_elems:
