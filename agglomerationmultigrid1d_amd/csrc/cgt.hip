@@ -31,9 +31,12 @@
 #ifndef AGGMG_CGT_NS_GS
 #define AGGMG_CGT_NS_GS 2
 #endif
+#ifndef AGGMG_CGT_NT
+#define AGGMG_CGT_NT kThreads
+#endif
 template <int M, int K = 0>
 struct CgtTile {
-  static constexpr int NT = kThreads;
+  static constexpr int NT = AGGMG_CGT_NT;   // threads per workgroup (tuning knob: tools/exp_tiles_r04.sh)
   static constexpr int NS0 = (M == 1) ? AGGMG_CGT_NS1 : (M == 2) ? AGGMG_CGT_NS2 : (M <= 4) ? AGGMG_CGT_NS4 : 3;
   static constexpr int NS = (K == 2) ? (NS0 < AGGMG_CGT_NS_GS ? AGGMG_CGT_NS_GS : NS0) : NS0;
   static constexpr int EPS = NT / M;
