@@ -132,6 +132,10 @@ SYMBOLS = {
     "aggmg_coarse_boundary_solve_dev": (c_int, [_P, _P, _P, _P, _P]),
     "aggmg_coarse_chunk_backward_dev": (c_int, [_P, _P, _P, c_int64, c_int64, _P, _P]),
     "aggmg_hier_level_kind": (c_int, [_P, _P, c_int, POINTER(c_int)]),
+    "aggmg_host_register": (c_int, [_P, _P, c_int64]),
+    "aggmg_host_unregister": (c_int, [_P, _P]),
+    "aggmg_host_alloc": (c_int, [_P, c_int64, POINTER(_P)]),
+    "aggmg_host_free": (c_int, [_P, _P]),
     "aggmg_hier_level_paired": (c_int, [_P, _P, c_int, c_int, POINTER(c_int)]),
     "aggmg_hier_launch_bytes": (c_int, [_P, _P, c_int, c_int, c_int, POINTER(c_int64), POINTER(c_int64)]),
     "aggmg_smoother_launch_bytes": (c_int, [_P, _P, _P, c_int, POINTER(c_int64), POINTER(c_int64)]),

@@ -101,6 +101,30 @@ class Context:
         v.upload(x)
         return v
 
+    def pin(self, x):
+        """page-lock the memory of a NumPy array for good (C ABI aggmg_host_register): host-pointer calls that pass it
+        -- multigrid_v_cycle(H, x0, b, out=), ldiv -- then move it by one DMA transfer instead of staging it.  The
+        array must outlive the registration: unpin(x) (or freeing the context) ends it."""
+        x = np.asarray(x)
+        if x.dtype != np.float64 or not x.flags["C_CONTIGUOUS"]:
+            raise ArgumentError("Context.pin: a C-contiguous float64 array")
+        self.check(self.lib.aggmg_host_register(self.handle, ctypes.c_void_p(x.ctypes.data), x.nbytes))
+        self._pinned = getattr(self, "_pinned", {})
+        self._pinned[x.ctypes.data] = x      # (keeps the pages alive while they are registered)
+        return x
+
+    def unpin(self, x):
+        self.check(self.lib.aggmg_host_unregister(self.handle, ctypes.c_void_p(x.ctypes.data)))
+        getattr(self, "_pinned", {}).pop(x.ctypes.data, None)
+
+    def pinned_empty(self, n):
+        """float64 NumPy array of n entries in page-locked memory owned by the context (C ABI aggmg_host_alloc); freed
+        with the context"""
+        p = ctypes.c_void_p()
+        self.check(self.lib.aggmg_host_alloc(self.handle, int(n) * 8, ctypes.byref(p)))
+        buf = (ctypes.c_double * int(n)).from_address(p.value)
+        return np.frombuffer(buf, dtype=np.float64, count=int(n))
+
     def profile_enable(self, on=True):
         """True / 1: HIP events around every launch; 2: only the fine-level fused-down launch;
         False / 0: off"""
@@ -899,10 +923,12 @@ class MeshHierarchy:
             pass
 
 
-def multigrid_v_cycle(H, x0, b, nPre=3, nPost=3, alpha=2.0 / 3.0):
+def multigrid_v_cycle(H, x0, b, nPre=3, nPost=3, alpha=2.0 / 3.0, out=None):
     """multigrid_v_cycle(H, x0, b; nPre=3, nPost=3, alpha=2/3) -> x   (src/solvers.jl:19-50).
     Returns a new vector; x0 and b are not modified.  x0, b: host arrays (-> NumPy array) or DeviceVectors
-    (-> DeviceVector, nothing leaves the device)."""
+    (-> DeviceVector, nothing leaves the device).  out (host arrays only, an extension): the array the result goes to
+    instead of a new one -- with x0, b, out page-locked once (Context.pin / pinned_empty) a call moves its three vectors
+    by DMA instead of staging them."""
     if not isinstance(nPre, (int, np.integer)) or not isinstance(nPost, (int, np.integer)):
         raise TypeError("nPre / nPost must be integers (nPre::Integer, src/solvers.jl:20)")
     if isinstance(x0, DeviceVector) and isinstance(b, DeviceVector):
@@ -919,7 +945,12 @@ def multigrid_v_cycle(H, x0, b, nPre=3, nPost=3, alpha=2.0 / 3.0):
     N = H._ops[0].shape[0]
     if x0.shape != (N,) or b.shape != (N,):
         raise DimensionMismatch("multigrid_v_cycle: x0 / b do not match the fine operator")
-    out = np.empty(N)
+    if out is None:
+        out = np.empty(N)
+    elif not (isinstance(out, np.ndarray) and out.dtype == np.float64 and out.shape == (N,) and out.flags["C_CONTIGUOUS"]):
+        raise DimensionMismatch("multigrid_v_cycle: out must be a contiguous float64 array of the fine operator's size")
+    elif np.shares_memory(out, x0) or np.shares_memory(out, b):
+        raise ArgumentError("multigrid_v_cycle: out must not alias x0 or b (they are not modified)")
     c = H.ctx
     c.check(c.lib.aggmg_vcycle(c.handle, H.handle, _pd(x0), _pd(b), int(nPre), int(nPost), float(alpha),
                                _pd(out)))
@@ -936,8 +967,18 @@ def ldiv(*args):
         y, H, b = args
     else:
         raise TypeError("ldiv(H, b) or ldiv(y, H, b)")
-    u0 = np.zeros(H._ops[0].shape[0])
-    y[:] = multigrid_v_cycle(H, u0, b)
+    N = H._ops[0].shape[0]
+    u0 = H.__dict__.get("_zero_guess")        # the zero initial guess, page-locked once per hierarchy
+    if u0 is None or u0.size != N:
+        u0 = H.ctx.pinned_empty(N)
+        u0[:] = 0.0
+        H.__dict__["_zero_guess"] = u0
+    direct = (y is not b and isinstance(y, np.ndarray) and y.dtype == np.float64 and y.shape == (N,) and y.flags["C_CONTIGUOUS"]
+              and not np.shares_memory(y, np.asarray(b)))
+    if direct:      # straight into y: with y and b page-locked (Context.pin) nothing is staged
+        multigrid_v_cycle(H, u0, b, out=y)
+    else:
+        y[:] = multigrid_v_cycle(H, u0, b)
     return None
 
 

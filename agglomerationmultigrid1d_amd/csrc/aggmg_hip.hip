@@ -59,9 +59,67 @@ extern "C" int aggmg_destroy(aggmg_ctx* ctx) {
     }
     if (L.stream) (void)hipStreamDestroy(L.stream);
   }
+  for (auto& r : ctx->pinned) {
+    if (r.owned) (void)hipHostFree(r.base);
+    else (void)hipHostUnregister(r.base);
+  }
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
   return AGGMG_OK;
+}
+
+// ---- page-locked host memory kept across calls (the host-pointer entry's fast path) ------------------------------
+static bool host_is_pinned(const aggmg_ctx* ctx, const void* p, size_t bytes) {
+  const char* c = static_cast<const char*>(p);
+  for (const auto& r : ctx->pinned)
+    if (c >= r.base && c + bytes <= r.base + r.bytes) return true;
+  return false;
+}
+
+extern "C" int aggmg_host_register(aggmg_ctx* ctx, void* ptr, int64_t nbytes) {
+  if (!ctx) return AGGMG_ERR_ARGUMENT;
+  if (!ptr || nbytes <= 0) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_host_register: NULL pointer or empty range");
+  HIPCHK(hipSetDevice(ctx->device));
+  if (host_is_pinned(ctx, ptr, (size_t)nbytes)) return AGGMG_OK;
+  HIPCHK(hipHostRegister(ptr, (size_t)nbytes, hipHostRegisterDefault));
+  ctx->pinned.push_back({static_cast<char*>(ptr), (size_t)nbytes, false});
+  return AGGMG_OK;
+}
+
+extern "C" int aggmg_host_unregister(aggmg_ctx* ctx, void* ptr) {
+  if (!ctx) return AGGMG_ERR_ARGUMENT;
+  for (size_t i = 0; i < ctx->pinned.size(); ++i)
+    if (ctx->pinned[i].base == static_cast<char*>(ptr) && !ctx->pinned[i].owned) {
+      HIPCHK(hipStreamSynchronize(ctx->stream));   // no copy of ours may still be reading it
+      HIPCHK(hipHostUnregister(ptr));
+      ctx->pinned.erase(ctx->pinned.begin() + (long)i);
+      return AGGMG_OK;
+    }
+  return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_host_unregister: not a range registered with this context");
+}
+
+extern "C" int aggmg_host_alloc(aggmg_ctx* ctx, int64_t nbytes, void** out) {
+  if (!ctx || !out) return AGGMG_ERR_ARGUMENT;
+  if (nbytes < 0) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_host_alloc: negative size");
+  HIPCHK(hipSetDevice(ctx->device));
+  void* p = nullptr;
+  HIPCHK(hipHostMalloc(&p, (size_t)std::max<int64_t>(nbytes, 8), hipHostMallocDefault));
+  ctx->pinned.push_back({static_cast<char*>(p), (size_t)std::max<int64_t>(nbytes, 8), true});
+  *out = p;
+  return AGGMG_OK;
+}
+
+extern "C" int aggmg_host_free(aggmg_ctx* ctx, void* ptr) {
+  if (!ctx) return AGGMG_ERR_ARGUMENT;
+  if (!ptr) return AGGMG_OK;
+  for (size_t i = 0; i < ctx->pinned.size(); ++i)
+    if (ctx->pinned[i].base == static_cast<char*>(ptr) && ctx->pinned[i].owned) {
+      HIPCHK(hipStreamSynchronize(ctx->stream));
+      HIPCHK(hipHostFree(ptr));
+      ctx->pinned.erase(ctx->pinned.begin() + (long)i);
+      return AGGMG_OK;
+    }
+  return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_host_free: not an allocation of this context");
 }
 
 extern "C" const char* aggmg_last_error(aggmg_ctx* ctx) {
@@ -1953,8 +2011,29 @@ void stage_slice(int device, aggmg_ctx::StageLane* L, bool to_device, char* dev,
 }
 
 // nvec copies of `bytes` each, all lanes working on one vector after the other; synchronous
-int stage_copy(aggmg_ctx* ctx, bool to_device, int nvec, double* const* dev, double* const* host, size_t bytes) {
-  if (!bytes || !nvec) return AGGMG_OK;
+int stage_copy(aggmg_ctx* ctx, bool to_device, int nvec_in, double* const* dev_in, double* const* host_in, size_t bytes) {
+  if (!bytes || !nvec_in) return AGGMG_OK;
+  // vectors in memory the caller page-locked for good (aggmg_host_register / aggmg_host_alloc): one asynchronous copy
+  // each on the compute stream, DMA straight from / to the caller's pages; the rest is staged as pageable memory
+  double* dev[4];
+  double* host[4];
+  int nvec = 0;
+  bool direct = false;
+  for (int v = 0; v < nvec_in; ++v) {
+    if (host_is_pinned(ctx, host_in[v], bytes)) {
+      if (to_device) HIPCHK(hipMemcpyAsync(dev_in[v], host_in[v], bytes, hipMemcpyHostToDevice, ctx->stream));
+      else HIPCHK(hipMemcpyAsync(host_in[v], dev_in[v], bytes, hipMemcpyDeviceToHost, ctx->stream));
+      direct = true;
+    } else if (nvec < 4) {
+      dev[nvec] = dev_in[v];
+      host[nvec] = host_in[v];
+      ++nvec;
+    }
+  }
+  if (!nvec) {
+    if (direct && !to_device) HIPCHK(hipStreamSynchronize(ctx->stream));   // the caller reads the result next
+    return AGGMG_OK;                                                         // (copies in: the cycle is ordered behind them)
+  }
   const int lanes = bytes < 4 * kStageChunk ? 0 : stage_lanes(ctx);
   if (lanes <= 0) {   // short vectors (or no pinned memory to be had): the plain copy
     for (int v = 0; v < nvec; ++v) {

@@ -62,7 +62,15 @@ struct aggmg_ctx {
     hipEvent_t ev[2] = {nullptr, nullptr};
   };
   std::vector<StageLane> stage;
-  bool stage_failed = false;  // the lanes could not be allocated once: aggmg_vcycle keeps to plain hipMemcpy
+  bool stage_failed = false;
+  // host ranges the caller page-locked for good (aggmg_host_register / aggmg_host_alloc): copies from / to them go
+  // straight over PCIe on the compute stream, no staging
+  struct Pinned {
+    char* base;
+    size_t bytes;
+    bool owned;   // allocated by aggmg_host_alloc (hipHostMalloc) rather than registered
+  };
+  std::vector<Pinned> pinned;  // the lanes could not be allocated once: aggmg_vcycle keeps to plain hipMemcpy
 };
 
 struct CsrDev {

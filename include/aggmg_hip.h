@@ -84,6 +84,17 @@ int aggmg_dev_alloc(aggmg_ctx* ctx, int64_t nbytes, void** out);
 int aggmg_dev_free(aggmg_ctx* ctx, void* ptr);
 int aggmg_memcpy_h2d(aggmg_ctx* ctx, void* dst_dev, const void* src_host, int64_t nbytes);
 int aggmg_memcpy_d2h(aggmg_ctx* ctx, void* dst_host, const void* src_dev, int64_t nbytes);
+/* Page-locked host memory for the host-pointer entry points (aggmg_vcycle: what multigrid_v_cycle(H, x0, b) /
+ * ldiv!(y, H, b) on host vectors call, src/solvers.jl:19-50,63-92).  Pageable arrays are staged through pinned chunks by
+ * worker threads (24 - 28 GB/s); arrays the caller keeps for many calls -- the vectors of a Krylov loop around ldiv! --
+ * can be page-locked ONCE instead: copies from and to a registered range are single asynchronous DMA transfers on the
+ * context's stream.  aggmg_host_register page-locks an existing range (hipHostRegister; the range must stay valid
+ * until aggmg_host_unregister or aggmg_destroy), aggmg_host_alloc hands out pinned memory (hipHostMalloc) that
+ * aggmg_host_free returns.  Registering per call does not pay: the registration costs what it saves (measured). */
+int aggmg_host_register(aggmg_ctx* ctx, void* ptr, int64_t nbytes);
+int aggmg_host_unregister(aggmg_ctx* ctx, void* ptr);
+int aggmg_host_alloc(aggmg_ctx* ctx, int64_t nbytes, void** out);
+int aggmg_host_free(aggmg_ctx* ctx, void* ptr);
 
 /* ---- operators: H.mStiffness[k], H.mInterpolation[k] (src/mesh_heirarchy.jl:20,26) ---------- */
 #define AGGMG_OP_STIFFNESS 0 /* used as A*u only                    src/solvers.jl:33,36,44 */

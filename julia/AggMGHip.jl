@@ -341,7 +341,9 @@ Base.Array(v::DeviceVector) = download(v)
 # x0 and b are not mutated, a new Vector is returned
 function multigrid_v_cycle(Hd::DeviceHierarchy, x0::AbstractVector, b::AbstractVector;
         nPre::Integer = 3, nPost::Integer = 3, alpha::AbstractFloat = 2.0 / 3.0)
-    x0v = Vector{Float64}(x0); bv = Vector{Float64}(b); out = similar(bv)
+    # (convert: no copy when the caller's vectors are Vector{Float64} already -- arrays page-locked with pin! stay the ones
+    # the library reads)
+    x0v = convert(Vector{Float64}, x0); bv = convert(Vector{Float64}, b); out = similar(bv)
     GC.@preserve x0v bv out check(Hd.ctx.h, ccall((:aggmg_vcycle, LIB), Cint,
         (Handle, Handle, Ptr{Float64}, Ptr{Float64}, Cint, Cint, Float64, Ptr{Float64}),
         Hd.ctx.h, Hd.h, x0v, bv, nPre, nPost, Float64(alpha), out))
@@ -382,6 +384,42 @@ function la.ldiv!(Hd::DeviceHierarchy, b::AbstractVector)
 end
 function la.ldiv!(y::AbstractVector, Hd::DeviceHierarchy, b::AbstractVector)
     y[:] = multigrid_v_cycle(Hd, zeros(size(Hd.H.mStiffness[1], 1)), b); return
+end
+# ldiv!(y, H, b) on Vector{Float64}s straight into y (no temporary result): with y and b page-locked once (pin!) -- the
+# vectors of a Krylov loop that calls ldiv! every iteration -- the call moves them by DMA instead of staging them
+function la.ldiv!(y::Vector{Float64}, Hd::DeviceHierarchy, b::Vector{Float64})
+    (length(y) == length(b)) || throw(DimensionMismatch("ldiv!: y and b differ in length"))
+    z = zero_guess(Hd, length(b))
+    GC.@preserve z b y check(Hd.ctx.h, ccall((:aggmg_vcycle, LIB), Cint,
+        (Handle, Handle, Ptr{Float64}, Ptr{Float64}, Cint, Cint, Float64, Ptr{Float64}),
+        Hd.ctx.h, Hd.h, z, b, 3, 3, 2.0 / 3.0, y))
+    return
+end
+
+# Page-locked host vectors (include/aggmg_hip.h: aggmg_host_register).  pin!(ctx, v) page-locks v's memory for good;
+# v must stay alive and must not be resized until unpin!(ctx, v) (the context keeps a reference).
+const PINNED = IdDict{Any,Any}()
+function pin!(ctx::Context, v::Vector{Float64})
+    GC.@preserve v check(ctx.h, ccall((:aggmg_host_register, LIB), Cint, (Handle, Ptr{Cvoid}, Int64),
+        ctx.h, pointer(v), Int64(sizeof(v))))
+    PINNED[v] = ctx
+    return v
+end
+function unpin!(ctx::Context, v::Vector{Float64})
+    GC.@preserve v check(ctx.h, ccall((:aggmg_host_unregister, LIB), Cint, (Handle, Ptr{Cvoid}), ctx.h, pointer(v)))
+    delete!(PINNED, v)
+    return v
+end
+# the zero initial guess of ldiv!, page-locked once per (hierarchy, length)
+const ZERO_GUESS = IdDict{Any,Vector{Float64}}()
+function zero_guess(Hd::DeviceHierarchy, n::Integer)
+    z = get(ZERO_GUESS, Hd, nothing)
+    if z === nothing || length(z) != n
+        z = zeros(n)
+        pin!(Hd.ctx, z)
+        ZERO_GUESS[Hd] = z
+    end
+    return z
 end
 
 # `A \\ b` of a device operator -- the fine-level direct solve behind the reference's `err` histories

@@ -315,3 +315,33 @@ def test_dense_interpolation_matrix_through_the_device(oracle, mg):
 
 def rand_like(o, n, seed):
     return np.random.default_rng(100 + seed).standard_normal(n)
+
+
+def test_page_locked_host_vectors(oracle, mg):
+    """aggmg_host_register / aggmg_host_alloc: host-pointer cycles on arrays page-locked once give the bits of the staged
+    pageable path; ranges can be unregistered again; an unknown range is refused"""
+    o = oracle
+    Ho, b = o.build_dg_agg_hierarchy(64, p=3, pAgg=1, nAgg=3, first=4)
+    H = mg.MeshHierarchy.from_reference(Ho)
+    ctx = H.ctx
+    N = len(b)
+    x0 = o.splitmix_normal(N, 3)
+    ref = mg.multigrid_v_cycle(H, x0, b)                     # pageable arrays, a new result array
+    xp = ctx.pinned_empty(N)
+    xp[:] = x0
+    bp = ctx.pin(np.array(b))
+    out = ctx.pinned_empty(N)
+    got = mg.multigrid_v_cycle(H, xp, bp, out=out)
+    assert got is out and np.array_equal(out, ref) and np.array_equal(xp, x0)
+    # mixed: pinned inputs, pageable result
+    assert np.array_equal(mg.multigrid_v_cycle(H, xp, bp), ref)
+    # ldiv!(y, H, b) straight into a pinned y
+    y = ctx.pinned_empty(N)
+    mg.ldiv(y, H, bp)
+    assert np.array_equal(y, mg.multigrid_v_cycle(H, np.zeros(N), b))
+    ctx.unpin(bp)
+    with pytest.raises(mg.ArgumentError):
+        ctx.unpin(bp)                                        # no longer registered
+    assert np.array_equal(mg.multigrid_v_cycle(H, xp, bp, out=out), ref)   # bp is pageable again: staged
+    with pytest.raises(mg.ArgumentError):
+        mg.multigrid_v_cycle(H, xp, bp, out=xp)              # the result must not alias an input
