@@ -125,6 +125,7 @@ SYMBOLS = {
     "aggmg_hier_get_restriction": (c_int, [_P, _P, POINTER(c_int)]),
     "aggmg_vcycle_down_dev": (c_int, [_P, _P, _P, _P, c_int, c_double]),
     "aggmg_vcycle_up_dev": (c_int, [_P, _P, _P, c_int, c_double, _P]),
+    "aggmg_vcycle_up_coarse_dev": (c_int, [_P, _P, _P, c_int, c_double, c_int, c_int64, c_int64]),
     "aggmg_vcycle_up_split_dev": (c_int, [_P, _P, _P, c_int, c_double, _P, c_int64, c_int64, c_int]),
     "aggmg_hier_coarse_buffers": (c_int, [_P, _P, POINTER(_P), POINTER(_P), POINTER(c_int64)]),
     "aggmg_coarse_plan": (c_int, [_P, _P, POINTER(c_int), POINTER(c_int64), POINTER(c_int), POINTER(c_int64)]),

@@ -540,7 +540,7 @@ static int launch_btd_t(aggmg_ctx* ctx, FusedArgs a, int halo, const TileSel& se
   if (a.gs) halo += a.nsweeps;  // two half-sweeps per sweep, one element of halo each
   int shift = 0;
   if (vr) {
-    if (sel.mode != 0) return fail(ctx, AGGMG_ERR_UNSUPPORTED, "tile selection on a level with agglomerates of different sizes");
+    if (sel.mode == 1 || sel.mode == 2) return fail(ctx, AGGMG_ERR_UNSUPPORTED, "tile selection on a level with agglomerates of different sizes");
     if (a.agg_shift >= 0 && T::TE - 2 * halo - a.agg_shift >= T::TE / 2) {
       shift = a.agg_shift;  // owned ranges on agglomerate boundaries: plain stores
     } else {
@@ -554,7 +554,7 @@ static int launch_btd_t(aggmg_ctx* ctx, FusedArgs a, int halo, const TileSel& se
   if (owned <= 0) return fail(ctx, AGGMG_ERR_UNSUPPORTED, "fused tile too small for the requested halo");
   a.owned = owned;
   a.halo_left = halo + shift;
-  const TileSubset sub = fused_tile_subset(a.lv.ne, owned, sel.mode, sel.head, sel.tail);   // host_plan.hpp
+  const TileSubset sub = fused_tile_subset(a.lv.ne, owned, sel.mode == 3 ? 0 : sel.mode, sel.head, sel.tail);   // host_plan.hpp (3: every tile)
   const int64_t ntiles = sub.ntiles;
   a.tile_split = sub.split;
   a.tile_skip = sub.skip;
@@ -1535,14 +1535,18 @@ static int launch_pair_down(aggmg_ctx* ctx, aggmg_hier* h, int k, int nPre, doub
   return AGGMG_OK;
 }
 
-// levels k + 1 then k; the result of level k goes to dst, the post-smoothed level k + 1 is consumed in LDS
-static int launch_pair_up(aggmg_ctx* ctx, aggmg_hier* h, int k, int nPost, double alpha, double* dst) {
+// levels k + 1 then k; the result of level k goes to dst, the post-smoothed level k + 1 is consumed in LDS.
+// part 0: every tile.  part 2 / 1 (element-partitioned runs, levels k + 1, k + 2 = the coarsest): the tiles that read none of
+// the first gh_lo / last gh_hi elements of level k + 2 -- the neighbours' ghost blocks of the coarsest solution, still
+// travelling -- and the remaining tiles at the two ends.
+static int launch_pair_up(aggmg_ctx* ctx, aggmg_hier* h, int k, int nPost, double alpha, double* dst, int part = 0, int64_t gh_lo = 0,
+                          int64_t gh_hi = 0) {
   const int n = (int)h->lv.size();
   Level& a = h->lv[k];
   Level& b = h->lv[k + 1];
   Level& c = h->lv[k + 2];
   PairArgs p = pair_args(h, k, alpha, nPost);
-  const int rhoA = p.ab.rho;
+  const int rhoA = p.ab.rho, rhoB = p.bc.rho;
   p.hb = (nPost + rhoA - 1) / rhoA;
   int own = std::min(kPairTEA - 2 * nPost, (kPairTEB - 2 * p.hb - 2 * nPost) * rhoA);
   own = (own / rhoA) * rhoA;
@@ -1557,7 +1561,25 @@ static int launch_pair_up(aggmg_ctx* ctx, aggmg_hier* h, int k, int nPost, doubl
   p.uc = (k + 2 == n - 1) ? c.u[0] : c.u[1];
   p.u_a = dst;
   p.ub_out = nullptr;   // nothing reads the post-smoothed iterate of level k + 1 but level k's prolongation
-  const int64_t ntiles = (p.A.ne + own - 1) / own;
+  const int64_t all = (p.A.ne + own - 1) / own;
+  int64_t ntiles = all;
+  if (part != 0) {
+    // tile t prolongs from the elements floor(Eb0 / rho_b) .. floor((Eb0 + te_b - 1) / rho_b) of level k + 2 (clipped to
+    // the level): tiles are ordered, so the ones touching the ghosts are a prefix and a suffix
+    auto jmin = [&](int64_t t) { return std::max<int64_t>((t * own) / rhoA - p.hb - nPost, 0) / rhoB; };
+    auto jmax = [&](int64_t t) { return std::min<int64_t>((t * own) / rhoA - p.hb - nPost + p.te_b - 1, p.B.ne - 1) / rhoB; };
+    int64_t tA = 0, tB = 0;
+    while (tA < all && jmin(tA) < gh_lo) ++tA;
+    while (tB < all - tA && jmax(all - 1 - tB) >= p.bc.nec - gh_hi) ++tB;
+    if (part == 1) {
+      p.tile_split = (int)tA;
+      p.tile_skip = all - tA - tB;
+      ntiles = tA + tB;
+    } else {
+      p.tile_skip = tA;
+      ntiles = all - tA - tB;
+    }
+  }
   if (ntiles == 0) return AGGMG_OK;
   const size_t lds = ((size_t)2 * (kPairTEA + 2) * kPairM + (size_t)kPairTEB * 2) * sizeof(double);
   ProfScope ps(ctx, AGGMG_KIND_FUSED_UP, k);
@@ -1648,9 +1670,32 @@ static int vcycle_down(aggmg_ctx* ctx, aggmg_hier* h, const double* x0, const do
 // ---- ascend (src/solvers.jl:41-47): expects the coarsest solution in lv[n-1].u[0] ---------------
 // sel (fine level only): which tiles of the level-0 launch to run; with a selection the coarser
 // levels are skipped (the caller ran them with k_last = 1)
+// csplit (element-partitioned runs): the first launch of the ascent -- it has to be a two-level launch next to the coarsest
+// level -- in two parts around the exchange of the coarsest solution's ghost blocks: mode 2 runs ONLY its tiles that read
+// no ghost block (nothing else), mode 1 its remaining tiles and then the rest of the ascent
+struct CoarseSplit {
+  int mode = 0;
+  int64_t gh_lo = 0, gh_hi = 0;
+};
 static int vcycle_up(aggmg_ctx* ctx, aggmg_hier* h, const double* b, int nPost, double alpha, double* x_out,
-                     int k_last = 0, const TileSel& sel = TileSel()) {
+                     int k_last = 0, const TileSel& sel = TileSel(), const CoarseSplit& cs = CoarseSplit()) {
   const int n = (int)h->lv.size();
+  if (cs.mode != 0) {
+    const int k = n - 2;
+    if (!(sel.mode == 0 && k - 1 >= std::max(k_last, 1) && pair_ok(ctx, h, k - 1, nPost)))
+      return fail(ctx, AGGMG_ERR_UNSUPPORTED, "split coarse ascent needs a two-level launch next to the coarsest level");
+    CHECK(launch_pair_up(ctx, h, k - 1, nPost, alpha, h->lv[k - 1].u[1], cs.mode, cs.gh_lo, cs.gh_hi));
+    if (cs.mode == 2) return AGGMG_OK;
+    for (int kk = k - 2; kk >= k_last; --kk) {   // the levels above the pair, as below (no further pairs are split)
+      if (kk - 1 >= std::max(k_last, 1) && pair_ok(ctx, h, kk - 1, nPost)) {
+        CHECK(launch_pair_up(ctx, h, kk - 1, nPost, alpha, h->lv[kk - 1].u[1]));
+        --kk;
+        continue;
+      }
+      return fail(ctx, AGGMG_ERR_UNSUPPORTED, "split coarse ascent: unpaired level above the coarse pair");
+    }
+    return AGGMG_OK;
+  }
   for (int k = (sel.mode != 0 ? 0 : n - 2); k >= k_last; --k) {
     Level& l = h->lv[k];
     Level& c = h->lv[k + 1];
@@ -1663,7 +1708,7 @@ static int vcycle_up(aggmg_ctx* ctx, aggmg_hier* h, const double* b, int nPost, 
       continue;
     }
     if (l.cgt_fused) {
-      if (k == 0 && sel.mode != 0)
+      if (k == 0 && (sel.mode == 1 || sel.mode == 2))
         return fail(ctx, AGGMG_ERR_UNSUPPORTED, "split ascent needs the fused block-tridiagonal fine level");
       CHECK(cgt_up(ctx, h, k, rhs, nPost, alpha, dst));
       continue;
@@ -1683,7 +1728,7 @@ static int vcycle_up(aggmg_ctx* ctx, aggmg_hier* h, const double* b, int nPost, 
       ProfScope ps(ctx, AGGMG_KIND_FUSED_UP, k);
       CHECK(launch_btd(ctx, *l.S->btd, a, std::max(nPost, 0), k == 0 ? sel : TileSel()));
     } else {
-      if (k == 0 && sel.mode != 0)
+      if (k == 0 && (sel.mode == 1 || sel.mode == 2))
         return fail(ctx, AGGMG_ERR_UNSUPPORTED, "split ascent needs the fused block-tridiagonal fine level");
       {
         ProfScope ps(ctx, AGGMG_KIND_PROLONG, k);
@@ -1874,7 +1919,12 @@ extern "C" int aggmg_vcycle_up_split_dev(aggmg_ctx* ctx, aggmg_hier* h, const do
   CHECK(vcycle_args(ctx, h, b, x_out, nPost, 0));
   if (h->lv.size() < 2) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_vcycle_up_split_dev: needs at least two levels");
   if (x_out == b) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_vcycle_up_split_dev: x_out must not alias b");
-  if (part < 0 || part > 2) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_vcycle_up_split_dev: part is 0, 1 or 2");
+  if (part < 0 || part > 3) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_vcycle_up_split_dev: part is 0, 1, 2 or 3");
+  if (part == 3) {   // the finest level alone, every tile (the coarser levels were run by part 0 / aggmg_vcycle_up_coarse_dev)
+    TileSel all;
+    all.mode = 3;
+    return vcycle_up(ctx, h, b, nPost, alpha, x_out, 0, all);
+  }
   Level& l = h->lv[0];
   if (!(l.S && l.S->btd && l.S->A == l.A && l.tb && btd_fits(*l.S, nPost, 0)))
     return fail(ctx, AGGMG_ERR_UNSUPPORTED, "split ascent needs the fused block-tridiagonal fine level");
@@ -1884,6 +1934,22 @@ extern "C" int aggmg_vcycle_up_split_dev(aggmg_ctx* ctx, aggmg_hier* h, const do
   sel.head = head_elems;
   sel.tail = tail_elem;
   return vcycle_up(ctx, h, b, nPost, alpha, x_out, 0, sel);
+}
+
+extern "C" int aggmg_vcycle_up_coarse_dev(aggmg_ctx* ctx, aggmg_hier* h, const double* b, int nPost, double alpha, int part,
+                                          int64_t ghosts_lo, int64_t ghosts_hi) {
+  CHECK(vcycle_args(ctx, h, b, b, nPost, 0));
+  if (h->lv.size() < 4) return fail(ctx, AGGMG_ERR_UNSUPPORTED, "aggmg_vcycle_up_coarse_dev: needs two smoothed levels below the finest");
+  if ((part != 1 && part != 2) || ghosts_lo < 0 || ghosts_hi < 0)
+    return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_vcycle_up_coarse_dev: part is 1 (ends, then the rest) or 2 (middle)");
+  // (only hierarchies whose levels below the finest are ONE pair next to the coarsest level: the 4-level shape of the
+  // benchmarks; anything else keeps the unsplit ascent)
+  if (h->lv.size() != 4) return fail(ctx, AGGMG_ERR_UNSUPPORTED, "aggmg_vcycle_up_coarse_dev: hierarchy shape not supported");
+  CoarseSplit cs;
+  cs.mode = part;
+  cs.gh_lo = ghosts_lo;
+  cs.gh_hi = ghosts_hi;
+  return vcycle_up(ctx, h, b, nPost, alpha, nullptr, 1, TileSel(), cs);
 }
 
 extern "C" int aggmg_hier_set_restriction(aggmg_ctx* ctx, aggmg_hier* h, int mode) {

@@ -163,7 +163,7 @@ struct aggmg_dist {
   ncclComm_t comm_side = nullptr;
   // interface exchange of the next cycle's x0 under the fine-level ascent
   hipStream_t side = nullptr;
-  hipEvent_t ev_main = nullptr, ev_ends = nullptr, ev_side = nullptr;
+  hipEvent_t ev_main = nullptr, ev_ends = nullptr, ev_side = nullptr, ev_coarse = nullptr;
   const double* pending = nullptr;
   bool pending_in_place = false;
   int64_t exchanges = 0;
@@ -193,7 +193,7 @@ struct aggmg_dist {
       }
     for (auto& g : graphs)
       if (g.exec) (void)hipGraphExecDestroy(g.exec);
-    for (hipEvent_t e : {ev_main, ev_ends, ev_side})
+    for (hipEvent_t e : {ev_main, ev_ends, ev_side, ev_coarse})
       if (e) (void)hipEventDestroy(e);
     if (side) (void)hipStreamDestroy(side);
   }
@@ -457,7 +457,7 @@ extern "C" int aggmg_dist_create(aggmg_ctx* ctx, aggmg_hier* local, aggmg_hier* 
     }
   }
   HIPCHK(hipStreamCreateWithFlags(&d->side, hipStreamNonBlocking));
-  for (hipEvent_t* e : {&d->ev_main, &d->ev_ends, &d->ev_side}) HIPCHK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+  for (hipEvent_t* e : {&d->ev_main, &d->ev_ends, &d->ev_side, &d->ev_coarse}) HIPCHK(hipEventCreateWithFlags(e, hipEventDisableTiming));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   *out = d.release();
   return AGGMG_OK;
@@ -657,6 +657,7 @@ static int dist_vcycle_eager(aggmg_ctx* ctx, aggmg_dist* d, double* x0, const do
   const int nc = d->nl - 1;
   const int mc = d->m[nc];
   bool ghosts_valid = (flags & AGGMG_DIST_X0_GHOSTS_VALID) != 0;
+  bool coarse_done = false;   // the levels below the finest have been run already (split around the coarse ghost exchange)
   hipStream_t main = ctx->stream;
   if (d->pending) {
     // the exchange issued under the previous cycle's ascent (already joined to the main stream): use
@@ -686,7 +687,33 @@ static int dist_vcycle_eager(aggmg_ctx* ctx, aggmg_dist* d, double* x0, const do
     CHECK(dist_allgather(ctx, d, Z + clo * 2 * mc, Z, 2 * cnt));
     CHECK(coarse_boundary_solve_interleaved(ctx, d->Hc, Z, d->xq.p));
     CHECK(aggmg_coarse_chunk_backward_dev(ctx, d->Hc, own, blo, bhi, d->xq.p, sol_c + gl * mc));
-    CHECK(exchange_ghosts(ctx, d, sol_c, nc));
+    // The neighbours' ghost blocks of the coarsest solution are read by the end tiles of the ascent only: the exchange
+    // goes to the side stream and the tiles in between run under it (AGGMG_DIST_COARSE_OVERLAP=0: exchange first, as
+    // before r04).  Needs the levels below the finest as one two-level launch; anything else waits for the exchange.
+    static const bool coarse_overlap = [] {
+      const char* e = getenv("AGGMG_DIST_COARSE_OVERLAP");
+      return !(e && e[0] == '0');
+    }();
+    if (coarse_overlap && d->world > 1 && d->ex[1].count > 0) {
+      HIPCHK(hipEventRecord(d->ev_main, main));
+      HIPCHK(hipStreamWaitEvent(d->side, d->ev_main, 0));
+      ctx->stream = d->side;
+      int st = exchange_ghosts(ctx, d, sol_c, nc);
+      (void)hipEventRecord(d->ev_coarse, d->side);
+      ctx->stream = main;
+      CHECK(st);
+      const int64_t gh_lo = d->own_lo[nc] - d->loc_lo[nc], gh_hi = d->loc_hi[nc] - d->own_hi[nc];
+      st = aggmg_vcycle_up_coarse_dev(ctx, H, b, nPost, alpha, 2, gh_lo, gh_hi);     // the tiles that read no ghost block
+      HIPCHK(hipStreamWaitEvent(main, d->ev_coarse, 0));
+      if (st == AGGMG_OK) {
+        CHECK(aggmg_vcycle_up_coarse_dev(ctx, H, b, nPost, alpha, 1, gh_lo, gh_hi)); // the end tiles
+        coarse_done = true;
+      } else if (st != AGGMG_ERR_UNSUPPORTED) {
+        return st;
+      }
+    } else {
+      CHECK(exchange_ghosts(ctx, d, sol_c, nc));
+    }
   } else {
     CHECK(dist_allgather(ctx, d, own, d->rhs_g.p, own_c));
     // a one-level hierarchy's V-cycle IS the coarsest direct solve (src/solvers.jl:39)
@@ -699,7 +726,7 @@ static int dist_vcycle_eager(aggmg_ctx* ctx, aggmg_dist* d, double* x0, const do
     const int64_t gl0 = d->own_lo[0] - d->loc_lo[0];
     const int64_t head = gl0 + d->W[0];                                      // local elements [0, head)
     const int64_t tail = gl0 + (d->own_hi[0] - d->own_lo[0]) - d->W[0];      // [tail, end)
-    int st = aggmg_vcycle_up_split_dev(ctx, H, b, nPost, alpha, x_out, head, tail, 0);  // the coarser levels
+    int st = coarse_done ? AGGMG_OK : aggmg_vcycle_up_split_dev(ctx, H, b, nPost, alpha, x_out, head, tail, 0);  // the coarser levels
     if (st == AGGMG_OK) {
       // side stream: the tiles holding the interface elements, then their pack + all-gather
       HIPCHK(hipEventRecord(d->ev_main, main));
@@ -725,6 +752,7 @@ static int dist_vcycle_eager(aggmg_ctx* ctx, aggmg_dist* d, double* x0, const do
     }
     if (st != AGGMG_ERR_UNSUPPORTED) return st;  // (not a fused block-tridiagonal fine level: plain ascent)
   }
+  if (coarse_done) return aggmg_vcycle_up_split_dev(ctx, H, b, nPost, alpha, x_out, 0, 0, 3);   // the finest level alone
   return aggmg_vcycle_up_dev(ctx, H, b, nPost, alpha, x_out);
 }
 

@@ -46,6 +46,10 @@ struct PairArgs {
   int own;    // descent: level-b elements owned per tile (multiple of bc.rho); ascent: level-a elements (multiple of ab.rho)
   int te_a, te_b;
   int hb;     // ascent: level-b elements beyond the parents of the owned level-a range on each side = ceil(nsweeps / rho_a)
+  // ascent: tile of workgroup w = w + (w >= tile_split ? tile_skip : 0) -- a launch may cover the tiles at the two ends of
+  // the level (the ones that read ghost values of the coarser level) or the ones in between (fused_tile_subset)
+  int tile_split;
+  int64_t tile_skip;
 };
 
 // one level's operator rows of a thread: row i of the packed symmetric inverse, rows i of Sup_{e-1} and Sup_e turned
@@ -311,8 +315,9 @@ __global__ __launch_bounds__(NT) void btd_pair_up_kernel(PairArgs a) {
   const int tid = threadIdx.x;
   const int ns = a.nsweeps;
   const int rhoA = a.ab.rho, rhoB = a.bc.rho;
-  const int64_t Ea0 = (int64_t)blockIdx.x * a.own - ns;
-  const int64_t Eb0 = ((int64_t)blockIdx.x * a.own) / rhoA - a.hb - ns;
+  const int64_t tile = (int64_t)blockIdx.x + ((int)blockIdx.x >= a.tile_split ? a.tile_skip : 0);
+  const int64_t Ea0 = tile * a.own - ns;
+  const int64_t Eb0 = (tile * a.own) / rhoA - a.hb - ns;
 
   // ---------------- level b -------------------------------------------------------------------------------------
   {
@@ -355,7 +360,7 @@ __global__ __launch_bounds__(NT) void btd_pair_up_kernel(PairArgs a) {
     double* cur = b0;
     double* nxt = b1;
     pair_sweeps<MB, NSB, EPSB>(ns, a.alpha, le, i, valid, g, Pr, Qr, uu, cur, nxt);
-    const int64_t ob0 = ((int64_t)blockIdx.x * a.own) / rhoA, ob1 = ob0 + a.own / rhoA;   // the parents of the owned level-a range
+    const int64_t ob0 = (tile * a.own) / rhoA, ob1 = ob0 + a.own / rhoA;   // the parents of the owned level-a range
 #pragma unroll
     for (int s = 0; s < NSB; ++s) {
       const int x = s * EPSB + le;

@@ -286,9 +286,18 @@ int aggmg_vcycle_up_dev(aggmg_ctx* ctx, aggmg_hier* h, const double* b, int nPos
  * part 1 = the fine-level tiles holding elements [0, head_elems) and [tail_elem, ne), part 2 = the
  * remaining fine-level tiles.  Parts 1 and 2 do not depend on each other (they may be issued on
  * different streams, aggmg_set_stream); together they are bitwise aggmg_vcycle_up_dev.
- * AGGMG_ERR_UNSUPPORTED unless the fine level runs the fused block-tridiagonal kernel. */
+ * AGGMG_ERR_UNSUPPORTED unless the fine level runs the fused block-tridiagonal kernel.  part 3: the finest level alone,
+ * every tile, whatever kernel runs it (after the coarser levels went through part 0 or aggmg_vcycle_up_coarse_dev). */
 int aggmg_vcycle_up_split_dev(aggmg_ctx* ctx, aggmg_hier* h, const double* b, int nPost, double alpha,
                               double* x_out, int64_t head_elems, int64_t tail_elem, int part);
+/* The ascent below the finest level in two parts around the exchange of the coarsest solution's ghost blocks
+ * (element-partitioned runs; src/solvers.jl:41-47 for the levels between the coarsest and the finest): part 2 runs the
+ * tiles of the first launch that read none of the first ghosts_lo / last ghosts_hi elements of the coarsest level -- they
+ * can go while the neighbours' blocks are still travelling --, part 1 the remaining tiles at the two ends and the rest of
+ * those levels.  Both parts together = aggmg_vcycle_up_split_dev(part 0), bit for bit.  AGGMG_ERR_UNSUPPORTED unless
+ * the levels below the finest are one two-level launch next to the coarsest level (aggmg_hier_level_paired). */
+int aggmg_vcycle_up_coarse_dev(aggmg_ctx* ctx, aggmg_hier* h, const double* b, int nPost, double alpha, int part,
+                               int64_t ghosts_lo, int64_t ghosts_hi);
 int aggmg_hier_coarse_buffers(aggmg_ctx* ctx, aggmg_hier* h, void** rhs_dev, void** sol_dev,
                               int64_t* n);
 /* The device coarsest solve phase by phase, for element-partitioned runs: block cyclic reduction
