@@ -161,6 +161,7 @@ SYMBOLS = {
     "aggmg_dist_allgather_dev": (c_int, [_P, _P, _P, _P, c_int64]),
     "aggmg_dist_exchange_ghosts_dev": (c_int, [_P, _P, _P, c_int]),
     "aggmg_dist_vcycle_dev": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_double, c_int]),
+    "aggmg_dist_set_coarse_overlap": (c_int, [_P, _P, c_int]),
     "aggmg_dist_info": (c_int, [_P, _P, POINTER(c_int64), POINTER(c_int), POINTER(c_int)]),
     "aggmg_dist_graph_info": (c_int, [_P, _P, POINTER(c_int64), POINTER(c_int), POINTER(c_int)]),
     "aggmg_dot_dev": (c_int, [_P, _P, _P, c_int64, POINTER(c_double)]),

@@ -164,6 +164,7 @@ struct aggmg_dist {
   // interface exchange of the next cycle's x0 under the fine-level ascent
   hipStream_t side = nullptr;
   hipEvent_t ev_main = nullptr, ev_ends = nullptr, ev_side = nullptr, ev_coarse = nullptr;
+  bool coarse_overlap = [] { const char* e = getenv("AGGMG_DIST_COARSE_OVERLAP"); return e && e[0] == '1'; }();
   const double* pending = nullptr;
   bool pending_in_place = false;
   int64_t exchanges = 0;
@@ -641,6 +642,18 @@ extern "C" int aggmg_dist_exchange_ghosts_dev(aggmg_ctx* ctx, aggmg_dist* d, dou
   return exchange_ghosts(ctx, d, x_local, level);
 }
 
+extern "C" int aggmg_dist_set_coarse_overlap(aggmg_ctx* ctx, aggmg_dist* d, int on) {
+  if (!ctx || !d) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_dist_set_coarse_overlap: NULL argument");
+  d->coarse_overlap = on != 0;
+  for (auto& g : d->graphs)   // captured cycles hold the schedule they were captured with
+    if (g.exec) {
+      (void)hipGraphExecDestroy(g.exec);
+      g.exec = nullptr;
+      g.seen = 0;
+    }
+  return AGGMG_OK;
+}
+
 extern "C" int aggmg_dist_info(aggmg_ctx* ctx, const aggmg_dist* d, int64_t* exchanges, int* chunked, int* backend) {
   if (!ctx || !d) return AGGMG_ERR_ARGUMENT;
   if (exchanges) *exchanges = d->exchanges;
@@ -688,13 +701,11 @@ static int dist_vcycle_eager(aggmg_ctx* ctx, aggmg_dist* d, double* x0, const do
     CHECK(coarse_boundary_solve_interleaved(ctx, d->Hc, Z, d->xq.p));
     CHECK(aggmg_coarse_chunk_backward_dev(ctx, d->Hc, own, blo, bhi, d->xq.p, sol_c + gl * mc));
     // The neighbours' ghost blocks of the coarsest solution are read by the end tiles of the ascent only: the exchange
-    // goes to the side stream and the tiles in between run under it (AGGMG_DIST_COARSE_OVERLAP=0: exchange first, as
-    // before r04).  Needs the levels below the finest as one two-level launch; anything else waits for the exchange.
-    static const bool coarse_overlap = [] {
-      const char* e = getenv("AGGMG_DIST_COARSE_OVERLAP");
-      return !(e && e[0] == '0');
-    }();
-    if (coarse_overlap && d->world > 1 && d->ex[1].count > 0) {
+    // can go to the side stream and the tiles in between run under it (aggmg_dist_set_coarse_overlap; off by default:
+    // with loop-back stand-ins the extra launch and the two stream joins cost 9 us against the 5 us copy they hide, a
+    // real neighbour exchange of 15 - 25 us would pay -- bench.py times both in its warm-up and keeps the faster).
+    // Needs the levels below the finest as one two-level launch; anything else waits for the exchange.
+    if (d->coarse_overlap && d->world > 1 && d->ex[1].count > 0) {
       HIPCHK(hipEventRecord(d->ev_main, main));
       HIPCHK(hipStreamWaitEvent(d->side, d->ev_main, 0));
       ctx->stream = d->side;

@@ -707,6 +707,11 @@ class NativeDistributedVCycle:
             traceback.print_exc()
             return 1
 
+    def set_coarse_overlap(self, on):
+        """the exchange of the coarsest solution's ghost blocks under the middle tiles of the two-level ascent (C ABI
+        aggmg_dist_set_coarse_overlap); every rank must choose the same"""
+        self.ctx.check(self.ctx.lib.aggmg_dist_set_coarse_overlap(self.ctx.handle, self.handle, int(bool(on))))
+
     def info(self):
         ex, ch, be = ctypes.c_int64(0), ctypes.c_int(0), ctypes.c_int(0)
         self.ctx.check(self.ctx.lib.aggmg_dist_info(self.ctx.handle, self.handle, ctypes.byref(ex), ctypes.byref(ch), ctypes.byref(be)))
@@ -1110,6 +1115,32 @@ def bench_main(args, rank, world, local_rank, nPre, nPost, alpha, group=None):
         except Exception as exc:      # the check must never take the run down
             selfcheck = f"not completed ({exc!r})"
 
+    # Schedule choice measured, not assumed (untimed warm-up): the coarse ghost exchange under the two-level ascent's middle
+    # tiles trades an extra launch and two stream joins for the latency of one neighbour exchange -- 9 us lost against 5 us
+    # hidden with loop-back stand-ins, a gain where a real exchange takes 15 - 25 us.  Both are timed, the max over ranks of
+    # each compared, and every rank keeps the same one.
+    coarse_overlap = None
+    if isinstance(dv, NativeDistributedVCycle) and world > 1 and dv.chunked and os.environ.get("AGGMG_DIST_COARSE_OVERLAP") is None:
+        tune = {}
+        p_, q_ = engine.new(layout.local_dofs(0)), engine.new(layout.local_dofs(0))
+        for on in (0, 1):
+            dv.set_coarse_overlap(on)
+            for _ in range(3):
+                dv.vcycle(p_, b, q_, nPre, nPost, alpha, overlap_next=True)
+                p_, q_ = q_, p_
+            torch.cuda.synchronize()
+            comm.barrier()
+            t1 = time.perf_counter()
+            for _ in range(20):
+                dv.vcycle(p_, b, q_, nPre, nPost, alpha, overlap_next=True)
+                p_, q_ = q_, p_
+            torch.cuda.synchronize()
+            tune[on] = comm.max(time.perf_counter() - t1) / 20
+        keep = 1 if tune[1] < tune[0] else 0
+        dv.set_coarse_overlap(keep)
+        coarse_overlap = {"chosen": bool(keep), "ms_per_cycle_off": 1e3 * tune[0], "ms_per_cycle_on": 1e3 * tune[1]}
+        del p_, q_
+
     src, dst = xa, xb
     # every cycle's output is the next cycle's x0 (the loop of multigrid, src/solvers.jl:124-126):
     # its interface exchange is issued under the fine-level ascent.  AGGMG_DIST_GRAPH=1 lets the library
@@ -1175,6 +1206,7 @@ def bench_main(args, rank, world, local_rank, nPre, nPost, alpha, group=None):
                        "rccl_ranks": getattr(dv, "rccl_ranks", None),
                        "rccl_selfcheck": selfcheck,
                        "hipgraph": (dv.graph_info() if use_graph else None),
+                       "coarse_ghost_exchange_overlapped": coarse_overlap,
                        "parallelism": f"element-range x{world}, deep halos W={layout.W}, "
                                       f"{ex_per_cycle} exchanges per cycle (interface elements as grouped neighbour send/recv "
                                       f"straight between the vectors"

@@ -457,6 +457,12 @@ int aggmg_dist_vcycle_dev(aggmg_ctx* ctx, aggmg_dist* d, double* x0, const doubl
                           int nPost, double alpha, int flags);
 /* exchanges: all-gathers issued so far; chunked: 1 when the coarsest solve follows the partition;
  * backend: 0 none, 1 caller-supplied, 2 RCCL, 3 loop-back */
+/* Whether the exchange of the coarsest solution's ghost blocks runs on the side stream under the middle tiles of the
+ * two-level ascent (aggmg_vcycle_up_coarse_dev) instead of in front of it.  Off by default (environment
+ * AGGMG_DIST_COARSE_OVERLAP=1 makes it the default): it trades an extra launch and two stream joins for the latency of one
+ * neighbour exchange, which pays only where that latency is real -- callers time both (bench.py does, in its warm-up) and
+ * must choose the same on every rank.  Same results bit for bit either way. */
+int aggmg_dist_set_coarse_overlap(aggmg_ctx* ctx, aggmg_dist* d, int on);
 int aggmg_dist_info(aggmg_ctx* ctx, const aggmg_dist* d, int64_t* exchanges, int* chunked, int* backend);
 int aggmg_dist_graph_info(aggmg_ctx* ctx, const aggmg_dist* d, int64_t* replays, int* captured, int* broken);
 

@@ -474,8 +474,8 @@ def _thread_ranks(world, fn):
     return out
 
 
-@pytest.mark.parametrize("n,chunk_log2", [(2**16, None), (2**19, None), (2**16, 1)])
-def test_eight_ranks_config4_match_single_gpu(n, chunk_log2, monkeypatch):
+@pytest.mark.parametrize("n,chunk_log2,coarse_overlap", [(2**16, None, 0), (2**19, None, 0), (2**16, 1, 0), (2**19, None, 1), (2**16, None, 1)])
+def test_eight_ranks_config4_match_single_gpu(n, chunk_log2, coarse_overlap, monkeypatch):
     """BASELINE config 4 at the north-star world size: the config-3 hierarchy element-partitioned over EIGHT ranks (threads
     of one process sharing the GPU, the library's C++ schedule with host-staged collectives): first / last rank one-sided,
     six interior ranks with two neighbours, chunk-interleaved boundary system gathered from eight ranks.  Owned values after
@@ -489,6 +489,9 @@ def test_eight_ranks_config4_match_single_gpu(n, chunk_log2, monkeypatch):
     from agglomerationmultigrid1d_amd.uniform import UniformDgAggHierarchy, build_device_hierarchy
     if chunk_log2 is not None:
         monkeypatch.setenv("AGGMG_DIST_COARSE_CHUNK_LOG2", str(chunk_log2))
+    # coarse_overlap: the exchange of the coarsest solution's ghost blocks on the side stream under the middle tiles of the
+    # two-level ascent, the end tiles after it (aggmg_vcycle_up_coarse_dev) -- the same bits
+    monkeypatch.setenv("AGGMG_DIST_COARSE_OVERLAP", str(coarse_overlap))
     world, ratios, p = 8, (4, 2, 2), 3
     Ug = UniformDgAggHierarchy(n, p=p, pAgg=1, ratios=ratios)
     ctx2 = mg.Context(0)
