@@ -22,10 +22,11 @@ SWEEPS = {"sweeps_1_per_launch": 1, "residual": 0, "sweeps_4_per_launch": 4, "sw
 
 
 def rows(sub, pat):
-    f = sorted(glob.glob(os.path.join(src, sub, "**", pat), recursive=True))
+    # (gpurun merges a call's outputs INTO the local directory: an earlier run's files -- other pids -- may still lie there)
+    f = sorted(glob.glob(os.path.join(src, sub, "**", pat), recursive=True), key=os.path.getmtime)
     if not f:
         raise SystemExit(f"no {pat} under {src}/{sub}")
-    return list(csv.DictReader(open(f[0])))
+    return list(csv.DictReader(open(f[-1])))   # the newest
 
 
 def phases(seq, key):
