@@ -428,7 +428,11 @@ static int launch_csr(aggmg_ctx* ctx, const CsrDev& A, const double* x, const do
   static const bool rowthread = cr_env_int_early("AGGMG_CSR_ROWTHREAD", 1) != 0;
   if (rowthread && A.maxrow >= 0 && A.maxrow <= kRowThreadMax && A.nrows < ((int64_t)1 << 31) * kThreads) {
     const unsigned nb = (unsigned)((A.nrows + kThreads - 1) / kThreads);
-    hipLaunchKernelGGL((csr_rowthread_kernel<MODE>), dim3(nb), dim3(kThreads), 0, ctx->stream, A.view(), x, b, dg, alpha, y);
+    static const bool bandrow = cr_env_int_early("AGGMG_CSR_BANDROW", 1) != 0;
+    if (bandrow && A.bw >= 0 && A.bw <= kBandMaxBw && A.nrows == A.ncols && y != x)   // banded: the x window through LDS
+      hipLaunchKernelGGL((csr_rowthread_band_kernel<MODE>), dim3(nb), dim3(kThreads), 0, ctx->stream, A.view(), A.bw, x, b, dg, alpha, y);
+    else
+      hipLaunchKernelGGL((csr_rowthread_kernel<MODE>), dim3(nb), dim3(kThreads), 0, ctx->stream, A.view(), x, b, dg, alpha, y);
     HIPCHK(hipGetLastError());
     return AGGMG_OK;
   }

@@ -172,6 +172,52 @@ __global__ __launch_bounds__(kThreads) void csr_rowthread_kernel(CsrView A, cons
   }
 }
 
+// The same for square operators whose entries lie within bw <= kBandMaxBw of the diagonal (every DG / agglomerated
+// operator in its own numbering): the window of x a workgroup's 256 rows reach is read ONCE, coalesced, into LDS and
+// the per-entry gathers x[col] -- a third of the kernel's vector-memory instructions -- become LDS reads.  Same
+// arithmetic, same bits.
+template <int MODE>
+__global__ __launch_bounds__(kThreads) void csr_rowthread_band_kernel(CsrView A, int bw, const double* __restrict__ x,
+                                                                      const double* __restrict__ b,
+                                                                      const double* __restrict__ dg, double alpha,
+                                                                      double* __restrict__ y) {
+  __shared__ double xw[kThreads + 2 * 32];   // kBandMaxBw = 32 (defined below)
+  const int64_t r0 = (int64_t)blockIdx.x * kThreads;
+  const int64_t w0 = r0 - bw > 0 ? r0 - bw : 0;
+  const int64_t w1 = r0 + kThreads + bw < A.nrows ? r0 + kThreads + bw : A.nrows;
+  for (int64_t w = w0 + threadIdx.x; w < w1; w += kThreads) xw[w - w0] = x[w];
+  __syncthreads();
+  const int64_t row = r0 + threadIdx.x;
+  if (row >= A.nrows) return;
+  const int p0 = A.rowptr[row], p1 = A.rowptr[row + 1];
+  double acc = 0.0;
+  {
+#pragma clang fp contract(off)
+    int p = p0;
+    for (; p + 3 < p1; p += 4) {
+      const int c0 = A.colind[p], c1 = A.colind[p + 1], c2 = A.colind[p + 2], c3 = A.colind[p + 3];
+      const double v0 = A.vals[p], v1 = A.vals[p + 1], v2 = A.vals[p + 2], v3 = A.vals[p + 3];
+      const double t0 = v0 * xw[c0 - w0], t1 = v1 * xw[c1 - w0], t2 = v2 * xw[c2 - w0], t3 = v3 * xw[c3 - w0];
+      acc = acc + t0;
+      acc = acc + t1;
+      acc = acc + t2;
+      acc = acc + t3;
+    }
+    for (; p < p1; ++p) {
+      const double t = A.vals[p] * xw[A.colind[p] - w0];
+      acc = acc + t;
+    }
+  }
+  if (MODE == kSpmvSet) y[row] = acc;
+  if (MODE == kSpmvAdd) y[row] += acc;
+  if (MODE == kResidual) y[row] = b[row] - acc;
+  if (MODE == kJacobi) {
+    const double r = b[row] - acc;
+    const double yy = r / dg[row];
+    y[row] = xw[row - w0] + alpha * yy;
+  }
+}
+
 // "CSR-band" variant: the same streaming pattern for square operators whose entries all lie within `bw` of the
 // diagonal (every DG / agglomerated operator of the reference in its own numbering; detected on the device at
 // upload).  A workgroup owns a run of rows plus S * bw rows of halo on either side and
@@ -184,7 +230,8 @@ __global__ __launch_bounds__(kThreads) void csr_rowthread_kernel(CsrView A, cons
 // launch give bit for bit what S launches give.  Row blocks (bandblk) are cut on the host so that the entries of a
 // block and its halo rows fit `prod` and its window fits kBandWin.
 constexpr int kBandSweeps = 4;   // most sweeps per launch (halo sized for it)
-constexpr int kBandMaxBw = 32;   // widest band the window kernel takes
+constexpr int kBandMaxBw = 32;   // widest band the window kernels take (csr_rowthread_band_kernel sizes its LDS for it)
+static_assert(kBandMaxBw == 32, "csr_rowthread_band_kernel's window");
 constexpr int kBandWin = 4 * kThreads + 2 * kBandSweeps * kBandMaxBw;
 template <int MODE>
 __global__ __launch_bounds__(kThreads) void csr_band_kernel(CsrView A, const int32_t* __restrict__ bandblk, int bw, int S,
