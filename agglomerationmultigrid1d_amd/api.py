@@ -931,6 +931,10 @@ def multigrid_v_cycle(H, x0, b, nPre=3, nPost=3, alpha=2.0 / 3.0, out=None):
     by DMA instead of staging them."""
     if not isinstance(nPre, (int, np.integer)) or not isinstance(nPost, (int, np.integer)):
         raise TypeError("nPre / nPost must be integers (nPre::Integer, src/solvers.jl:20)")
+    if x0 is None and isinstance(b, DeviceVector):      # zero initial guess (ldiv!): nothing is read for it
+        out = H.ctx.alloc(b.n)
+        H.vcycle_dev(None, b, out, int(nPre), int(nPost), float(alpha))
+        return out
     if isinstance(x0, DeviceVector) and isinstance(b, DeviceVector):
         # vectors already in HBM: nothing crosses PCIe, a new DeviceVector comes back (aggmg_vcycle_dev) -- the form
         # for callers that loop; host arrays cost 3 * 8 * N bytes of PCIe per call (bench.py: pcie_inclusive)
@@ -940,19 +944,19 @@ def multigrid_v_cycle(H, x0, b, nPre=3, nPost=3, alpha=2.0 / 3.0, out=None):
         out = H.ctx.alloc(N)
         H.vcycle_dev(x0, b, out, int(nPre), int(nPost), float(alpha))
         return out
-    x0 = _f64(x0)
+    x0 = None if x0 is None else _f64(x0)     # None: a zero initial guess (what ldiv! uses), no vector of zeros sent
     b = _f64(b)
     N = H._ops[0].shape[0]
-    if x0.shape != (N,) or b.shape != (N,):
+    if (x0 is not None and x0.shape != (N,)) or b.shape != (N,):
         raise DimensionMismatch("multigrid_v_cycle: x0 / b do not match the fine operator")
     if out is None:
         out = np.empty(N)
     elif not (isinstance(out, np.ndarray) and out.dtype == np.float64 and out.shape == (N,) and out.flags["C_CONTIGUOUS"]):
         raise DimensionMismatch("multigrid_v_cycle: out must be a contiguous float64 array of the fine operator's size")
-    elif np.shares_memory(out, x0) or np.shares_memory(out, b):
+    elif (x0 is not None and np.shares_memory(out, x0)) or np.shares_memory(out, b):
         raise ArgumentError("multigrid_v_cycle: out must not alias x0 or b (they are not modified)")
     c = H.ctx
-    c.check(c.lib.aggmg_vcycle(c.handle, H.handle, _pd(x0), _pd(b), int(nPre), int(nPost), float(alpha),
+    c.check(c.lib.aggmg_vcycle(c.handle, H.handle, None if x0 is None else _pd(x0), _pd(b), int(nPre), int(nPost), float(alpha),
                                _pd(out)))
     return out
 
@@ -968,11 +972,7 @@ def ldiv(*args):
     else:
         raise TypeError("ldiv(H, b) or ldiv(y, H, b)")
     N = H._ops[0].shape[0]
-    u0 = H.__dict__.get("_zero_guess")        # the zero initial guess, page-locked once per hierarchy
-    if u0 is None or u0.size != N:
-        u0 = H.ctx.pinned_empty(N)
-        u0[:] = 0.0
-        H.__dict__["_zero_guess"] = u0
+    u0 = None        # zero initial guess: aggmg_vcycle(x0 = NULL), no vector of zeros crosses PCIe
     direct = (y is not b and isinstance(y, np.ndarray) and y.dtype == np.float64 and y.shape == (N,) and y.flags["C_CONTIGUOUS"]
               and not np.shares_memory(y, np.asarray(b)))
     if direct:      # straight into y: with y and b page-locked (Context.pin) nothing is staged

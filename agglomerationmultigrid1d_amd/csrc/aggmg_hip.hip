@@ -1771,7 +1771,9 @@ static int vcycle_args(aggmg_ctx* ctx, aggmg_hier* h, const void* a, const void*
 
 extern "C" int aggmg_vcycle_dev(aggmg_ctx* ctx, aggmg_hier* h, const double* x0, const double* b, int nPre,
                                 int nPost, double alpha, double* x_out) {
-  CHECK(vcycle_args(ctx, h, x0, b, nPre, nPost));
+  // x0 == NULL: zero initial guess (ldiv!, src/solvers.jl:63-92) -- the fine level starts from zeros like every other
+  // level does (:29-31) and reads no iterate at all
+  CHECK(vcycle_args(ctx, h, x0 ? x0 : b, b, nPre, nPost));
   if (!x_out) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_vcycle: NULL argument");
   if (x_out == x0 || x_out == b) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_vcycle: x_out must not alias x0 or b");
   if (h->coarse_mode == AGGMG_COARSE_EXTERNAL)
@@ -2135,19 +2137,23 @@ int stage_copy(aggmg_ctx* ctx, bool to_device, int nvec_in, double* const* dev_i
 extern "C" int aggmg_vcycle(aggmg_ctx* ctx, aggmg_hier* h, const double* x0, const double* b, int nPre, int nPost,
                             double alpha, double* x_out) {
   if (!ctx) return AGGMG_ERR_ARGUMENT;
-  if (!h || !x0 || !b || !x_out) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_vcycle: NULL argument");
+  if (!h || !b || !x_out) return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_vcycle: NULL argument");
   HIPCHK(hipSetDevice(ctx->device));
   const int64_t N = h->lv[0].N;
   const size_t bytes = (size_t)N * sizeof(double);
   // the three device vectors of the host-pointer entry live with the hierarchy (no allocation per call)
   for (double*& p : h->io)
     if (!p) HIPCHK(hipMalloc((void**)&p, std::max<size_t>(bytes, 8)));
-  {
+  if (x0) {
     double* dv[2] = {h->io[0], h->io[1]};
     double* hv[2] = {const_cast<double*>(x0), const_cast<double*>(b)};
     CHECK(stage_copy(ctx, true, 2, dv, hv, bytes));
+  } else {   // zero initial guess (ldiv!): one vector less over PCIe
+    double* dv[1] = {h->io[1]};
+    double* hv[1] = {const_cast<double*>(b)};
+    CHECK(stage_copy(ctx, true, 1, dv, hv, bytes));
   }
-  CHECK(aggmg_vcycle_dev(ctx, h, h->io[0], h->io[1], nPre, nPost, alpha, h->io[2]));
+  CHECK(aggmg_vcycle_dev(ctx, h, x0 ? h->io[0] : nullptr, h->io[1], nPre, nPost, alpha, h->io[2]));
   {
     double* dv[1] = {h->io[2]};
     double* hv[1] = {x_out};
@@ -2556,7 +2562,7 @@ extern "C" int aggmg_pcg_dev(aggmg_ctx* ctx, aggmg_hier* h, const double* b, dou
   CHECK(read_scalar(ctx, sc + 13, &nb));
   *n_iters = 0;
   CHECK(aggmg_residual_dev(ctx, A, x_inout, b, r));                       // r = b - A x
-  CHECK(aggmg_vcycle_dev(ctx, h, zero, r, nPre, nPost, alpha, z));        // z = M^-1 r  (ldiv!)
+  CHECK(aggmg_vcycle_dev(ctx, h, nullptr, r, nPre, nPost, alpha, z));     // z = M^-1 r  (ldiv!: zero initial guess)
   HIPCHK(hipMemcpyAsync(pv, z, N * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
   CHECK(dev_dot(ctx, N, r, z, sc + 0, 0));
   for (int it = 0; it < maxiter; ++it) {
@@ -2569,7 +2575,7 @@ extern "C" int aggmg_pcg_dev(aggmg_ctx* ctx, aggmg_hier* h, const double* b, dou
     res_hist[it] = res;
     *n_iters = it + 1;
     if (res < tol * nb) break;
-    CHECK(aggmg_vcycle_dev(ctx, h, zero, r, nPre, nPost, alpha, z));
+    CHECK(aggmg_vcycle_dev(ctx, h, nullptr, r, nPre, nPost, alpha, z));
     CHECK(dev_dot(ctx, N, r, z, sc + 2, 0));
     hipLaunchKernelGGL(pcg_p_kernel, dim3(grid), dim3(kThreads), 0, ctx->stream, N, pv, (const double*)z,
                        (const double*)(sc + 2), (const double*)(sc + 0));

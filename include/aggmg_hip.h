@@ -244,7 +244,10 @@ int aggmg_hier_create(aggmg_ctx* ctx, int nlevels, aggmg_op* const* stiffness,
                       int coarse_mode, aggmg_hier** out);
 int aggmg_hier_free(aggmg_ctx* ctx, aggmg_hier* h);
 /* multigrid_v_cycle(H, x0, b; nPre, nPost, alpha) -> x    src/solvers.jl:19-50.
- * x0 and b are not modified (src/solvers.jl:25-26); x_out may alias neither. */
+ * x0 and b are not modified (src/solvers.jl:25-26); x_out may alias neither.
+ * x0 == NULL: a zero initial guess -- ldiv!(H, b) / ldiv!(y, H, b), src/solvers.jl:63-92 -- without a vector of zeros
+ * being sent (host form: one transfer less) or read (the finest level then starts from zeros like the others, :29-31);
+ * the same bits as passing zeros. */
 int aggmg_vcycle(aggmg_ctx* ctx, aggmg_hier* h, const double* x0, const double* b, int nPre,
                  int nPost, double alpha, double* x_out);
 int aggmg_vcycle_dev(aggmg_ctx* ctx, aggmg_hier* h, const double* x0, const double* b, int nPre,

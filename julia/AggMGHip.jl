@@ -365,10 +365,9 @@ end
 # ldiv!(y, H, b) with y, b in HBM: one V-cycle from a zero guess written into y (y must not be b: the entry point
 # refuses aliased output; ldiv!(H, b) for a DeviceVector goes through a fresh vector and swaps the storage)
 function la.ldiv!(y::DeviceVector, Hd::DeviceHierarchy, b::DeviceVector)
-    z = DeviceVector(Hd.ctx, b.n)                       # zeroed by aggmg_dev_alloc
-    GC.@preserve z b y check(Hd.ctx.h, ccall((:aggmg_vcycle_dev, LIB), Cint,
+    GC.@preserve b y check(Hd.ctx.h, ccall((:aggmg_vcycle_dev, LIB), Cint,      # x0 = C_NULL: zero initial guess
         (Handle, Handle, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Cint, Float64, Ptr{Cvoid}),
-        Hd.ctx.h, Hd.h, z.p, b.p, 3, 3, 2.0 / 3.0, y.p))
+        Hd.ctx.h, Hd.h, C_NULL, b.p, 3, 3, 2.0 / 3.0, y.p))
     return
 end
 function la.ldiv!(Hd::DeviceHierarchy, b::DeviceVector)
@@ -389,10 +388,10 @@ end
 # vectors of a Krylov loop that calls ldiv! every iteration -- the call moves them by DMA instead of staging them
 function la.ldiv!(y::Vector{Float64}, Hd::DeviceHierarchy, b::Vector{Float64})
     (length(y) == length(b)) || throw(DimensionMismatch("ldiv!: y and b differ in length"))
-    z = zero_guess(Hd, length(b))
-    GC.@preserve z b y check(Hd.ctx.h, ccall((:aggmg_vcycle, LIB), Cint,
+    # x0 = C_NULL: the zero initial guess of ldiv! (include/aggmg_hip.h) -- no vector of zeros is sent
+    GC.@preserve b y check(Hd.ctx.h, ccall((:aggmg_vcycle, LIB), Cint,
         (Handle, Handle, Ptr{Float64}, Ptr{Float64}, Cint, Cint, Float64, Ptr{Float64}),
-        Hd.ctx.h, Hd.h, z, b, 3, 3, 2.0 / 3.0, y))
+        Hd.ctx.h, Hd.h, Ptr{Float64}(C_NULL), b, 3, 3, 2.0 / 3.0, y))
     return
 end
 
@@ -409,17 +408,6 @@ function unpin!(ctx::Context, v::Vector{Float64})
     GC.@preserve v check(ctx.h, ccall((:aggmg_host_unregister, LIB), Cint, (Handle, Ptr{Cvoid}), ctx.h, pointer(v)))
     delete!(PINNED, v)
     return v
-end
-# the zero initial guess of ldiv!, page-locked once per (hierarchy, length)
-const ZERO_GUESS = IdDict{Any,Vector{Float64}}()
-function zero_guess(Hd::DeviceHierarchy, n::Integer)
-    z = get(ZERO_GUESS, Hd, nothing)
-    if z === nothing || length(z) != n
-        z = zeros(n)
-        pin!(Hd.ctx, z)
-        ZERO_GUESS[Hd] = z
-    end
-    return z
 end
 
 # `A \\ b` of a device operator -- the fine-level direct solve behind the reference's `err` histories

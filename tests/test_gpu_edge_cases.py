@@ -345,3 +345,28 @@ def test_page_locked_host_vectors(oracle, mg):
     assert np.array_equal(mg.multigrid_v_cycle(H, xp, bp, out=out), ref)   # bp is pageable again: staged
     with pytest.raises(mg.ArgumentError):
         mg.multigrid_v_cycle(H, xp, bp, out=xp)              # the result must not alias an input
+
+
+def test_null_initial_guess_is_a_vector_of_zeros(oracle, mg):
+    """aggmg_vcycle / aggmg_vcycle_dev with x0 = NULL -- ldiv!'s zero initial guess (src/solvers.jl:63-92) without a vector of
+    zeros being sent or read -- gives the bits of passing zeros: fused block-tridiagonal, chain and generic fine levels, host
+    and device forms; ldiv and the preconditioned CG loop go through it"""
+    o = oracle
+    for Ho, b, kw in ((*o.build_dg_agg_hierarchy(128, p=3, pAgg=1, nAgg=3, first=4), {}),
+                      (*o.build_cg_hierarchy(64, ps=(4, 2, 1), nDG=1, pDG=0), {}),
+                      (*o.build_dg_p_hierarchy(32, ps=(4, 2, 1)), {})):
+        H = mg.MeshHierarchy.from_reference(Ho)
+        ctx = H.ctx
+        N = len(b)
+        ref = mg.multigrid_v_cycle(H, np.zeros(N), b)
+        assert np.array_equal(mg.multigrid_v_cycle(H, None, b), ref)
+        bd = ctx.to_device(b)
+        assert np.array_equal(mg.multigrid_v_cycle(H, None, bd).download(), ref)
+        y = np.empty(N)
+        mg.ldiv(y, H, b)
+        assert np.array_equal(y, ref)
+        b2 = b.copy()
+        mg.ldiv(H, b2)
+        assert np.array_equal(b2, ref)
+        xr = o.multigrid_v_cycle(Ho, np.zeros(N), b)
+        assert np.linalg.norm(Ho.mStiffness[0] @ (ref - xr)) <= 1e-12 * np.linalg.norm(b)
