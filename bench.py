@@ -704,10 +704,18 @@ def main():
                     tp.append(time.perf_counter() - t2)
                     xp, yp = yp, xp
                 tpm = statistics.median(tp)
+                tl = []
+                for _ in range(5):      # ldiv!(y, H, b): zero initial guess (x0 = NULL), two transfers
+                    t2 = time.perf_counter()
+                    mg.ldiv(yp, H, bp)
+                    tl.append(time.perf_counter() - t2)
+                tlm = statistics.median(tl)
                 ctx.unpin(bp)
                 pcie = {"value": N * (nPre + nPost) / tm, "unit": "DoF-updates/s", "ms_per_call": 1e3 * tm,
                         "pinned": {"value": N * (nPre + nPost) / tpm, "ms_per_call": 1e3 * tpm, "effective_GBs": 3 * 8 * N / tpm / 1e9,
-                                   "note": "x0, b, x_out page-locked once by the caller (Context.pin / pinned_empty), result array reused"},
+                                   "note": "x0, b, x_out page-locked once by the caller (Context.pin / pinned_empty), result array reused",
+                                   "ldiv_ms_per_call": 1e3 * tlm,
+                                   "ldiv_note": "ldiv!(y, H, b) on the same arrays: the zero initial guess is not sent (x0 = NULL)"},
                         "host_bytes_per_call": 3 * 8 * N, "effective_GBs": 3 * 8 * N / tm / 1e9,
                         "note": "multigrid_v_cycle(H, x0, b) on host arrays (aggmg_vcycle): x0, b copied in and a NEW result "
                                 "array copied out on every call, pageable memory staged through pinned chunks by 4 "
