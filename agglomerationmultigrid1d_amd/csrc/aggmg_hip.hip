@@ -963,6 +963,19 @@ extern "C" int aggmg_smoother_apply(aggmg_ctx* ctx, aggmg_smoother* sm, const do
       // alpha * (Diagonal \ B): reuse the scaled-axpy kernel with counts := diag
       hipLaunchKernelGGL(axpy_scaled_kernel, dim3(nb2), dim3(kThreads), 0, ctx->stream, N, (const double*)nullptr,
                          bc, (const double*)sm->diag, alpha, yc);
+    } else if (sm->overlapping) {
+      // overlapping lists (additive / hybrid Schwarz, src/smoother.jl:6-46): the block results kept apart, then added
+      // up per row in list order -- no atomics, the same bits run to run (r03: atomic adds into a zeroed vector)
+      CHECK(setup_block_cover(ctx, sm));
+      double* Yf = nullptr;
+      CHECK(scratch(ctx, 1, std::max<int64_t>(N, sm->nb * sm->m), &Yf));
+      const unsigned nblk = (unsigned)((sm->nb * sm->m + kThreads - 1) / kThreads);
+      if (nblk)
+        hipLaunchKernelGGL(block_apply_flat_kernel, dim3(nblk), dim3(kThreads), 0, ctx->stream, sm->binv, sm->inds, (int)sm->m,
+                           sm->nb, bc, Yf);
+      hipLaunchKernelGGL(block_combine_kernel, dim3(nb2), dim3(kThreads), 0, ctx->stream, N, (const int32_t*)sm->cover_ptr,
+                         (const uint32_t*)sm->cover_idx, (const double*)Yf, (const double*)nullptr,
+                         sm->kind == 2 ? (const double*)sm->counts : (const double*)nullptr, alpha, yc);
     } else {
       HIPCHK(hipMemsetAsync(dT.p, 0, N * sizeof(double), ctx->stream));
       const unsigned nblk = (unsigned)((sm->nb * sm->m + kThreads - 1) / kThreads);

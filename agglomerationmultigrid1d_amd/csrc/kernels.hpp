@@ -384,7 +384,7 @@ __global__ __launch_bounds__(kThreads) void block_sweep_kernel(CsrView A, const 
 
 // out[row] = u[row] + alpha * (sum of the Y entries covering the row) / (cnt ? cnt[row] : 1); the covering entries of a
 // row (cover_ptr / cover_idx: flat indices block * m + i, ascending) come from the smoother's index lists, rows in no
-// block keep their value.  out may alias u.
+// block keep their value (u null: zero).  out may alias u.
 static __global__ __launch_bounds__(kThreads) void block_combine_kernel(int64_t n, const int32_t* __restrict__ cover_ptr,
                                                                         const uint32_t* __restrict__ cover_idx,
                                                                         const double* __restrict__ Y, const double* u,
@@ -395,7 +395,23 @@ static __global__ __launch_bounds__(kThreads) void block_combine_kernel(int64_t 
   for (int q = cover_ptr[row]; q < cover_ptr[row + 1]; ++q) v += Y[cover_idx[q]];
   if (cnt) v = v / cnt[row];
   v = alpha * v;
-  out[row] = u[row] + v;
+  out[row] = u ? u[row] + v : v;
+}
+
+// Y[block * m + i] = (Binv_block r[inds_block])_i : the block results of overlapping lists kept apart, for
+// block_combine_kernel to add up in list order (apply_smoother of the Schwarz smoothers without atomics)
+static __global__ __launch_bounds__(kThreads) void block_apply_flat_kernel(const double* __restrict__ binv,
+                                                                           const int32_t* __restrict__ inds, int m, int64_t nb,
+                                                                           const double* __restrict__ r, double* __restrict__ Y) {
+  const int64_t t = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  const int64_t blk = t / m;
+  const int i = (int)(t - blk * m);
+  if (blk >= nb) return;
+  const double* Bi = binv + (blk * m + i) * m;
+  const int32_t* id = inds + blk * m;
+  double acc = 0.0;
+  for (int j = 0; j < m; ++j) acc += Bi[j] * r[id[j]];
+  Y[t] = acc;
 }
 
 // out = (u ? u : 0) + alpha * (y / (cnt ? cnt : 1)); out may alias u (block smoothers update in place)

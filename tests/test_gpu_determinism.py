@@ -93,3 +93,24 @@ def test_two_runs_from_scratch_agree_bitwise(mg, name):
     assert kinds == kinds_want, kinds
     for u, v in zip(a, b):
         assert np.all(np.isfinite(u)) and np.array_equal(u, v), (name, float(np.max(np.abs(u - v))))
+
+
+@pytest.mark.parametrize("kind", ["addSchwarz", "hybridSchwarz"])
+def test_apply_smoother_on_overlapping_lists_is_reproducible(mg, kind):
+    """apply_smoother of the Schwarz smoothers (src/smoother.jl:6-46) adds the results of overlapping blocks per row in list
+    order (r03: atomic adds into a zeroed vector): two contexts, blocks listed in different random orders -- the same bits
+    (the blocks are sorted once, so the listing order does not matter either)"""
+    from agglomerationmultigrid1d_amd import _lib
+    from agglomerationmultigrid1d_amd.uniform import UniformCgDgHierarchy
+    U = UniformCgDgHierarchy(2**12, ps=(4,))
+    A, el = U.A[0], U.element_nodes(0)
+    B = np.random.default_rng(0).standard_normal((A.shape[0], 3))
+    outs = []
+    for seed in (1, 2):
+        ctx = mg.Context(0)
+        op = mg.DeviceOperator(A, _lib.OP_STIFFNESS, ctx)
+        perm = np.random.default_rng(seed).permutation(el.shape[1])
+        cls = {"addSchwarz": mg.AdditiveSchwarzSmoother, "hybridSchwarz": mg.HybridSchwarzSmoother}[kind]
+        S = cls(op, np.ascontiguousarray(el[:, perm]), ctx)
+        outs.append(mg.apply_smoother(S, B, alpha=0.7))
+    assert np.array_equal(outs[0], outs[1])
