@@ -747,6 +747,13 @@ def main():
         if k_ in R["comp_all"]:
             v_["compulsory_bytes"] = R["comp_all"][k_]
             v_["frac"] = R["comp_all"][k_] / (v_["ms_per_launch"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+            # PMC bytes of the same launch role (profiles/traffic.json; a two-level launch is filed as pair_*)
+            kd_, lv_ = k_.split("_")[1], int(k_.rsplit("L", 1)[1])
+            role_ = ("pair_" if lv_ in R["paired"].get(kd_, []) else "fused_") + f"{kd_}_L{lv_}"
+            t_ = _traffic(role_, f"dg_log2n{args.log2_elems}")
+            if t_:
+                v_["traffic"] = t_
+                v_["physical_frac"] = t_ / (v_["ms_per_launch"] * 1e-3) / 1e9 / HBM_PEAK_GBS
     coarse_dev = [v["ms_per_launch"] for k, v in kern_ms.items() if k.startswith("coarse_")]
     coarse_step_ms = coarse_dev[0] if coarse_dev else 0.0
     out = {

@@ -157,7 +157,7 @@ for nm in names:
         ck = f"coarse_{kind}_log2n{E}"
         traffic[ck] = traffic.get(ck, 0.0) + hb
         traffic[ck + "_ms_profile_mean"] = traffic.get(ck + "_ms_profile_mean", 0.0) + statistics.mean(vals)
-    if hb is not None and nm.startswith("fused_"):
+    if hb is not None and (nm.startswith("fused_") or nm.startswith("pair_")):
         key = nm.replace("fused_", "chain_") if kind == "cg" else nm
         traffic[f"{key}_{kind}_log2n{E}"] = hb
         traffic[f"{key}_{kind}_log2n{E}_ms_profile_mean"] = statistics.mean(vals)   # the kernel-trace mean of the same role
