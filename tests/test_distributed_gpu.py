@@ -599,3 +599,51 @@ def test_bench_eight_ranks_rehearsal(dist_config):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 8 and d["steps"] == 3 and d["scaling"] == "strong" and d["value"] > 0
     assert d["config"]["backend"] == "threads" and "rehearsal" in d and d["roofline"]["frac"] <= 1.0
+
+
+@pytest.mark.parametrize("world,n,p,ratios,sweeps", [(8, 2**15, 2, (2, 2, 2), (2, 1)), (6, 6 * 2**12, 3, (4, 2), (3, 3)),
+                                                    (5, 5 * 2**12, 1, (4, 4, 2), (1, 1)), (8, 2**17, 3, (4, 2, 2), (4, 4))])
+def test_thread_ranks_other_shapes_match_single_gpu(world, n, p, ratios, sweeps):
+    """the partitioned cycle away from the benchmark shape: other degrees, ratios, level counts, sweep counts (ghost layers
+    sized from them) and world sizes that are not powers of two -- ranks as threads sharing the GPU, the library's schedule
+    with the coarse ghost exchange in its default place, owned values bitwise those of the single-GPU cycle"""
+    import torch
+    import agglomerationmultigrid1d_amd as mg
+    from agglomerationmultigrid1d_amd import distributed as D
+    from agglomerationmultigrid1d_amd.uniform import UniformDgAggHierarchy, build_device_hierarchy
+    nPre, nPost = sweeps
+    alpha = 0.8
+    Ug = UniformDgAggHierarchy(n, p=p, pAgg=1, ratios=ratios)
+    ctx2 = mg.Context(0)
+    Hg = build_device_hierarchy(Ug, ctx2)
+    bg = ctx2.to_device(Ug.rhs())
+    xa, xb = ctx2.to_device(np.zeros(len(Ug.rhs()))), ctx2.alloc(len(Ug.rhs()))
+    for _ in range(3):
+        Hg.vcycle_dev(xa, bg, xb, nPre, nPost, alpha)
+        xa, xb = xb, xa
+    ref = xa.download()
+    Hg.free()
+
+    def rank_fn(rank, comm):
+        ctx = mg.Context(0)
+        layout = D.RankLayout(n, ratios, [p + 1] + [2] * len(ratios), world, rank, nPre, nPost)
+        engine, U = D.build_local_uniform(n, p, 1, ratios, layout, ctx, comm)
+        dv = D.NativeDistributedVCycle(engine, layout, comm, collectives="torch")
+        b = torch.from_numpy(U.rhs()).to(engine.dev)
+        x, y = engine.new(layout.local_dofs(0)), engine.new(layout.local_dofs(0))
+        for _ in range(3):
+            dv.vcycle(x, b, y, nPre, nPost, alpha, overlap_next=True)
+            x, y = y, x
+        torch.cuda.synchronize()
+        got = x.cpu().numpy()[layout.owned_slice(0)]
+        lo, hi = layout.own[0]
+        ref_own = ref[lo * (p + 1):hi * (p + 1)]
+        res = (float(np.max(np.abs(got - ref_own))), float(np.max(np.abs(ref_own))), dv.chunked)
+        comm.barrier()
+        dv.free()
+        return res
+
+    for rank, (err, scale, chunked) in enumerate(_thread_ranks(world, rank_fn)):
+        # (a replicated coarsest solve and the single-GPU one take the same launches: bitwise; a chunked one plans its chunks
+        # for the partition: equal to the accuracy of the coarsest solves)
+        assert err == 0.0 or (chunked and err <= 1e-9 * scale), (rank, err, scale, chunked)
