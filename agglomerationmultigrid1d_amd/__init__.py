@@ -11,7 +11,7 @@ from .api import (AbstractSmoother, AdditiveSchwarzSmoother, BlockDiagonal, Bloc
                   DeviceVector, HybridSchwarzSmoother, JacobiSmoother, MeshHierarchy,
                   apply_smoother, cg_smoother, default_context, dg_smoother,
                   dot, iterative_smoother_solve, ldiv, multigrid, multigrid_dev, multigrid_v_cycle, norm2, pcg,
-                  prolong_add, residual, restrict, smooth, smoother_launch_bytes)
+                  prolong_add, residual, restrict, smooth, smoother_launch_bytes, smoother_solve_dev)
 
 from . import interpolation
 from .interpolation import (aggdg_aggdg_interpolation, aggdg_cg_interpolation, aggdg_dg_interpolation,

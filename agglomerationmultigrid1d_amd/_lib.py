@@ -18,6 +18,7 @@ OPT_SYMMETRIC_PACKING = 1
 OPT_COARSE_CHUNK_LOG2 = 2
 OPT_DETECT_CHAIN = 3
 OPT_PAIR_LEVELS = 4
+OPT_MG_CHECKPOINT = 5
 PROFILE_NTAGS = 256
 KIND_FUSED_DOWN, KIND_FUSED_UP, KIND_SMOOTH, KIND_RESIDUAL, KIND_RESTRICT, KIND_PROLONG, \
     KIND_JACOBI, KIND_BLOCK_APPLY, KIND_COARSE, KIND_FUSED_MID = range(10)

@@ -1125,21 +1125,33 @@ def iterative_smoother_solve(A, smoother, x0, b, maxiter=1000, tol=1e-6, alpha=1
     (aggmg_smoother_solve_dev; the direct solve once, DirectSolver).  exact=False: err comes back empty."""
     op = smoother.A if not isinstance(A, DeviceOperator) else A
     c = op.ctx
-    N = op.shape[0]
-    dx0, db, dx = c.to_device(_f64(x0)), c.to_device(_f64(b)), c.alloc(N)
+    dx0, db = c.to_device(_f64(x0)), c.to_device(_f64(b))
     u_exact = None
     if exact:
         u_exact = _direct_solver(smoother, op, None if isinstance(A, DeviceOperator) else A).solve_dev(db)
+    dx, nit, res, err = smoother_solve_dev(op, smoother, dx0, db, maxiter, tol, alpha, check_every=check_every, u_exact=u_exact)
+    return dx.download(), (nit if check_every > 1 else len(res)), res, err
+
+
+def smoother_solve_dev(A_op, smoother, x0, b, maxiter, tol, alpha=1.0, check_every=1, u_exact=None):
+    """The loop of iterative_smoother_solve (src/solvers.jl:196-208) resident on the device -- C ABI
+    aggmg_smoother_solve_dev.  x0, b (and u_exact, the direct solution of :194, or None): DeviceVectors.
+    -> (x DeviceVector, iterations, res list, err list ([] without u_exact))."""
+    c = A_op.ctx
+    N = A_op.shape[0]
+    if x0.n != N or b.n != N or (u_exact is not None and u_exact.n != N):
+        raise DimensionMismatch("iterative_smoother_solve: x0 / b do not match the operator")
+    dx = c.alloc(N)
     nchk = max(1, -(-int(maxiter) // max(1, int(check_every))))
     hist, ehist = np.zeros(nchk), np.zeros(nchk)
     nit, nck = ctypes.c_int(0), ctypes.c_int(0)
-    c.check(c.lib.aggmg_smoother_solve_dev(c.handle, op.handle, smoother.handle, dx0.ptr, db.ptr, int(maxiter),
+    c.check(c.lib.aggmg_smoother_solve_dev(c.handle, A_op.handle, smoother.handle, x0.ptr, b.ptr, int(maxiter),
                                            float(tol), float(alpha), int(check_every), dx.ptr, _pd(hist),
                                            ctypes.byref(nit), ctypes.byref(nck), _ptr(u_exact),
-                                           _pd(ehist) if exact else None))
+                                           _pd(ehist) if u_exact is not None else None))
     res = hist[:nck.value].tolist()
-    err = ehist[:nck.value].tolist() if exact else []
-    return dx.download(), (nit.value if check_every > 1 else len(res)), res, err
+    err = ehist[:nck.value].tolist() if u_exact is not None else []
+    return dx, nit.value, res, err
 
 
 # stand-alone fused operations on host arrays (C ABI `aggmg_smooth`, `aggmg_residual`, ...)

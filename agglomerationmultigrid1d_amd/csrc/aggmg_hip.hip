@@ -155,6 +155,9 @@ extern "C" int aggmg_set_option(aggmg_ctx* ctx, int option, int value) {
     case AGGMG_OPT_PAIR_LEVELS:
       ctx->pair_levels = value != 0;
       return AGGMG_OK;
+    case AGGMG_OPT_MG_CHECKPOINT:
+      ctx->mg_checkpoint = value != 0;
+      return AGGMG_OK;
   }
   return fail(ctx, AGGMG_ERR_ARGUMENT, "aggmg_set_option: unknown option");
 }
@@ -537,7 +540,7 @@ static void xfer_out(FusedArgs& a, const TransferBtd& t) {
 }
 
 template <int M, bool CMP>
-static int launch_btd_t(aggmg_ctx* ctx, FusedArgs a, int halo, const TileSel& sel) {
+static int launch_btd_t(aggmg_ctx* ctx, FusedArgs a, int halo, const TileSel& sel, int64_t* ntiles_out) {
   using T = BtdTile<M, CMP>;
   const bool vr = (a.lf_out || a.ld_out) && a.par_out;
   const int align = ((a.lf_out || a.ld_out) && !vr) ? a.rho_out : 1;
@@ -562,11 +565,16 @@ static int launch_btd_t(aggmg_ctx* ctx, FusedArgs a, int halo, const TileSel& se
   const int64_t ntiles = sub.ntiles;
   a.tile_split = sub.split;
   a.tile_skip = sub.skip;
+  if (ntiles_out) *ntiles_out = ntiles;
   if (ntiles == 0) return AGGMG_OK;
-  const size_t lds = (size_t)2 * (T::TE + 2) * M * sizeof(double);
+  const bool chk = a.chk_part != nullptr;   // checkpoint variant (multigrid's per-cycle residual test inside the launch)
+  if (chk && a.gs) return fail(ctx, AGGMG_ERR_UNSUPPORTED, "internal: checkpoint launch with Gauss-Seidel sweeps");
+  a.chk_tiles = ntiles;
+  if (a.chk_stride < 1) a.chk_stride = 1 << 30;   // a single checkpoint, after chk_sweep sweeps
+  const size_t lds = (size_t)2 * (T::TE + 2) * M * sizeof(double) + (chk ? (size_t)2 * (T::NT / 64) * sizeof(double) : 0);
   constexpr bool kGrp = (CMP && (M == 2 || M == 4 || M == 8)) || (!CMP && (M == 2 || M == 4));
   const bool sym = kGrp && a.lv.bsym;
-  // four instantiations per (M, CMP): symmetric packing x smoother (block-Jacobi / red-black GS)
+  // instantiations per (M, CMP): symmetric packing x (block-Jacobi / red-black GS / block-Jacobi with checkpoint)
   auto go = [&](auto kern) {
     hipLaunchKernelGGL(kern, dim3((unsigned)ntiles), dim3(T::NT), lds, ctx->stream, a);
   };
@@ -574,6 +582,8 @@ static int launch_btd_t(aggmg_ctx* ctx, FusedArgs a, int halo, const TileSel& se
     if (sym) {
       if (a.gs)
         go(btd_fused_kernel<M, CMP, T::NS, true, T::NT, true>);
+      else if (chk)
+        go(btd_fused_kernel<M, CMP, T::NS, true, T::NT, false, true>);
       else
         go(btd_fused_kernel<M, CMP, T::NS, true, T::NT, false>);
       HIPCHK(hipGetLastError());
@@ -582,6 +592,8 @@ static int launch_btd_t(aggmg_ctx* ctx, FusedArgs a, int halo, const TileSel& se
   }
   if (a.gs)
     go(btd_fused_kernel<M, CMP, T::NS, false, T::NT, true>);
+  else if (chk)
+    go(btd_fused_kernel<M, CMP, T::NS, false, T::NT, false, true>);
   else
     go(btd_fused_kernel<M, CMP, T::NS, false, T::NT, false>);
   HIPCHK(hipGetLastError());
@@ -593,17 +605,18 @@ static int btd_max_halo() {
   return (BtdTile<M, CMP>::TE - 8) / 2;
 }
 
-static int launch_btd(aggmg_ctx* ctx, const BtdDev& b, const FusedArgs& a, int halo, const TileSel& sel = TileSel()) {
+static int launch_btd(aggmg_ctx* ctx, const BtdDev& b, const FusedArgs& a, int halo, const TileSel& sel = TileSel(),
+                      int64_t* ntiles_out = nullptr) {
 #define CASE(MM)                                             \
   case MM:                                                   \
-    return b.cmp ? launch_btd_t<MM, true>(ctx, a, halo, sel) \
-                 : launch_btd_t<MM, false>(ctx, a, halo, sel);
+    return b.cmp ? launch_btd_t<MM, true>(ctx, a, halo, sel, ntiles_out) \
+                 : launch_btd_t<MM, false>(ctx, a, halo, sel, ntiles_out);
 #define CASE_C(MM) \
   case MM:         \
-    return launch_btd_t<MM, true>(ctx, a, halo, sel);
+    return launch_btd_t<MM, true>(ctx, a, halo, sel, ntiles_out);
   switch (b.m) {
     case 1:
-      return launch_btd_t<1, false>(ctx, a, halo, sel);
+      return launch_btd_t<1, false>(ctx, a, halo, sel, ntiles_out);
       CASE(2) CASE(3) CASE(4) CASE(5) CASE_C(6) CASE_C(7) CASE_C(8) CASE_C(9)
     default:
       return fail(ctx, AGGMG_ERR_UNSUPPORTED, "block size not instantiated for the fused kernel");
@@ -2392,7 +2405,7 @@ static int solv_vec(aggmg_ctx* ctx, int slot, int64_t len, double** out) {
 
 static int solv_scalars(aggmg_ctx* ctx) {
   if (!ctx->solv_part) HIPCHK(hipMalloc((void**)&ctx->solv_part, kDotBlocks * sizeof(double)));
-  if (!ctx->solv_sc) HIPCHK(hipMalloc((void**)&ctx->solv_sc, 16 * sizeof(double)));
+  if (!ctx->solv_sc) HIPCHK(hipMalloc((void**)&ctx->solv_sc, 48 * sizeof(double)));   // [16 .. 47]: checkpoint norms of a launch
   return AGGMG_OK;
 }
 
@@ -2486,6 +2499,91 @@ extern "C" int aggmg_multigrid_dev(aggmg_ctx* ctx, aggmg_hier* h, const double* 
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return AGGMG_OK;
   }
+  // Fused block-tridiagonal fine level: the residual test (and the error norm) of a checked cycle are formed INSIDE the
+  // fine-level launch that post-smooths it -- the launch that goes on to pre-smooth the next cycle (aggmg_vcycles_dev's
+  // cross-cycle fusion) -- so a check after every cycle, the reference's semantics (src/solvers.jl:124-131), costs a
+  // store of the iterate and a few reductions instead of a residual launch over the fine operator and a cycle without
+  // the cross-cycle fusion (AGGMG_OPT_MG_CHECKPOINT = 0: the form below, for A/B runs and tests).
+  const bool use_chk = ctx->mg_checkpoint;
+  {
+    const int n = (int)h->lv.size();
+    Level& l0 = h->lv[0];
+    const bool fusable = n >= 2 && l0.S && l0.S->btd && l0.S->A == l0.A && l0.tb && h->restriction == AGGMG_RESTRICT_EXPLICIT &&
+                         btd_fits(*l0.S, nPre + nPost, 1) && !l0.S->gs && h->coarse_mode != AGGMG_COARSE_EXTERNAL;
+    if (use_chk && fusable) {
+      const BtdDev& B0 = *l0.S->btd;
+      double* part = nullptr;
+      CHECK(solv_vec(ctx, 2, 2 * (2 * B0.ne / std::max(btd_tile_elems(B0), 1) + 2), &part));
+      double* sc = ctx->solv_sc + 8;   // [8] ||A x - b||  [9] ||x - u_exact||
+      Level& c1 = h->lv[1];
+      const double* uc = (1 == n - 1) ? c1.u[0] : c1.u[1];
+      auto coarse_part = [&](bool descend) -> int {  // levels 1.. of one cycle: rhs_1 is in c1.rhs, result u_1
+        if (descend) CHECK(vcycle_down(ctx, h, nullptr, b, nPre, alpha, 1));
+        Level& c = h->lv[n - 1];
+        CHECK(coarse_solve(ctx, h, c.rhs, c.u[0]));
+        if (n > 2) CHECK(vcycle_up(ctx, h, b, nPost, alpha, nullptr, 1));
+        return AGGMG_OK;
+      };
+      h->last_coarse_ms = 0.0;
+      CHECK(vcycle_down(ctx, h, x0, b, nPre, alpha, 0));   // cycle 1: every level down ...
+      CHECK(coarse_part(false));                            // ... the coarsest solve and the coarser levels up
+      double* it_cur = l0.u[0];   // pre-smoothed fine iterate of the current cycle
+      double* it_alt = l0.u[1];
+      for (int it = 1; it <= maxiter; ++it) {
+        const bool check = (it % check_every == 0) || it == maxiter;
+        FusedArgs a = btd_args(B0);
+        a.u_in = it_cur;
+        a.b = b;
+        a.alpha = alpha;
+        a.lf_in = l0.tb->lf;
+        a.uc = uc;
+        xfer_in(a, *l0.tb);
+        int64_t ntiles = 0;
+        if (it < maxiter) {   // post-smoothing of cycle `it`, [checkpoint: x_it], pre-smoothing + restriction of cycle it + 1
+          a.u_out = it_alt;
+          a.nsweeps = nPost + nPre;
+          a.do_residual = 1;
+          a.lf_out = l0.tb->lf;
+          a.rc_out = c1.rhs;
+          xfer_out(a, *l0.tb);
+        } else {              // the last ascent: its result is x_maxiter
+          a.u_out = x_out;
+          a.nsweeps = nPost;
+        }
+        if (check) {
+          a.chk_sweep = nPost;
+          a.chk_stride = 1 << 30;   // one checkpoint per launch
+          a.chk_x = it < maxiter ? x_out : nullptr;
+          a.chk_exact = u_exact;
+          a.chk_part = part;
+        }
+        {
+          ProfScope ps(ctx, it < maxiter ? AGGMG_KIND_FUSED_MID : AGGMG_KIND_FUSED_UP, 0);
+          // (the last ascent's checkpoint forms residual rows of the FINAL iterate: one more element of halo, as a residual)
+          CHECK(launch_btd(ctx, B0, a, it < maxiter ? nPost + nPre + 1 : nPost + 1, TileSel(), &ntiles));
+        }
+        if (it < maxiter) std::swap(it_cur, it_alt);
+        done = it;
+        if (check) {
+          hipLaunchKernelGGL(chk_reduce_kernel, dim3(1), dim3(kThreads), 0, ctx->stream, ntiles, (const double*)part, sc);
+          HIPCHK(hipGetLastError());
+          double host[2] = {0.0, 0.0};
+          HIPCHK(hipMemcpyAsync(host, sc, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+          HIPCHK(hipStreamSynchronize(ctx->stream));
+          if (u_exact) err_hist[checks] = host[1];   // err[i] = ||x - u_exact||, src/solvers.jl:128
+          res_hist[checks++] = host[0];              // res[i] = ||A x - b||,      :127
+          if (host[0] < tol * nb) break;             // :131
+        }
+        if (it < maxiter) CHECK(coarse_part(true));
+      }
+      // (a cycle that was not the last one left x_done in x_out at its checkpoint; the last ascent wrote it there itself.
+      // Stopping happens at checks only, so x_out holds the iterate the histories end with.)
+      HIPCHK(hipStreamSynchronize(ctx->stream));
+      *n_cycles = done;
+      *n_checks = checks;
+      return AGGMG_OK;
+    }
+  }
   while (done < maxiter) {
     const int k = std::min(check_every, maxiter - done);
     double* dst = (cur == x_out) ? alt : x_out;
@@ -2527,6 +2625,70 @@ extern "C" int aggmg_smoother_solve_dev(aggmg_ctx* ctx, aggmg_op* A, aggmg_smoot
   int done = 0, checks = 0;
   *n_iters = 0;
   *n_checks = 0;
+  // Fused block-tridiagonal smoother on its own operator: launches of up to S sweeps with the residual test (and the error
+  // norm) of every checked sweep formed INSIDE the launch (the checkpoint variant of the fused kernel, as
+  // aggmg_multigrid_dev) -- the reference's test after every sweep (src/solvers.jl:198-206) at the multi-sweep smoother's
+  // traffic instead of a sweep launch, a residual launch and a reduction per iteration.  A launch whose histories show
+  // the tolerance met after j < S sweeps is run again for j sweeps from the same iterate (the same arithmetic: the
+  // iterate the reference stops with, bit for bit).  AGGMG_OPT_MG_CHECKPOINT = 0: the form below.
+  if (ctx->mg_checkpoint && sm->btd && sm->A == A && !sm->gs && btd_max_sweeps(*sm->btd, 1) >= 1 && maxiter > 0) {
+    const BtdDev& B0 = *sm->btd;
+    const int smax = std::min(btd_max_sweeps(B0, 1), 16);   // (+ 1: the residual rows of the last sweep's iterate)
+    double* part = nullptr;
+    CHECK(solv_vec(ctx, 2, (int64_t)smax * 2 * (2 * B0.ne / std::max(btd_tile_elems(B0), 1) + 2), &part));
+    double* sc = ctx->solv_sc + 16;
+    while (done < maxiter) {
+      const int S = std::min(smax, maxiter - done);
+      double* dst = (cur == x_out) ? alt : x_out;
+      // checked iteration counts in (done, done + S]: multiples of check_every, and maxiter
+      const int first = check_every - done % check_every;   // sweeps of this launch before its first check
+      FusedArgs a = btd_args(B0);
+      a.u_in = cur;
+      a.b = b;
+      a.alpha = alpha;
+      a.u_out = dst;
+      a.nsweeps = S;
+      a.chk_sweep = first;
+      a.chk_stride = check_every;
+      a.chk_final = (done + S == maxiter && (done + S) % check_every != 0) ? 1 : 0;
+      a.chk_exact = u_exact;
+      a.chk_part = part;
+      int nchk = (first <= S ? 1 + (S - first) / check_every : 0) + a.chk_final;
+      int64_t ntiles = 0;
+      {
+        ProfScope ps(ctx, AGGMG_KIND_SMOOTH, 0);
+        if (nchk == 0) a.chk_part = nullptr;
+        CHECK(launch_btd(ctx, B0, a, S + (nchk ? 1 : 0), TileSel(), &ntiles));
+      }
+      int stop = -1;   // sweeps of this launch after which the tolerance was met
+      if (nchk) {
+        hipLaunchKernelGGL(chk_reduce_kernel, dim3((unsigned)nchk), dim3(kThreads), 0, ctx->stream, ntiles, (const double*)part, sc);
+        HIPCHK(hipGetLastError());
+        double host[32];
+        HIPCHK(hipMemcpyAsync(host, sc, (size_t)2 * nchk * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        for (int k = 0; k < nchk && stop < 0; ++k) {
+          const int at = (a.chk_final && k == nchk - 1) ? S : first + k * check_every;
+          if (u_exact) err_hist[checks] = host[2 * k + 1];   // err[i] = ||x - uExact||, src/solvers.jl:202
+          res_hist[checks++] = host[2 * k];                  // res[i] = ||A x - b||,    :201
+          if (host[2 * k] < tol * nb) stop = at;             // :206
+        }
+      }
+      if (stop >= 0 && stop < S) {   // met before the launch's last sweep: that iterate again, without the rest
+        CHECK(btd_smooth(ctx, B0, cur, b, alpha, stop, dst, 0, N, 0));
+        done += stop;
+      } else {
+        done += S;
+      }
+      cur = dst;
+      if (stop >= 0) break;
+    }
+    if (cur != x_out) HIPCHK(hipMemcpyAsync(x_out, cur, N * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    *n_iters = done;
+    *n_checks = checks;
+    return AGGMG_OK;
+  }
   while (done < maxiter) {
     const int k = std::min(check_every, maxiter - done);
     double* dst = (cur == x_out) ? alt : x_out;

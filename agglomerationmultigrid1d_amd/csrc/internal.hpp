@@ -41,6 +41,7 @@ struct aggmg_ctx {
   bool sym_packing = true;  // AGGMG_OPT_SYMMETRIC_PACKING
   int cr_max_q = 12;        // AGGMG_OPT_COARSE_CHUNK_LOG2
   bool detect_chain = true; // AGGMG_OPT_DETECT_CHAIN
+  bool mg_checkpoint = [] { const char* e = std::getenv("AGGMG_MG_CHECKPOINT"); return !(e && e[0] == '0'); }();  // AGGMG_OPT_MG_CHECKPOINT
   bool pair_levels = [] { const char* e = std::getenv("AGGMG_PAIR"); return !(e && e[0] == '0'); }();  // AGGMG_OPT_PAIR_LEVELS
   int profiling = 0;  // 0 off, 1 every launch, 2 only the fine-level fused-down launch (dominant kernel)
   std::vector<ProfEvent> prof;

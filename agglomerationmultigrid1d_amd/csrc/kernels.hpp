@@ -508,6 +508,34 @@ static __global__ __launch_bounds__(kThreads) void dot_final_kernel(int nparts, 
   if (threadIdx.x == 0) out[0] = take_sqrt ? sqrt(sh[0]) : sh[0];
 }
 
+// out[0] = sqrt(sum_t part[t][0]), out[1] = sqrt(sum_t part[t][1]): the tile sums of a checkpoint launch (one
+// workgroup, fixed summation order)
+static __global__ __launch_bounds__(kThreads) void chk_reduce_kernel(int64_t ntiles, const double* __restrict__ part,
+                                                                   double* __restrict__ out) {
+  __shared__ double sh[2][kThreads];
+  part += (int64_t)blockIdx.x * ntiles * 2;   // one workgroup per checkpoint of the launch
+  out += blockIdx.x * 2;
+  double a0 = 0.0, a1 = 0.0;
+  for (int64_t t = threadIdx.x; t < ntiles; t += kThreads) {
+    a0 += part[2 * t];
+    a1 += part[2 * t + 1];
+  }
+  sh[0][threadIdx.x] = a0;
+  sh[1][threadIdx.x] = a1;
+  __syncthreads();
+  for (int s = kThreads / 2; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) {
+      sh[0][threadIdx.x] += sh[0][threadIdx.x + s];
+      sh[1][threadIdx.x] += sh[1][threadIdx.x + s];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    out[0] = sqrt(sh[0][0]);
+    out[1] = sqrt(sh[1][0]);
+  }
+}
+
 // PCG step with q = -A p (the residual kernel's sign):  a = rz / (-(p.q));  x += a p;  r += a q
 static __global__ __launch_bounds__(kThreads) void pcg_xr_kernel(int64_t n, double* __restrict__ x, double* __restrict__ r,
                                                           const double* __restrict__ p,
@@ -605,6 +633,21 @@ struct FusedArgs {
   // counterpart): even elements then odd ones (1), or odd then even (2); each half-sweep uses the
   // other colour's newest values and costs one element of halo.
   int gs;
+  // Checkpoint (btd_fused_kernel<..., CHK = true> only; the loop of multigrid, src/solvers.jl:124-131, with its
+  // residual test after EVERY cycle): after chk_sweep of the nsweeps sweeps -- between the post-smoothing of one cycle
+  // and the pre-smoothing of the next, which share this launch -- the iterate of the owned elements goes to chk_x (may
+  // be null), and the tile's sums of squares of b - A u and (chk_exact not null) of u - u_exact over its owned rows to
+  // chk_part[tile][2]: ||A x - b|| (:127) and ||x - u_exact|| (:128) without a residual launch of their own.
+  int chk_sweep;
+  // more than one checkpoint per launch (iterative_smoother_solve's test after every sweep, src/solvers.jl:198-206):
+  // after chk_sweep, chk_sweep + chk_stride, ... sweeps, and (chk_final) after the last one; checkpoint k's tile sums go
+  // to chk_part[(k * chk_tiles + tile)][2] (chk_tiles: the launch's tile count, set by the launcher)
+  int chk_stride;
+  int chk_final;
+  int64_t chk_tiles;
+  double* chk_x;
+  const double* chk_exact;
+  double* chk_part;
 };
 
 __device__ __forceinline__ int64_t fused_tile(const FusedArgs& a) {
@@ -672,9 +715,10 @@ __device__ __forceinline__ double group_bcast(double v, int j) {
 
 // GS: red-black block Gauss-Seidel sweeps (FusedArgs::gs gives the colour order) instead of
 // block-Jacobi ones -- a compile-time variant, so the block-Jacobi kernel carries none of it
-template <int M, bool CMP, int NS, bool SYM = false, int NT = kThreads, bool GS = false>
+template <int M, bool CMP, int NS, bool SYM = false, int NT = kThreads, bool GS = false, bool CHK = false>
 __global__ __launch_bounds__(NT) void btd_fused_kernel(FusedArgs a) {
   static_assert(!SYM || M == 2 || M == 4 || M == 8, "symmetric packing needs the lane-group path");
+  static_assert(!(CHK && GS), "the checkpoint is for block-Jacobi launches");
   // GRP: the rows of one element sit in M = 2^k adjacent lanes, so element-wide sums and
   // broadcasts (q.u+, B^{-1} b) go through cross-lane moves instead of LDS round trips
   constexpr bool GRP = CMP && (M == 2 || M == 4 || M == 8);
@@ -897,7 +941,78 @@ __global__ __launch_bounds__(NT) void btd_fused_kernel(FusedArgs a) {
   double* cur = buf0;
   double* nxt = buf1;
   const int nhalf = GS ? 2 * a.nsweeps : a.nsweeps;
+  // CHK: the checkpoint of FusedArgs -- explicit residual of the iterate in `it` (the operator's own entries, ascending
+  // column order: the final residual's expressions) on the owned rows, its square and that of u - u_exact summed over the
+  // tile in a fixed order (wave by wave, then the four waves)
+  [[maybe_unused]] int kchk = 0;
+  [[maybe_unused]] auto checkpoint = [&](const double* it) {
+    double sr = 0.0, se = 0.0;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const int x = s * EPS + le;
+      if (valid[s] && x >= own0 && x < own1) {
+        const int64_t e = e0 + x;
+        const int64_t row = e * M + i;
+        const double* um = it + (x - 1) * M;
+        const double* ux = it + x * M;
+        const double* up = it + (x + 1) * M;
+        double t = 0.0;
+        if (CMP) {
+          t += a.lv.scol[row] * um[a.lv.c_sub];
+#pragma unroll
+          for (int j = 0; j < M; ++j) t += a.lv.dblk[row * M + j] * ux[j];
+          if (GRP) {
+            const double d = group_sum<M>(qv[s][0] * up[i]);
+            if (i == a.lv.r_sup) t += d;
+          } else if (i == a.lv.r_sup) {
+#pragma unroll
+            for (int j = 0; j < (GRP ? 1 : M); ++j) t += qv[s][j] * up[j];
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < M; ++j) t += a.lv.sub[row * M + j] * um[j];
+#pragma unroll
+          for (int j = 0; j < M; ++j) t += a.lv.dblk[row * M + j] * ux[j];
+#pragma unroll
+          for (int j = 0; j < M; ++j) t += a.lv.sup[row * M + j] * up[j];
+        }
+        const double r = bb[s] - t;
+        sr += r * r;
+        if (a.chk_exact) {
+          const double d = uu[s] - a.chk_exact[row];
+          se += d * d;
+        }
+        if (a.chk_x) AGGMG_ST(a.chk_x[row], uu[s]);
+      }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      sr += __shfl_xor(sr, off, 64);
+      se += __shfl_xor(se, off, 64);
+    }
+    double* red = lds + 2 * (TE + 2) * M;   // (the launch reserves 2 * NT / 64 doubles behind the iterate buffers)
+    if ((tid & 63) == 0) {
+      red[2 * (tid >> 6)] = sr;
+      red[2 * (tid >> 6) + 1] = se;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      double tr = 0.0, te = 0.0;
+      for (int w = 0; w < NT / 64; ++w) {
+        tr += red[2 * w];
+        te += red[2 * w + 1];
+      }
+      double* out = a.chk_part + (kchk * a.chk_tiles + fused_tile(a)) * 2;
+      out[0] = tr;
+      out[1] = te;
+    }
+    ++kchk;
+  };
+  [[maybe_unused]] auto chk_due = [&](int sw) { return sw >= a.chk_sweep && (sw - a.chk_sweep) % a.chk_stride == 0; };
   for (int sw = 0; sw < nhalf; ++sw) {
+    if constexpr (CHK) {
+      if (chk_due(sw)) checkpoint(cur);
+    }
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
       const int x = s * EPS + le;
@@ -941,6 +1056,10 @@ __global__ __launch_bounds__(NT) void btd_fused_kernel(FusedArgs a) {
       cur = nxt;
       nxt = t;
     }
+  }
+
+  if constexpr (CHK) {
+    if (a.chk_final || chk_due(nhalf)) checkpoint(cur);   // a launch that ends on a checked iterate: the last ascent
   }
 
   // ---- store the iterate of the owned elements ---------------------------------------------

@@ -676,6 +676,13 @@ def main():
             t2 = time.perf_counter()
             _, ncyc, res = mg.multigrid_dev(H, ctx.to_device(np.zeros(N)), b, 400, 1e-8, check_every=8)
             outer["multigrid"] = {"cycles": ncyc, "ms": 1e3 * (time.perf_counter() - t2), "final_residual": res[-1]}
+            # the reference's own semantics -- res / err after EVERY cycle (src/solvers.jl:124-131): the norms are formed
+            # inside the fine-level launch that post-smooths cycle i and pre-smooths cycle i + 1
+            t2 = time.perf_counter()
+            _, ncyc1, res1 = mg.multigrid_dev(H, ctx.to_device(np.zeros(N)), b, 400, 1e-8, check_every=1)
+            dt1 = 1e3 * (time.perf_counter() - t2)
+            outer["multigrid_check_every_cycle"] = {"cycles": ncyc1, "ms": dt1, "ms_per_cycle": dt1 / max(ncyc1, 1),
+                                                    "final_residual": res1[-1]}
             t2 = time.perf_counter()
             _, nit, resp = mg.pcg(H, b_host, maxiter=100, tol=1e-8)
             outer["pcg_ldiv"] = {"iterations": nit, "ms_incl_h2d_d2h": 1e3 * (time.perf_counter() - t2),

@@ -76,6 +76,13 @@ int aggmg_synchronize(aggmg_ctx* ctx);
  * agglomerated levels per launch where it can (aggmg_hier_level_paired) -- same results bit for bit; 0 keeps one
  * launch per level (A/B timing, tests). */
 #define AGGMG_OPT_PAIR_LEVELS 4
+/* AGGMG_OPT_MG_CHECKPOINT (default 1; environment AGGMG_MG_CHECKPOINT=0 makes the default 0): aggmg_multigrid_dev forms
+ * the residual norm (and the error norm) of a checked cycle inside the fine-level launch that post-smooths it -- the launch
+ * that goes on to pre-smooth the next cycle -- instead of in a residual launch of its own; the iterates are bit for bit
+ * the same, the norms equal to round-off (another summation order).  aggmg_smoother_solve_dev likewise: launches of
+ * several sweeps with the norms of every checked sweep formed inside (a launch in whose middle the tolerance is met is run
+ * again up to that sweep).  Fused block-tridiagonal fine levels / smoothers only; others take the separate launches. */
+#define AGGMG_OPT_MG_CHECKPOINT 5
 int aggmg_set_option(aggmg_ctx* ctx, int option, int value);
 /* Raw device memory owned by the context's device (plumbing for harnesses without torch, and the storage of the
  * Julia shim's DeviceVector).  aggmg_dev_alloc returns ZEROED memory: a fresh vector is the zero initial guess of

@@ -101,6 +101,41 @@ def test_smoother_solve_device_loop(oracle, mg):
     assert np.allclose(resg, reso, rtol=1e-10, atol=1e-12 * np.linalg.norm(bc))
 
 
+@pytest.mark.parametrize("ne", [48, 3000])    # one tile / many tiles
+def test_smoother_solve_checkpoints_inside_the_sweep_launches(oracle, mg, ne):
+    """iterative_smoother_solve's test after every sweep (src/solvers.jl:198-206) formed INSIDE multi-sweep launches of the
+    fused block-Jacobi kernel (AGGMG_OPT_MG_CHECKPOINT, default on) against one sweep launch + one residual launch per
+    iteration: the same iterates bit for bit, the same iteration counts -- also when the tolerance is met in the middle of a
+    launch, which is then run again up to that sweep --, histories equal to round-off; check_every 1 / 2 / 5 / 9 with a
+    maxiter that is not a multiple; with and without the error history; and against the oracle"""
+    from agglomerationmultigrid1d_amd import _lib
+    o = oracle
+    Ho, b = o.build_dg_agg_hierarchy(ne, p=3, pAgg=1, nAgg=1, first=4)
+    A, dg = Ho.mStiffness[0], Ho.mMeshes[0]
+    u0 = o.splitmix_normal(len(b), 11)
+    # a tolerance the iteration meets after a sweep count that is no multiple of the launch's sweeps
+    _, _, r_probe, _ = o.iterative_smoother_solve(A, o.dg_smoother(dg, A, 'blockJac'), u0, b, maxiter=17, tol=1e-30, alpha=2.0 / 3.0)
+    tol_mid = 0.5 * (r_probe[9] + r_probe[10]) / np.linalg.norm(b)
+    cases = ((1, 23, 1e-30, True), (1, 40, tol_mid, False), (2, 23, 1e-30, False), (5, 23, tol_mid, True), (9, 40, 1e-30, False),
+             (1, 1, 1e-30, True), (3, 2, 1e-30, False))
+    out = {}
+    for chk in (1, 0):
+        ctx = mg.Context(0)
+        ctx.set_option(_lib.OPT_MG_CHECKPOINT, chk)
+        Sg = mg.dg_smoother(dg, A, 'blockJac', ctx=ctx)
+        out[chk] = [mg.iterative_smoother_solve(A, Sg, u0, b, maxiter=mi, tol=tol, alpha=2.0 / 3.0, exact=ex, check_every=ce)
+                    for ce, mi, tol, ex in cases]
+    for (ce, mi, tol, ex), (xa, ia, ra, ea), (xb, ib, rb, eb) in zip(cases, out[1], out[0]):
+        assert ia == ib and len(ra) == len(rb) and len(ea) == len(eb) == (len(ra) if ex else 0), (ce, mi)
+        assert np.array_equal(xa, xb), (ce, mi)
+        assert np.allclose(ra, rb, rtol=1e-10, atol=1e-13 * np.linalg.norm(b)) and np.allclose(ea, eb, rtol=1e-9, atol=1e-12), (ce, mi)
+    assert out[1][1][1] == 11                         # stopped inside a launch: 11 sweeps, not the launch's full count
+    xo, ito, reso, _ = o.iterative_smoother_solve(A, o.dg_smoother(dg, A, 'blockJac'), u0, b, maxiter=40, tol=tol_mid, alpha=2.0 / 3.0)
+    xg, itg, resg, _ = out[1][1]
+    assert itg == ito and np.allclose(resg, reso, rtol=1e-9, atol=1e-12 * np.linalg.norm(b))
+    assert np.linalg.norm(xg - xo) <= 1e-11 * np.linalg.norm(xo)
+
+
 def test_err_histories_are_formed_on_the_device(oracle, mg):
     """multigrid / iterative_smoother_solve return the reference's full 4-tuple (x, iter, res, err) with
     err[i] = ||x_i - A \\ b||_2 (src/solvers.jl:120,128 and :194,202) -- exact=True, the default of both mirrors -- and the
@@ -200,3 +235,34 @@ def test_v_cycle_on_device_vectors_equals_host_entry(oracle, mg):
     with pytest.raises(mg.DimensionMismatch):
         mg.multigrid_v_cycle(H, ctx.alloc(N - 1), db)
     H.free()
+
+
+@pytest.mark.parametrize("ne", [256, 4096])    # one tile / many tiles (the last ascent's checkpoint needs its own halo)
+def test_multigrid_checkpoint_inside_the_fine_level_launch(oracle, mg, ne):
+    """multigrid's residual test after every cycle (src/solvers.jl:124-131) formed INSIDE the fine-level launch that
+    post-smooths the cycle and pre-smooths the next (AGGMG_OPT_MG_CHECKPOINT, default on) against the form with a residual
+    launch of its own: the same iterates bit for bit, the same cycle counts, histories equal to round-off -- with and
+    without the error history, check_every 1 / 2 / 3, stopping on the tolerance and on maxiter; and against the oracle"""
+    from agglomerationmultigrid1d_amd import _lib
+    o = oracle
+    Ho, b = o.build_dg_agg_hierarchy(ne, p=3, pAgg=1, nAgg=3, first=4)
+    x0 = o.splitmix_normal(len(b), 5)
+    out = {}
+    for chk in (1, 0):
+        ctx = mg.Context(0)
+        ctx.set_option(_lib.OPT_MG_CHECKPOINT, chk)
+        H = mg.MeshHierarchy.from_reference(Ho, ctx=ctx)
+        assert H.level_kinds()[0] == "fused_btd"
+        runs = []
+        for ce, maxiter, tol, exact in ((1, 40, 1e-9, True), (1, 7, 1e-30, False), (2, 9, 1e-30, True), (3, 40, 1e-6, False), (1, 1, 1e-30, True)):
+            runs.append(mg.multigrid(H, x0, b, maxiter, tol, exact=exact, check_every=ce))
+        out[chk] = runs
+    for (xa, ia, ra, ea), (xb, ib, rb, eb) in zip(out[1], out[0]):
+        assert ia == ib and len(ra) == len(rb) and len(ea) == len(eb)
+        assert np.array_equal(xa, xb)                                  # the iterates: the same arithmetic
+        assert np.allclose(ra, rb, rtol=1e-10, atol=1e-13 * np.linalg.norm(b)) and np.allclose(ea, eb, rtol=1e-9, atol=1e-14)
+    xo, ito, reso, erro = o.multigrid(Ho, x0, b, 40, 1e-9)
+    xg, itg, resg, errg = out[1][0]
+    assert itg == ito and np.allclose(resg, reso, rtol=1e-6, atol=1e-11 * np.linalg.norm(b))
+    # (u_exact: the device's cyclic reduction here, a banded LU there -- they differ by cond(A) * eps, which grows as ne^2)
+    assert np.allclose(errg, erro, rtol=1e-6, atol=(1e-9 if ne <= 256 else 1e-6) * erro[0])
