@@ -570,8 +570,18 @@ static int launch_btd_t(aggmg_ctx* ctx, FusedArgs a, int halo, const TileSel& se
   const bool chk = a.chk_part != nullptr;   // checkpoint variant (multigrid's per-cycle residual test inside the launch)
   if (chk && a.gs) return fail(ctx, AGGMG_ERR_UNSUPPORTED, "internal: checkpoint launch with Gauss-Seidel sweeps");
   a.chk_tiles = ntiles;
+  if (chk) {   // measurement aid (tools/exp_outer_loop.py): the checkpoint variant's code with no checkpoint ever due
+    static const int never = cr_env_int_early("AGGMG_CHK_NEVER", 0);
+    if (never) {
+      a.chk_sweep = 1 << 29;
+      a.chk_final = 0;
+    }
+  }
   if (a.chk_stride < 1) a.chk_stride = 1 << 30;   // a single checkpoint, after chk_sweep sweeps
-  const size_t lds = (size_t)2 * (T::TE + 2) * M * sizeof(double) + (chk ? (size_t)2 * (T::NT / 64) * sizeof(double) : 0);
+  // (checkpoint variant: + the wave sums of a reduction, + -- compressed couplings -- the thread-private slots the
+  // residual rows' operator entries are parked in between a checkpoint and the later residuals of the launch)
+  const size_t lds = (size_t)2 * (T::TE + 2) * M * sizeof(double) +
+                     (chk ? ((size_t)2 * (T::NT / 64) + (CMP ? (size_t)T::NT * T::NS * (M + 1) : 0)) * sizeof(double) : 0);
   constexpr bool kGrp = (CMP && (M == 2 || M == 4 || M == 8)) || (!CMP && (M == 2 || M == 4));
   const bool sym = kGrp && a.lv.bsym;
   // instantiations per (M, CMP): symmetric packing x (block-Jacobi / red-black GS / block-Jacobi with checkpoint)

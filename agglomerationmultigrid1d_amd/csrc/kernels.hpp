@@ -715,8 +715,13 @@ __device__ __forceinline__ double group_bcast(double v, int j) {
 
 // GS: red-black block Gauss-Seidel sweeps (FusedArgs::gs gives the colour order) instead of
 // block-Jacobi ones -- a compile-time variant, so the block-Jacobi kernel carries none of it
+// (AGGMG_CHK_WAVES: minimum waves per SIMD asked of the checkpoint variant; measured 7 and 6 -- spills into the sweep
+// loop, 2.8 / 2.3 ms against 1.45 ms per launch -- so 1: no constraint)
+#ifndef AGGMG_CHK_WAVES
+#define AGGMG_CHK_WAVES 1
+#endif
 template <int M, bool CMP, int NS, bool SYM = false, int NT = kThreads, bool GS = false, bool CHK = false>
-__global__ __launch_bounds__(NT) void btd_fused_kernel(FusedArgs a) {
+__global__ __launch_bounds__(NT, CHK ? AGGMG_CHK_WAVES : 1) void btd_fused_kernel(FusedArgs a) {
   static_assert(!SYM || M == 2 || M == 4 || M == 8, "symmetric packing needs the lane-group path");
   static_assert(!(CHK && GS), "the checkpoint is for block-Jacobi launches");
   // GRP: the rows of one element sit in M = 2^k adjacent lanes, so element-wide sums and
@@ -945,6 +950,28 @@ __global__ __launch_bounds__(NT) void btd_fused_kernel(FusedArgs a) {
   // column order: the final residual's expressions) on the owned rows, its square and that of u - u_exact summed over the
   // tile in a fixed order (wave by wave, then the four waves)
   [[maybe_unused]] int kchk = 0;
+  // (CHK, CMP) the residual rows' operator entries -- the row of the diagonal block, the sub-diagonal column entry -- are
+  // read from memory by the FIRST checkpoint only and parked in thread-private LDS slots behind the reduction scratch:
+  // later checkpoints and the launch's closing residual (the restriction's) take them from there instead of a second pass
+  // over the diagonal blocks (2.1 GB at 2^24 elements p = 3)
+  [[maybe_unused]] double* const stash = lds + 2 * (TE + 2) * M + 2 * (NT / 64);
+  [[maybe_unused]] bool stashed = false;
+  [[maybe_unused]] auto row_entries = [&](int s, int64_t row, double (&dk)[M], double& sc) {
+    if (CHK && CMP && stashed) {
+#pragma unroll
+      for (int j = 0; j < M; ++j) dk[j] = stash[(s * (M + 1) + j) * NT + tid];
+      sc = stash[(s * (M + 1) + M) * NT + tid];
+    } else {
+      sc = a.lv.scol[row];
+#pragma unroll
+      for (int j = 0; j < M; ++j) dk[j] = a.lv.dblk[row * M + j];
+      if constexpr (CHK && CMP) {
+#pragma unroll
+        for (int j = 0; j < M; ++j) stash[(s * (M + 1) + j) * NT + tid] = dk[j];
+        stash[(s * (M + 1) + M) * NT + tid] = sc;
+      }
+    }
+  };
   [[maybe_unused]] auto checkpoint = [&](const double* it) {
     double sr = 0.0, se = 0.0;
 #pragma unroll
@@ -958,9 +985,11 @@ __global__ __launch_bounds__(NT) void btd_fused_kernel(FusedArgs a) {
         const double* up = it + (x + 1) * M;
         double t = 0.0;
         if (CMP) {
-          t += a.lv.scol[row] * um[a.lv.c_sub];
+          double dk[M], sc;
+          row_entries(s, row, dk, sc);
+          t += sc * um[a.lv.c_sub];
 #pragma unroll
-          for (int j = 0; j < M; ++j) t += a.lv.dblk[row * M + j] * ux[j];
+          for (int j = 0; j < M; ++j) t += dk[j] * ux[j];
           if (GRP) {
             const double d = group_sum<M>(qv[s][0] * up[i]);
             if (i == a.lv.r_sup) t += d;
@@ -978,11 +1007,23 @@ __global__ __launch_bounds__(NT) void btd_fused_kernel(FusedArgs a) {
         }
         const double r = bb[s] - t;
         sr += r * r;
-        if (a.chk_exact) {
-          const double d = uu[s] - a.chk_exact[row];
-          se += d * d;
+      }
+      __builtin_amdgcn_sched_barrier(0);   // one slab's row entries in flight at a time: the sweeps' registers stay live here
+    }
+    // (the error norm and the store of the iterate after the residual rows, not among them: fewer registers live at once)
+    if (a.chk_exact || a.chk_x) {
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const int x = s * EPS + le;
+        if (valid[s] && x >= own0 && x < own1) {
+          const int64_t row = (e0 + x) * M + i;
+          if (a.chk_exact) {
+            const double d = uu[s] - a.chk_exact[row];
+            se += d * d;
+          }
+          if (a.chk_x) AGGMG_ST(a.chk_x[row], uu[s]);
         }
-        if (a.chk_x) AGGMG_ST(a.chk_x[row], uu[s]);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
 #pragma unroll
@@ -990,6 +1031,7 @@ __global__ __launch_bounds__(NT) void btd_fused_kernel(FusedArgs a) {
       sr += __shfl_xor(sr, off, 64);
       se += __shfl_xor(se, off, 64);
     }
+    stashed = true;
     double* red = lds + 2 * (TE + 2) * M;   // (the launch reserves 2 * NT / 64 doubles behind the iterate buffers)
     if ((tid & 63) == 0) {
       red[2 * (tid >> 6)] = sr;
@@ -1090,9 +1132,17 @@ __global__ __launch_bounds__(NT) void btd_fused_kernel(FusedArgs a) {
         const double* up = cur + (x + 1) * M;
         double t = 0.0;
         if (CMP) {
-          t += a.lv.scol[row] * um[a.lv.c_sub];
+          double dk[M], sc;
+          if constexpr (CHK) {
+            row_entries(s, row, dk, sc);
+          } else {
+            sc = a.lv.scol[row];
 #pragma unroll
-          for (int j = 0; j < M; ++j) t += a.lv.dblk[row * M + j] * ux[j];
+            for (int j = 0; j < M; ++j) dk[j] = a.lv.dblk[row * M + j];
+          }
+          t += sc * um[a.lv.c_sub];
+#pragma unroll
+          for (int j = 0; j < M; ++j) t += dk[j] * ux[j];
           if (GRP) {
             const double d = group_sum<M>(qv[s][0] * up[i]);
             if (i == a.lv.r_sup) t += d;
