@@ -32,6 +32,12 @@ class NumpyEngine:
     def new(self, n):
         return torch.zeros(int(n), dtype=torch.float64)
 
+    def owned_sumsq(self, ranges, b, x=None):
+        v = b.numpy()
+        if x is not None:
+            v = v - self.o.csc_matvec(self.H.mStiffness[0], x.numpy())
+        return float(sum(np.dot(v[lo:hi], v[lo:hi]) for lo, hi in ranges))
+
     def down(self, x0, b, nPre, alpha):
         o, H = self.o, self.H
         n = len(H.mStiffness)

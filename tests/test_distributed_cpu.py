@@ -254,3 +254,88 @@ def test_thread_comm_collectives():
         return True
 
     assert all(_thread_ranks(8, rank_fn))
+
+
+def _mg_worker(rank, world, port, n, p, ratios, maxiter, tol, check_every, q):
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]
+    import aggmg_oracle as o
+    from dist_helpers import LocalRef, NumpyEngine
+    from agglomerationmultigrid1d_amd import distributed as D
+    from agglomerationmultigrid1d_amd.uniform import UniformDgAggHierarchy
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        layout = D.RankLayout(n, ratios, [p + 1] + [2] * len(ratios), world, rank, 3, 3)
+        U = UniformDgAggHierarchy(n, p=p, pAgg=1, ratios=ratios, elem_range=layout.loc[0])
+        Ug = UniformDgAggHierarchy(n, p=p, pAgg=1, ratios=ratios)
+        dv = D.DistributedVCycle(NumpyEngine(o, LocalRef(o, U), Ug.stiffness_csc(Ug.nlevels - 1)), layout, D.Comm(world, rank))
+        x0 = torch.zeros(layout.local_dofs(0), dtype=torch.float64)
+        x, it, res = D.multigrid(dv, x0, torch.from_numpy(U.rhs().copy()), maxiter, tol, check_every=check_every)
+        q.put((rank, it, res, x.numpy()[layout.owned_slice(0)].copy(), layout.own[0]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,check_every,tol", [(2, 1, 2e-4), (2, 3, 2e-4), (3, 1, 1e-30)])
+def test_partitioned_multigrid_loop_matches_single_domain(world, check_every, tol):
+    """distributed.multigrid -- the loop of multigrid (src/solvers.jl:116-139) over the partitioned V-cycle, residual
+    norms summed over the ranks' owned rows, gloo ranks as processes -- against the oracle's multigrid on the whole
+    domain: the same cycle count on every rank, the same residual history (to the order of the sums), the same iterate"""
+    sys.path[:0] = [os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]
+    import aggmg_oracle as o
+    from dist_helpers import LocalRef
+    from agglomerationmultigrid1d_amd.uniform import UniformDgAggHierarchy
+    n, p, ratios, maxiter = 96 * world, 3, (4, 2), 7 if tol < 1e-20 else 20   # (2e-4: met after 8 cycles)
+    Ug = UniformDgAggHierarchy(n, p=p, pAgg=1, ratios=ratios)
+    bg = Ug.rhs()
+    Hg = LocalRef(o, Ug)
+    _, _, reso, _ = o.multigrid(Hg, np.zeros(len(bg)), bg, maxiter, 1e-30)          # the whole history
+    checked = [i for i in range(1, maxiter + 1) if i % check_every == 0 or i == maxiter]
+    # the loop stops at the first CHECKED cycle whose residual meets the tolerance
+    stop = next((i for i in checked if reso[i - 1] < tol * np.linalg.norm(bg)), maxiter)
+    want = [reso[i - 1] for i in checked if i <= stop]
+    xo = o.multigrid(Hg, np.zeros(len(bg)), bg, stop, 1e-30)[0]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=_mg_worker, args=(r, world, port, n, p, ratios, maxiter, tol, check_every, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    out = sorted((q.get(timeout=300) for _ in range(world)), key=lambda t: t[0])
+    for pr in procs:
+        pr.join(300)
+    assert all(pr.exitcode == 0 for pr in procs), [pr.exitcode for pr in procs]
+    assert stop < maxiter or tol < 1e-20
+    for rank, it, res, xown, (lo, hi) in out:
+        assert it == stop and res == out[0][2], (rank, it, stop)          # every rank: the same history, bit for bit
+        assert np.allclose(res, want, rtol=1e-9, atol=1e-13 * np.linalg.norm(bg)), (rank, res, want)
+        assert np.max(np.abs(xown - xo[lo * (p + 1):hi * (p + 1)])) <= 1e-13 * np.max(np.abs(xo))
+
+
+def test_eight_thread_ranks_partitioned_multigrid_loop():
+    """the same loop on eight ranks (threads, ThreadComm.sum in rank order)"""
+    sys.path[:0] = [os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]
+    import aggmg_oracle as o
+    from dist_helpers import LocalRef, NumpyEngine
+    from agglomerationmultigrid1d_amd import distributed as D
+    from agglomerationmultigrid1d_amd.uniform import UniformDgAggHierarchy
+    world, n, p, ratios = 8, 1024, 3, (4, 2, 2)
+    Ug = UniformDgAggHierarchy(n, p=p, pAgg=1, ratios=ratios)
+    bg = Ug.rhs()
+    xo, ito, reso, _ = o.multigrid(LocalRef(o, Ug), np.zeros(len(bg)), bg, 20, 2e-4)
+    Ac = Ug.stiffness_csc(Ug.nlevels - 1)
+
+    def rank_fn(rank, comm):
+        layout = D.RankLayout(n, ratios, [p + 1] + [2] * len(ratios), world, rank, 3, 3)
+        U = UniformDgAggHierarchy(n, p=p, pAgg=1, ratios=ratios, elem_range=layout.loc[0])
+        dv = D.DistributedVCycle(NumpyEngine(o, LocalRef(o, U), Ac), layout, comm)
+        x, it, res = D.multigrid(dv, torch.zeros(layout.local_dofs(0), dtype=torch.float64), torch.from_numpy(U.rhs().copy()), 20, 2e-4)
+        lo, hi = layout.own[0]
+        return it, res, float(np.max(np.abs(x.numpy()[layout.owned_slice(0)] - xo[lo * (p + 1):hi * (p + 1)])))
+
+    out = _thread_ranks(world, rank_fn)
+    for it, res, err in out:
+        assert it == ito and res == out[0][1]
+        assert np.allclose(res, reso, rtol=1e-9, atol=1e-13 * np.linalg.norm(bg))
+        assert err <= 1e-13 * np.max(np.abs(xo))

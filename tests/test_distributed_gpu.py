@@ -599,6 +599,8 @@ def test_bench_eight_ranks_rehearsal(dist_config):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 8 and d["steps"] == 3 and d["scaling"] == "strong" and d["value"] > 0
     assert d["config"]["backend"] == "threads" and "rehearsal" in d and d["roofline"]["frac"] <= 1.0
+    o_ = d["outer_solvers_to_1e-8"]["multigrid"]      # the partitioned multigrid() loop ran and met its tolerance
+    assert 0 < o_["cycles"] < 200 and o_["final_residual"] > 0
 
 
 @pytest.mark.parametrize("world,n,p,ratios,sweeps", [(8, 2**15, 2, (2, 2, 2), (2, 1)), (6, 6 * 2**12, 3, (4, 2), (3, 3)),
@@ -647,3 +649,64 @@ def test_thread_ranks_other_shapes_match_single_gpu(world, n, p, ratios, sweeps)
         # (a replicated coarsest solve and the single-GPU one take the same launches: bitwise; a chunked one plans its chunks
         # for the partition: equal to the accuracy of the coarsest solves)
         assert err == 0.0 or (chunked and err <= 1e-9 * scale), (rank, err, scale, chunked)
+
+
+@pytest.mark.parametrize("config,check_every", [(4, 1), (4, 3), (5, 1)])
+def test_eight_ranks_partitioned_multigrid_loop_matches_single_gpu(config, check_every):
+    """distributed.multigrid -- the loop of multigrid (src/solvers.jl:116-139) over the partitioned cycle of the library's
+    C++ schedule, ||A x - b|| summed over the ranks' owned rows in rank order -- on EIGHT ranks (threads sharing the GPU)
+    against aggmg_multigrid_dev on one GPU: the same cycle count on every rank, the same residual history on every rank
+    bit for bit and equal to the single-GPU one to the order of the sums, owned iterates bitwise the single-GPU iterate.
+    Config 4 (DG / agglomerated, block-Jacobi) and config 5's shape (CG chain, point-Jacobi: the owned DoFs are two
+    index ranges, vertices and element-interior nodes)."""
+    import torch
+    import agglomerationmultigrid1d_amd as mg
+    from agglomerationmultigrid1d_amd import distributed as D
+    from agglomerationmultigrid1d_amd.uniform import (UniformCgDgHierarchy, UniformDgAggHierarchy, build_device_cg_hierarchy,
+                                                      build_device_hierarchy)
+    world, maxiter = 8, 30
+    ctx2 = mg.Context(0)
+    if config == 4:
+        n, p, ratios = 2**16, 3, (4, 2, 2)
+        Ug = UniformDgAggHierarchy(n, p=p, pAgg=1, ratios=ratios)
+        Hg = build_device_hierarchy(Ug, ctx2)
+    else:
+        n, ps = 2**14, (4, 2, 1)
+        Ug = UniformCgDgHierarchy(n, ps=ps)
+        Hg = build_device_cg_hierarchy(Ug, ctx2)
+    N = len(Ug.rhs())
+    bg = ctx2.to_device(Ug.rhs())
+    # a tolerance met after a handful of cycles: taken from the single-GPU history itself
+    _, _, hist = mg.multigrid_dev(Hg, ctx2.to_device(np.zeros(N)), bg, 12, 1e-30)
+    tol = 0.5 * (hist[6] + hist[7]) / np.linalg.norm(Ug.rhs())
+    xg, itg, resg = mg.multigrid_dev(Hg, ctx2.to_device(np.zeros(N)), bg, maxiter, tol, check_every=check_every)
+    assert itg == (8 if check_every == 1 else 9)
+    ref = xg.download()
+    Hg.free()
+
+    def rank_fn(rank, comm):
+        ctx = mg.Context(0)
+        if config == 4:
+            layout = D.RankLayout(n, ratios, [p + 1, 2, 2, 2], world, rank)
+            engine, U = D.build_local_uniform(n, p, 1, ratios, layout, ctx, comm)
+        else:
+            layout = D.CgRankLayout(n, ps, world, rank, 3, 3)
+            engine, U = D.build_local_cg(n, ps, layout, ctx, comm)
+        dv = D.NativeDistributedVCycle(engine, layout, comm, collectives="torch")
+        b = torch.from_numpy(U.rhs()).to(engine.dev)
+        x, it, res = D.multigrid(dv, engine.new(layout.local_dofs(0)), b, maxiter, tol, check_every=check_every)
+        torch.cuda.synchronize()
+        if config == 4:
+            lo, hi = layout.own[0]
+            got, want = x.cpu().numpy()[layout.owned_slice(0)], ref[lo * (p + 1):hi * (p + 1)]
+        else:
+            got, want = x.cpu().numpy()[layout.owned_index(0)], ref[layout.global_index(0)]
+        comm.barrier()
+        dv.free()
+        return it, res, float(np.max(np.abs(got - want)))
+
+    out = _thread_ranks(world, rank_fn)
+    for rank, (it, res, err) in enumerate(out):
+        assert it == itg and res == out[0][1], (rank, it, itg)
+        assert np.allclose(res, resg, rtol=1e-10, atol=1e-13 * np.linalg.norm(Ug.rhs())), (rank, res, resg)
+        assert err == 0.0, (rank, err)
