@@ -2480,6 +2480,17 @@ extern "C" int aggmg_residual_norm_dev(aggmg_ctx* ctx, aggmg_op* A, const double
   return residual_norm(ctx, A, x, b, out);
 }
 
+// norms of the checkpoints of a launch: part[nchk][ntiles][2] -> out[nchk][2] (chk_reduce1/2_kernel); `mid`: room for
+// nchk * kChkReduceGroups * 2 doubles
+static int chk_reduce(aggmg_ctx* ctx, int nchk, int64_t ntiles, const double* part, double* mid, double* out) {
+  const int G = (int)std::min<int64_t>(kChkReduceGroups, std::max<int64_t>(1, (ntiles + kThreads - 1) / kThreads));
+  hipLaunchKernelGGL(chk_reduce1_kernel, dim3((unsigned)G, (unsigned)nchk), dim3(kThreads), 0, ctx->stream, ntiles, part, mid);
+  HIPCHK(hipGetLastError());
+  hipLaunchKernelGGL(chk_reduce2_kernel, dim3((unsigned)nchk), dim3(kThreads), 0, ctx->stream, G, (const double*)mid, out);
+  HIPCHK(hipGetLastError());
+  return AGGMG_OK;
+}
+
 extern "C" int aggmg_multigrid_dev(aggmg_ctx* ctx, aggmg_hier* h, const double* x0, const double* b, int maxiter,
                                    double tol, int check_every, int nPre, int nPost, double alpha, double* x_out,
                                    double* res_hist, int* n_cycles, int* n_checks, const double* u_exact,
@@ -2523,7 +2534,9 @@ extern "C" int aggmg_multigrid_dev(aggmg_ctx* ctx, aggmg_hier* h, const double* 
     if (use_chk && fusable) {
       const BtdDev& B0 = *l0.S->btd;
       double* part = nullptr;
-      CHECK(solv_vec(ctx, 2, 2 * (2 * B0.ne / std::max(btd_tile_elems(B0), 1) + 2), &part));
+      const int64_t npart = 2 * (2 * B0.ne / std::max(btd_tile_elems(B0), 1) + 2);
+      CHECK(solv_vec(ctx, 2, npart + 2 * kChkReduceGroups, &part));
+      double* mid = part + npart;
       double* sc = ctx->solv_sc + 8;   // [8] ||A x - b||  [9] ||x - u_exact||
       Level& c1 = h->lv[1];
       const double* uc = (1 == n - 1) ? c1.u[0] : c1.u[1];
@@ -2575,8 +2588,7 @@ extern "C" int aggmg_multigrid_dev(aggmg_ctx* ctx, aggmg_hier* h, const double* 
         if (it < maxiter) std::swap(it_cur, it_alt);
         done = it;
         if (check) {
-          hipLaunchKernelGGL(chk_reduce_kernel, dim3(1), dim3(kThreads), 0, ctx->stream, ntiles, (const double*)part, sc);
-          HIPCHK(hipGetLastError());
+          CHECK(chk_reduce(ctx, 1, ntiles, part, mid, sc));
           double host[2] = {0.0, 0.0};
           HIPCHK(hipMemcpyAsync(host, sc, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
           HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -2588,6 +2600,63 @@ extern "C" int aggmg_multigrid_dev(aggmg_ctx* ctx, aggmg_hier* h, const double* 
       }
       // (a cycle that was not the last one left x_done in x_out at its checkpoint; the last ascent wrote it there itself.
       // Stopping happens at checks only, so x_out holds the iterate the histories end with.)
+      HIPCHK(hipStreamSynchronize(ctx->stream));
+      *n_cycles = done;
+      *n_checks = checks;
+      return AGGMG_OK;
+    }
+  }
+  {
+    // CG chain fine level (point-Jacobi): the same loop with the chain kernel's checkpoint variant
+    const int n = (int)h->lv.size();
+    Level& l0 = h->lv[0];
+    if (use_chk && n >= 2 && l0.cgt_fused && l0.S->cgt->sw == 0 && h->coarse_mode != AGGMG_COARSE_EXTERNAL &&
+        nPost + nPre <= cgt_max_fused_sweeps(*l0.S->cgt)) {
+      const CgtDev& g = *l0.S->cgt;
+      double* part = nullptr;
+      const int64_t npart = 2 * (4 * g.ne / std::max(cgt_tile_blocks(g.m), 1) + 2);
+      CHECK(solv_vec(ctx, 2, npart + 2 * kChkReduceGroups, &part));
+      double* mid = part + npart;
+      double* sc = ctx->solv_sc + 8;
+      auto rest = [&]() -> int {  // levels 1.. of one cycle (their right-hand side is in place)
+        Level& c = h->lv[n - 1];
+        CHECK(coarse_solve(ctx, h, c.rhs, c.u[0]));
+        if (n > 2) CHECK(vcycle_up(ctx, h, b, nPost, alpha, nullptr, 1));
+        return AGGMG_OK;
+      };
+      h->last_coarse_ms = 0.0;
+      CHECK(vcycle_down(ctx, h, x0, b, nPre, alpha, 0));
+      CHECK(rest());
+      double* it_cur = l0.u[0];
+      double* it_alt = l0.u[1];
+      for (int it = 1; it <= maxiter; ++it) {
+        const bool check = (it % check_every == 0) || it == maxiter;
+        CgtChk chk;
+        chk.sweep = nPost;
+        chk.x = it < maxiter ? x_out : nullptr;
+        chk.exact = u_exact;
+        chk.part = part;
+        if (it < maxiter) {
+          CHECK(cgt_mid(ctx, h, it_cur, it_alt, b, nPost + nPre, alpha, check ? &chk : nullptr));
+          std::swap(it_cur, it_alt);
+        } else {
+          CHECK(cgt_up(ctx, h, 0, b, nPost, alpha, x_out, it_cur, &chk));
+        }
+        done = it;
+        if (check) {
+          CHECK(chk_reduce(ctx, 1, chk.ntiles, part, mid, sc));
+          double host[2] = {0.0, 0.0};
+          HIPCHK(hipMemcpyAsync(host, sc, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+          HIPCHK(hipStreamSynchronize(ctx->stream));
+          if (u_exact) err_hist[checks] = host[1];
+          res_hist[checks++] = host[0];
+          if (host[0] < tol * nb) break;
+        }
+        if (it < maxiter) {
+          CHECK(vcycle_down(ctx, h, nullptr, b, nPre, alpha, 1));
+          CHECK(rest());
+        }
+      }
       HIPCHK(hipStreamSynchronize(ctx->stream));
       *n_cycles = done;
       *n_checks = checks;
@@ -2635,6 +2704,11 @@ extern "C" int aggmg_smoother_solve_dev(aggmg_ctx* ctx, aggmg_op* A, aggmg_smoot
   int done = 0, checks = 0;
   *n_iters = 0;
   *n_checks = 0;
+  if (maxiter == 0) {  // the reference returns its initial `x = zeros(length(x0))` (src/solvers.jl:192)
+    HIPCHK(hipMemsetAsync(x_out, 0, N * sizeof(double), ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return AGGMG_OK;
+  }
   // Fused block-tridiagonal smoother on its own operator: launches of up to S sweeps with the residual test (and the error
   // norm) of every checked sweep formed INSIDE the launch (the checkpoint variant of the fused kernel, as
   // aggmg_multigrid_dev) -- the reference's test after every sweep (src/solvers.jl:198-206) at the multi-sweep smoother's
@@ -2645,7 +2719,9 @@ extern "C" int aggmg_smoother_solve_dev(aggmg_ctx* ctx, aggmg_op* A, aggmg_smoot
     const BtdDev& B0 = *sm->btd;
     const int smax = std::min(btd_max_sweeps(B0, 1), 16);   // (+ 1: the residual rows of the last sweep's iterate)
     double* part = nullptr;
-    CHECK(solv_vec(ctx, 2, (int64_t)smax * 2 * (2 * B0.ne / std::max(btd_tile_elems(B0), 1) + 2), &part));
+    const int64_t npart = (int64_t)smax * 2 * (2 * B0.ne / std::max(btd_tile_elems(B0), 1) + 2);
+    CHECK(solv_vec(ctx, 2, npart + (int64_t)smax * 2 * kChkReduceGroups, &part));
+    double* mid = part + npart;
     double* sc = ctx->solv_sc + 16;
     while (done < maxiter) {
       const int S = std::min(smax, maxiter - done);
@@ -2672,8 +2748,7 @@ extern "C" int aggmg_smoother_solve_dev(aggmg_ctx* ctx, aggmg_op* A, aggmg_smoot
       }
       int stop = -1;   // sweeps of this launch after which the tolerance was met
       if (nchk) {
-        hipLaunchKernelGGL(chk_reduce_kernel, dim3((unsigned)nchk), dim3(kThreads), 0, ctx->stream, ntiles, (const double*)part, sc);
-        HIPCHK(hipGetLastError());
+        CHECK(chk_reduce(ctx, nchk, ntiles, part, mid, sc));
         double host[32];
         HIPCHK(hipMemcpyAsync(host, sc, (size_t)2 * nchk * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -2686,6 +2761,55 @@ extern "C" int aggmg_smoother_solve_dev(aggmg_ctx* ctx, aggmg_op* A, aggmg_smoot
       }
       if (stop >= 0 && stop < S) {   // met before the launch's last sweep: that iterate again, without the rest
         CHECK(btd_smooth(ctx, B0, cur, b, alpha, stop, dst, 0, N, 0));
+        done += stop;
+      } else {
+        done += S;
+      }
+      cur = dst;
+      if (stop >= 0) break;
+    }
+    if (cur != x_out) HIPCHK(hipMemcpyAsync(x_out, cur, N * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    *n_iters = done;
+    *n_checks = checks;
+    return AGGMG_OK;
+  }
+  // point-Jacobi on a CG chain: the same with the chain kernel
+  if (ctx->mg_checkpoint && sm->cgt && sm->A == A && sm->cgt->sw == 0 && cgt_max_fused_sweeps(*sm->cgt) >= 2) {
+    const CgtDev& g = *sm->cgt;
+    const int smax = std::min(cgt_max_fused_sweeps(g) - 1, 16);
+    double* part = nullptr;
+    const int64_t npart = (int64_t)smax * 2 * (4 * g.ne / std::max(cgt_tile_blocks(g.m), 1) + 2);
+    CHECK(solv_vec(ctx, 2, npart + (int64_t)smax * 2 * kChkReduceGroups, &part));
+    double* mid = part + npart;
+    double* sc = ctx->solv_sc + 16;
+    while (done < maxiter) {
+      const int S = std::min(smax, maxiter - done);
+      double* dst = (cur == x_out) ? alt : x_out;
+      const int first = check_every - done % check_every;
+      CgtChk chk;
+      chk.sweep = first;
+      chk.stride = check_every;
+      chk.final = (done + S == maxiter && (done + S) % check_every != 0) ? 1 : 0;
+      chk.exact = u_exact;
+      chk.part = part;
+      const int nchk = (first <= S ? 1 + (S - first) / check_every : 0) + chk.final;
+      CHECK(cgt_smooth_ext(ctx, g, cur, b, alpha, S, dst, 0, nchk ? &chk : nullptr));
+      int stop = -1;
+      if (nchk) {
+        CHECK(chk_reduce(ctx, nchk, chk.ntiles, part, mid, sc));
+        double host[32];
+        HIPCHK(hipMemcpyAsync(host, sc, (size_t)2 * nchk * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        for (int k = 0; k < nchk && stop < 0; ++k) {
+          const int at = (chk.final && k == nchk - 1) ? S : first + k * check_every;
+          if (u_exact) err_hist[checks] = host[2 * k + 1];
+          res_hist[checks++] = host[2 * k];
+          if (host[2 * k] < tol * nb) stop = at;
+        }
+      }
+      if (stop >= 0 && stop < S) {
+        CHECK(cgt_smooth_ext(ctx, g, cur, b, alpha, stop, dst, 0));
         done += stop;
       } else {
         done += S;

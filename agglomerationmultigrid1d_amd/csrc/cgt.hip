@@ -67,18 +67,20 @@ static int cgt_max_sweeps(int m, int sw = 0) {
   return std::max(1, std::min(8, te / (8 * cgt_halo_per_sweep(sw))));
 }
 
+int cgt_max_fused_sweeps(const CgtDev& g) { return cgt_max_sweeps(g.m, g.sw); }
+
 template <int M, int K>
-static int cgt_launch_tt(aggmg_ctx* ctx, CgtArgs a, int sw);
+static int cgt_launch_tt(aggmg_ctx* ctx, CgtArgs a, int sw, int64_t* ntiles_out);
 
 template <int M>
-static int cgt_launch_t(aggmg_ctx* ctx, CgtArgs a, int sw) {
+static int cgt_launch_t(aggmg_ctx* ctx, CgtArgs a, int sw, int64_t* ntiles_out) {
   if (a.nsweeps == 0) sw = 0;
-  if (sw == 3) return cgt_launch_tt<M, 2>(ctx, a, sw);
-  return sw ? cgt_launch_tt<M, 1>(ctx, a, sw) : cgt_launch_tt<M, 0>(ctx, a, sw);
+  if (sw == 3) return cgt_launch_tt<M, 2>(ctx, a, sw, ntiles_out);
+  return sw ? cgt_launch_tt<M, 1>(ctx, a, sw, ntiles_out) : cgt_launch_tt<M, 0>(ctx, a, sw, ntiles_out);
 }
 
 template <int M, int K>
-static int cgt_launch_tt(aggmg_ctx* ctx, CgtArgs a, int sw) {
+static int cgt_launch_tt(aggmg_ctx* ctx, CgtArgs a, int sw, int64_t* ntiles_out) {
   using T = CgtTile<M, K>;
   // halo: one block per sweep and side (element Schwarz: the update of a block reads the residual of its two
   // neighbours, i.e. the iterate two blocks away); the residual needs one more valid neighbour on both sides,
@@ -89,7 +91,11 @@ static int cgt_launch_tt(aggmg_ctx* ctx, CgtArgs a, int sw) {
   if (a.do_residual) {
     hl += 1 + (a.tout.type == kTrChain ? 1 : 0);
     hr += 1 + (a.tout.type == kTrAgg ? 1 : 0);
+  } else if (a.chk_part) {   // a checkpoint after the last sweep forms residual rows of the final iterate
+    hl += 1;
+    hr += 1;
   }
+  if (a.chk_part && K != 0) return fail(ctx, AGGMG_ERR_UNSUPPORTED, "internal: checkpoint launch with element-block sweeps");
   const int align = a.tout.type == kTrAgg ? a.tout.rho : 1;
   const int owned = ((T::TE - hl - hr) / align) * align;
   if (owned <= 0) return fail(ctx, AGGMG_ERR_UNSUPPORTED, "chain tile too small for the requested halo");
@@ -98,9 +104,19 @@ static int cgt_launch_tt(aggmg_ctx* ctx, CgtArgs a, int sw) {
   a.tile_split = 0;
   a.tile_skip = 0;
   const int64_t ntiles = (a.lv.ne + owned - 1) / owned;
+  if (ntiles_out) *ntiles_out = ntiles;
   if (ntiles == 0) return AGGMG_OK;
   if (ntiles >= ((int64_t)1 << 31)) return fail(ctx, AGGMG_ERR_UNSUPPORTED, "grid too large");
-  const size_t lds = (size_t)(sw ? 3 : 2) * (T::TE + 2) * M * sizeof(double);
+  a.chk_tiles = ntiles;
+  if (a.chk_stride < 1) a.chk_stride = 1 << 30;
+  const size_t lds = (size_t)(sw ? 3 : 2) * (T::TE + 2) * M * sizeof(double) + (a.chk_part ? (size_t)2 * (T::NT / 64) * sizeof(double) : 0);
+  if constexpr (K == 0) {
+    if (a.chk_part) {
+      hipLaunchKernelGGL((cgt_fused_kernel<M, T::NS, T::NT, 0, true>), dim3((unsigned)ntiles), dim3(T::NT), lds, ctx->stream, a);
+      HIPCHK(hipGetLastError());
+      return AGGMG_OK;
+    }
+  }
   if constexpr (K == 2) {
     hipLaunchKernelGGL((cgt_fused_kernel<M, T::NS, T::NT, 3>), dim3((unsigned)ntiles), dim3(T::NT), lds, ctx->stream, a);
   } else if constexpr (K == 1) {
@@ -115,11 +131,11 @@ static int cgt_launch_tt(aggmg_ctx* ctx, CgtArgs a, int sw) {
   return AGGMG_OK;
 }
 
-static int cgt_launch(aggmg_ctx* ctx, const CgtDev& g, const CgtArgs& a) {
+static int cgt_launch(aggmg_ctx* ctx, const CgtDev& g, const CgtArgs& a, int64_t* ntiles_out = nullptr) {
   switch (g.m) {
 #define CASE(MM) \
   case MM:       \
-    return cgt_launch_t<MM>(ctx, a, g.sw);
+    return cgt_launch_t<MM>(ctx, a, g.sw, ntiles_out);
     CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
 #undef CASE
   }
@@ -166,10 +182,11 @@ struct CgtChain {
 };
 
 static int cgt_run(aggmg_ctx* ctx, const CgtDev& g, const CgtChain& c, double alpha, int nsweeps, const CgtArgs& first,
-                   const CgtArgs& last, int kind, int level) {
+                   const CgtArgs& last, int kind, int level, CgtChk* chk = nullptr) {
   // at most smax sweeps per launch (2 * smax + 3 blocks of halo always fit a tile)
   const int smax = cgt_max_sweeps(g.m, g.sw);
   const int nl = std::max(1, (nsweeps + smax - 1) / smax);
+  if (chk && (nl != 1 || g.sw != 0)) return fail(ctx, AGGMG_ERR_UNSUPPORTED, "internal: checkpoints need the sweeps in one point-Jacobi launch");
   if (nl > 1 && (!c.t0 || (nl > 2 && !c.t1))) return fail(ctx, AGGMG_ERR_UNSUPPORTED, "internal: chain temporaries missing");
   const double* src = c.src;
   bool src_ext = c.src_ext;
@@ -200,9 +217,19 @@ static int cgt_run(aggmg_ctx* ctx, const CgtDev& g, const CgtChain& c, double al
       dst = (q % 2 == 0) ? c.t0 : c.t1;  // launch q reads what launch q - 1 wrote
     }
     a.u_out = dst;
+    if (chk) {
+      a.chk_sweep = chk->sweep;
+      a.chk_stride = chk->stride;
+      a.chk_final = chk->final;
+      a.chk_x = chk->x;
+      a.chk_exact = chk->exact;
+      a.chk_part = chk->part;
+      a.ext |= kExtB;   // (the caller-side indices are formed: chk_x / chk_exact go through them)
+      if (!c.b_ext) return fail(ctx, AGGMG_ERR_UNSUPPORTED, "internal: checkpoint launch on block-ordered vectors");
+    }
     {
       ProfScope ps(ctx, q == nl - 1 ? kind : AGGMG_KIND_SMOOTH, level);
-      CHECK(cgt_launch(ctx, g, a));
+      CHECK(cgt_launch(ctx, g, a, chk ? &chk->ntiles : nullptr));
     }
     src = dst;
     src_ext = false;
@@ -211,7 +238,7 @@ static int cgt_run(aggmg_ctx* ctx, const CgtDev& g, const CgtChain& c, double al
 }
 
 int cgt_smooth_ext(aggmg_ctx* ctx, const CgtDev& g, const double* u_in, const double* b, double alpha, int nsweeps,
-                   double* u_out, int level) {
+                   double* u_out, int level, CgtChk* chk) {
   if (nsweeps == 0) {
     if (u_in)
       HIPCHK(hipMemcpyAsync(u_out, u_in, g.N * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
@@ -232,7 +259,7 @@ int cgt_smooth_ext(aggmg_ctx* ctx, const CgtDev& g, const double* u_in, const do
   }
   CgtArgs none;
   std::memset(&none, 0, sizeof(none));
-  return cgt_run(ctx, g, c, alpha, nsweeps, none, none, AGGMG_KIND_SMOOTH, level);
+  return cgt_run(ctx, g, c, alpha, nsweeps, none, none, AGGMG_KIND_SMOOTH, level, chk);
 }
 
 int cgt_residual_ext(aggmg_ctx* ctx, const CgtDev& g, const double* u, const double* b, double* r_out) {
@@ -270,7 +297,8 @@ int cgt_down(aggmg_ctx* ctx, aggmg_hier* h, int k, const double* uin, const doub
 
 // ascending half (src/solvers.jl:41-47): prolongation-add, nPost sweeps
 // src: the pre-smoothed iterate in block order (default: the level's u[0])
-int cgt_up(aggmg_ctx* ctx, aggmg_hier* h, int k, const double* rhs, int nPost, double alpha, double* dst, const double* src) {
+int cgt_up(aggmg_ctx* ctx, aggmg_hier* h, int k, const double* rhs, int nPost, double alpha, double* dst, const double* src,
+           CgtChk* chk) {
   const int n = (int)h->lv.size();
   Level& l = h->lv[k];
   Level& c = h->lv[k + 1];
@@ -291,14 +319,15 @@ int cgt_up(aggmg_ctx* ctx, aggmg_hier* h, int k, const double* rhs, int nPost, d
   std::memset(&none, 0, sizeof(none));
   first.tin = cgt_xfer(*l.tc, c.native_io);
   first.uc = (k + 1 == n - 1) ? c.u[0] : c.u[1];
-  return cgt_run(ctx, g, ch, alpha, nPost, first, none, AGGMG_KIND_FUSED_UP, k);
+  return cgt_run(ctx, g, ch, alpha, nPost, first, none, AGGMG_KIND_FUSED_UP, k, chk);
 }
 
 // Between two cycles of multigrid()'s loop (src/solvers.jl:124-126) the fine level post-smooths and then
 // pre-smooths the same iterate with the same right-hand side: prolongation-add, nPost + nPre sweeps,
 // residual and restriction in ONE launch -- the fine operator is read once per cycle instead of twice.
 // cur -> alt, both in block order; b is the caller's vector.
-int cgt_mid(aggmg_ctx* ctx, aggmg_hier* h, const double* cur, double* alt, const double* b, int nsweeps, double alpha) {
+int cgt_mid(aggmg_ctx* ctx, aggmg_hier* h, const double* cur, double* alt, const double* b, int nsweeps, double alpha,
+            CgtChk* chk) {
   const int n = (int)h->lv.size();
   Level& l = h->lv[0];
   Level& c = h->lv[1];
@@ -320,7 +349,7 @@ int cgt_mid(aggmg_ctx* ctx, aggmg_hier* h, const double* cur, double* alt, const
   last.do_residual = 1;
   last.tout = cgt_xfer(*l.tc, c.native_io);
   last.rc_out = c.rhs;
-  return cgt_run(ctx, g, ch, alpha, nsweeps, first, last, AGGMG_KIND_FUSED_MID, 0);
+  return cgt_run(ctx, g, ch, alpha, nsweeps, first, last, AGGMG_KIND_FUSED_MID, 0, chk);
 }
 
 // ---- compulsory bytes: what the arrays of a launch hold, each read or written once -------------

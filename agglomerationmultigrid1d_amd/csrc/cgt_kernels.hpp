@@ -76,6 +76,15 @@ struct CgtArgs {
   int tile_split;
   int64_t tile_skip;
   int gs;  // SW == 3: colour order of a sweep, 1 = even elements then odd ones, 2 = the reverse (post-smoothing)
+  // checkpoints (CHK variant; the fields and their meaning as FusedArgs's, kernels.hpp): after chk_sweep, chk_sweep +
+  // chk_stride, ... sweeps, and (chk_final) after the last, the tile's sums of squares of b - A u and of u - chk_exact over
+  // its owned rows go to chk_part[(k * chk_tiles + tile)][2], the iterate to chk_x; chk_exact / chk_x live in the caller's
+  // numbering (through perm, like b)
+  int chk_sweep, chk_stride, chk_final;
+  int64_t chk_tiles;
+  double* chk_x;
+  const double* chk_exact;
+  double* chk_part;
 };
 
 __device__ __forceinline__ int64_t cgt_tile(const CgtArgs& a) {
@@ -93,8 +102,9 @@ __device__ __forceinline__ int64_t cgt_tile(const CgtArgs& a) {
 // CG-fine hierarchy of config 5): red-black element Gauss-Seidel.  A sweep is two half-sweeps, one per element
 // colour (elements of one colour share no node): r = b - A u, then u[nodes_e] += alpha (A_e \ r[nodes_e]) for
 // every element of the colour; a.gs gives the colour order.  Four blocks of halo per sweep and side.
-template <int M, int NS, int NT, int SW = 0>
+template <int M, int NS, int NT, int SW = 0, bool CHK = false>
 __global__ __launch_bounds__(NT) void cgt_fused_kernel(CgtArgs a) {
+  static_assert(!CHK || SW == 0, "the checkpoint variant is for point-Jacobi launches");
   // GRP: a block's rows sit in M = 2^k adjacent lanes; lane i keeps entry i of the block's
   // sub-diagonal row and the dot product with the left neighbour is a cross-lane sum
   constexpr bool GRP = (M == 1 || M == 2 || M == 4 || M == 8);
@@ -267,7 +277,58 @@ __global__ __launch_bounds__(NT) void cgt_fused_kernel(CgtArgs a) {
   // ---- sweeps: u <- u + alpha * ((b - A u) / diag)   (LDS ping-pong) ------------------------------
   double* cur = buf0;
   double* nxt = buf1;
+  // CHK: residual rows of the iterate in `it` on the owned blocks (the operator rows are in registers: the expressions of
+  // the closing residual), sums over the tile in a fixed order -- waves, then the workgroup's waves
+  [[maybe_unused]] int kchk = 0;
+  [[maybe_unused]] auto checkpoint = [&](const double* it) {
+    double sr2 = 0.0, se2 = 0.0;
+    const int c0 = a.halo_left, c1 = a.halo_left + a.owned;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const int x = s * EPS + le;
+      if (active) {
+        const double t = row_Au(s, x, it);   // (every lane of a group takes part in the cross-lane sum)
+        if (valid[s] && x >= c0 && x < c1) {
+          const double r = bb[s] - t;
+          sr2 += r * r;
+          if (pr[s] >= 0) {   // (padding rows of the trailing block: identity rows with b = u = 0, no caller-side entry)
+            if (a.chk_exact) {
+              const double dd = uu[s] - a.chk_exact[pr[s]];
+              se2 += dd * dd;
+            }
+            if (a.chk_x) AGGMG_ST(a.chk_x[pr[s]], uu[s]);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      sr2 += __shfl_xor(sr2, off, 64);
+      se2 += __shfl_xor(se2, off, 64);
+    }
+    double* red = lds + 2 * (TE + 2) * M;   // (the launch reserves 2 * NT / 64 doubles behind the iterate buffers)
+    if ((tid & 63) == 0) {
+      red[2 * (tid >> 6)] = sr2;
+      red[2 * (tid >> 6) + 1] = se2;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      double tr = 0.0, te = 0.0;
+      for (int w = 0; w < NT / 64; ++w) {
+        tr += red[2 * w];
+        te += red[2 * w + 1];
+      }
+      double* out = a.chk_part + (kchk * a.chk_tiles + cgt_tile(a)) * 2;
+      out[0] = tr;
+      out[1] = te;
+    }
+    ++kchk;
+  };
+  [[maybe_unused]] auto chk_due = [&](int sw) { return sw >= a.chk_sweep && (sw - a.chk_sweep) % a.chk_stride == 0; };
   for (int sw = 0; sw < (SW == 3 ? 2 * a.nsweeps : a.nsweeps); ++sw) {
+    if constexpr (CHK) {
+      if (chk_due(sw)) checkpoint(cur);
+    }
     if (SW) {
       const int colour = (SW == 3) ? ((a.gs == 2) ? 1 - (sw & 1) : (sw & 1)) : 0;
       // phase A: the residual of every row of the tile into LDS
@@ -327,6 +388,10 @@ __global__ __launch_bounds__(NT) void cgt_fused_kernel(CgtArgs a) {
     double* t = cur;
     cur = nxt;
     nxt = t;
+  }
+
+  if constexpr (CHK) {
+    if (a.chk_final || chk_due(a.nsweeps)) checkpoint(cur);   // a launch that ends on a checked iterate
   }
 
   // ---- store the iterate of the owned blocks -------------------------------------------------------

@@ -384,18 +384,30 @@ struct ProfScope {
 // CG chain path (cgt.hip)
 // ---------------------------------------------------------------------------------------------
 int cgt_tile_blocks(int m);
+// checkpoints of a chain launch (CgtArgs::chk_*): in -- after `sweep`, `sweep + stride`, ... sweeps and (`final`) after the
+// last one, norms' partial sums to `part`, iterate to `x`, error against `exact` (both in the caller's numbering, may be
+// null); out -- the launch's tile count (the stride of `part` between checkpoints)
+struct CgtChk {
+  int sweep = 0, stride = 1 << 30, final = 0;
+  double* x = nullptr;
+  const double* exact = nullptr;
+  double* part = nullptr;
+  int64_t ntiles = 0;
+};
+int cgt_max_fused_sweeps(const CgtDev& g);   // sweeps one launch takes (point-Jacobi: + a residual or a closing checkpoint)
 int cgt_build(aggmg_ctx* ctx, aggmg_smoother* sm, const int64_t* elems, int64_t m1, int64_t nel, int one_based);
 int cgt_attach_schwarz(aggmg_ctx* ctx, aggmg_smoother* sm, int sw);
 int cgt_build_transfer(aggmg_ctx* ctx, const aggmg_op* L, const CgtDev& fine, const CgtDev* coarse, int hint_mc,
                        TransferCgt* out, bool* ok);
 // nsweeps sweeps on external (reference-numbered) vectors; u_in may be nullptr (zero), u_out != u_in
 int cgt_smooth_ext(aggmg_ctx* ctx, const CgtDev& g, const double* u_in, const double* b, double alpha, int nsweeps,
-                   double* u_out, int level);
+                   double* u_out, int level, CgtChk* chk = nullptr);
 int cgt_residual_ext(aggmg_ctx* ctx, const CgtDev& g, const double* u, const double* b, double* r_out);
 int cgt_down(aggmg_ctx* ctx, aggmg_hier* h, int k, const double* uin, const double* rhs, int nPre, double alpha);
 int cgt_up(aggmg_ctx* ctx, aggmg_hier* h, int k, const double* rhs, int nPost, double alpha, double* dst,
-           const double* src = nullptr);
-int cgt_mid(aggmg_ctx* ctx, aggmg_hier* h, const double* cur, double* alt, const double* b, int nsweeps, double alpha);
+           const double* src = nullptr, CgtChk* chk = nullptr);
+int cgt_mid(aggmg_ctx* ctx, aggmg_hier* h, const double* cur, double* alt, const double* b, int nsweeps, double alpha,
+            CgtChk* chk = nullptr);
 // compulsory bytes (every array of the launch once) of a chain level's fused launches / of a stand-alone sweep or residual launch
 int cgt_launch_bytes(aggmg_ctx* ctx, const aggmg_hier* h, int level, bool down, bool up, bool has_x0, int64_t* rd, int64_t* wr);
 int cgt_op_launch_bytes(const CgtDev& g, bool sweeps, int64_t* rd, int64_t* wr);

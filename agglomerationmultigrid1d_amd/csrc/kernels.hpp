@@ -508,15 +508,16 @@ static __global__ __launch_bounds__(kThreads) void dot_final_kernel(int nparts, 
   if (threadIdx.x == 0) out[0] = take_sqrt ? sqrt(sh[0]) : sh[0];
 }
 
-// out[0] = sqrt(sum_t part[t][0]), out[1] = sqrt(sum_t part[t][1]): the tile sums of a checkpoint launch (one
-// workgroup, fixed summation order)
-static __global__ __launch_bounds__(kThreads) void chk_reduce_kernel(int64_t ntiles, const double* __restrict__ part,
-                                                                   double* __restrict__ out) {
+// The tile sums of a checkpoint launch -> out[k] = (sqrt(sum_t part[k][t][0]), sqrt(sum_t part[k][t][1])) per checkpoint k,
+// in two stages with a fixed summation order (hundreds of thousands of tiles at 2^24 elements: one workgroup walking
+// them alone took 0.5 - 3 ms, latency-bound): stage 1, grid (G, checkpoints): workgroup g sums tiles g * 256 + tid,
+// + G * 256, ... into mid[k][g][2]; stage 2, one workgroup per checkpoint: the G sums, root.
+static __global__ __launch_bounds__(kThreads) void chk_reduce1_kernel(int64_t ntiles, const double* __restrict__ part,
+                                                                    double* __restrict__ mid) {
   __shared__ double sh[2][kThreads];
-  part += (int64_t)blockIdx.x * ntiles * 2;   // one workgroup per checkpoint of the launch
-  out += blockIdx.x * 2;
+  part += (int64_t)blockIdx.y * ntiles * 2;
   double a0 = 0.0, a1 = 0.0;
-  for (int64_t t = threadIdx.x; t < ntiles; t += kThreads) {
+  for (int64_t t = (int64_t)blockIdx.x * kThreads + threadIdx.x; t < ntiles; t += (int64_t)gridDim.x * kThreads) {
     a0 += part[2 * t];
     a1 += part[2 * t + 1];
   }
@@ -531,10 +532,35 @@ static __global__ __launch_bounds__(kThreads) void chk_reduce_kernel(int64_t nti
     __syncthreads();
   }
   if (threadIdx.x == 0) {
-    out[0] = sqrt(sh[0][0]);
-    out[1] = sqrt(sh[1][0]);
+    double* o = mid + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 2;
+    o[0] = sh[0][0];
+    o[1] = sh[1][0];
   }
 }
+static __global__ __launch_bounds__(kThreads) void chk_reduce2_kernel(int G, const double* __restrict__ mid, double* __restrict__ out) {
+  __shared__ double sh[2][kThreads];
+  mid += (int64_t)blockIdx.x * G * 2;
+  double a0 = 0.0, a1 = 0.0;
+  for (int t = threadIdx.x; t < G; t += kThreads) {
+    a0 += mid[2 * t];
+    a1 += mid[2 * t + 1];
+  }
+  sh[0][threadIdx.x] = a0;
+  sh[1][threadIdx.x] = a1;
+  __syncthreads();
+  for (int s = kThreads / 2; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) {
+      sh[0][threadIdx.x] += sh[0][threadIdx.x + s];
+      sh[1][threadIdx.x] += sh[1][threadIdx.x + s];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    out[blockIdx.x * 2] = sqrt(sh[0][0]);
+    out[blockIdx.x * 2 + 1] = sqrt(sh[1][0]);
+  }
+}
+constexpr int kChkReduceGroups = 256;   // stage-1 workgroups per checkpoint at most
 
 // PCG step with q = -A p (the residual kernel's sign):  a = rz / (-(p.q));  x += a p;  r += a q
 static __global__ __launch_bounds__(kThreads) void pcg_xr_kernel(int64_t n, double* __restrict__ x, double* __restrict__ r,

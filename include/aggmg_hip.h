@@ -81,7 +81,8 @@ int aggmg_synchronize(aggmg_ctx* ctx);
  * that goes on to pre-smooth the next cycle -- instead of in a residual launch of its own; the iterates are bit for bit
  * the same, the norms equal to round-off (another summation order).  aggmg_smoother_solve_dev likewise: launches of
  * several sweeps with the norms of every checked sweep formed inside (a launch in whose middle the tolerance is met is run
- * again up to that sweep).  Fused block-tridiagonal fine levels / smoothers only; others take the separate launches. */
+ * again up to that sweep).  Fused block-tridiagonal and point-Jacobi CG-chain fine levels / smoothers; others take the
+ * separate launches. */
 #define AGGMG_OPT_MG_CHECKPOINT 5
 int aggmg_set_option(aggmg_ctx* ctx, int option, int value);
 /* Raw device memory owned by the context's device (plumbing for harnesses without torch, and the storage of the

@@ -86,6 +86,9 @@ def test_smoother_solve_device_loop(oracle, mg):
     assert itg == ito == 40 and errg == []
     assert np.allclose(resg, reso, rtol=1e-10, atol=1e-12 * np.linalg.norm(b))
     assert np.linalg.norm(xg - xo) <= 1e-12 * np.linalg.norm(xo)
+    # maxiter = 0: the reference returns its initial `x = zeros(length(x0))` (src/solvers.jl:192), whatever x0 holds
+    xz, itz, resz, _ = mg.iterative_smoother_solve(A, Sg, np.ones(len(b)), b, maxiter=0, tol=1e-30, alpha=2.0 / 3.0, exact=False)
+    assert itz == 0 and resz == [] and not xz.any()
     x5, it5, res5, _ = mg.iterative_smoother_solve(A, Sg, u0, b, maxiter=40, tol=1e-30, alpha=2.0 / 3.0, exact=False,
                                                   check_every=5)
     assert it5 == 40 and len(res5) == 8
@@ -132,6 +135,47 @@ def test_smoother_solve_checkpoints_inside_the_sweep_launches(oracle, mg, ne):
     assert out[1][1][1] == 11                         # stopped inside a launch: 11 sweeps, not the launch's full count
     xo, ito, reso, _ = o.iterative_smoother_solve(A, o.dg_smoother(dg, A, 'blockJac'), u0, b, maxiter=40, tol=tol_mid, alpha=2.0 / 3.0)
     xg, itg, resg, _ = out[1][1]
+    assert itg == ito and np.allclose(resg, reso, rtol=1e-9, atol=1e-12 * np.linalg.norm(b))
+    assert np.linalg.norm(xg - xo) <= 1e-11 * np.linalg.norm(xo)
+
+
+@pytest.mark.parametrize("ne", [40, 3000])    # one tile / many tiles
+def test_checkpoints_inside_the_chain_kernel_launches(oracle, mg, ne):
+    """The same two loops on a CG hierarchy (CG p = 4 -> 2 -> 1 -> DG p = 0, point-Jacobi; the fine levels run the chain
+    kernel): multigrid's test after every cycle inside the launch shared by consecutive cycles, iterative_smoother_solve's
+    test after every sweep inside multi-sweep launches -- against the forms with separate residual launches
+    (AGGMG_OPT_MG_CHECKPOINT = 0): iterates bit for bit (the checkpoint's x goes out through the level's permutation),
+    equal counts, histories to round-off; and against the oracle."""
+    from agglomerationmultigrid1d_amd import _lib
+    o = oracle
+    Ho, b = o.build_cg_hierarchy(ne, ps=(4, 2, 1), nDG=1)
+    A, cgm = Ho.mStiffness[0], Ho.mMeshes[0]
+    x0 = o.splitmix_normal(len(b), 3)
+    _, _, rp, _ = o.iterative_smoother_solve(A, o.cg_smoother(cgm, A, 'jac'), x0, b, maxiter=12, tol=1e-30, alpha=0.5)
+    tol_mid = 0.5 * (rp[8] + rp[9]) / np.linalg.norm(b)
+    mg_cases = ((1, 25, 1e-7, True), (1, 6, 1e-30, False), (2, 7, 1e-30, True), (3, 25, 1e-5, False), (1, 1, 1e-30, False))
+    sm_cases = ((1, 19, 1e-30, False), (1, 30, tol_mid, True), (4, 19, 1e-30, False), (3, 30, tol_mid, False), (1, 1, 1e-30, False))
+    out = {}
+    for chk in (1, 0):
+        ctx = mg.Context(0)
+        ctx.set_option(_lib.OPT_MG_CHECKPOINT, chk)
+        H = mg.MeshHierarchy.from_reference(Ho, ctx=ctx)
+        assert H.level_kinds()[0] == "fused_chain"
+        runs = [mg.multigrid(H, x0, b, mi, tol, exact=ex, check_every=ce) for ce, mi, tol, ex in mg_cases]
+        Sg = mg.cg_smoother(cgm, A, 'jac', ctx=ctx)
+        runs += [mg.iterative_smoother_solve(A, Sg, x0, b, maxiter=mi, tol=tol, alpha=0.5, exact=ex, check_every=ce)
+                 for ce, mi, tol, ex in sm_cases]
+        out[chk] = runs
+    for k, ((xa, ia, ra, ea), (xb, ib, rb, eb)) in enumerate(zip(out[1], out[0])):
+        assert ia == ib and len(ra) == len(rb) and len(ea) == len(eb), k
+        assert np.array_equal(xa, xb), k
+        assert np.allclose(ra, rb, rtol=1e-10, atol=1e-13 * np.linalg.norm(b)) and np.allclose(ea, eb, rtol=1e-8, atol=1e-11), k
+    assert out[1][len(mg_cases) + 1][1] == 10        # the smoother loop stopped inside a launch
+    xo, ito, reso, _ = o.multigrid(Ho, x0, b, 25, 1e-7)
+    xg, itg, resg, _ = out[1][0]
+    assert itg == ito and np.allclose(resg, reso, rtol=1e-7, atol=1e-11 * np.linalg.norm(b))
+    xo, ito, reso, _ = o.iterative_smoother_solve(A, o.cg_smoother(cgm, A, 'jac'), x0, b, maxiter=30, tol=tol_mid, alpha=0.5)
+    xg, itg, resg, _ = out[1][len(mg_cases) + 1]
     assert itg == ito and np.allclose(resg, reso, rtol=1e-9, atol=1e-12 * np.linalg.norm(b))
     assert np.linalg.norm(xg - xo) <= 1e-11 * np.linalg.norm(xo)
 

@@ -17,16 +17,22 @@ def main():
     ap.add_argument("--log2-elems", type=int, default=24)
     ap.add_argument("--iters", type=int, default=12)
     ap.add_argument("--profile", action="store_true")
+    ap.add_argument("--cg", action="store_true", help="config 5's shape (CG p = 4 -> 2 -> 1 -> DG p = 0, point-Jacobi) instead of config 3's")
     args = ap.parse_args()
     import agglomerationmultigrid1d_amd as mg
-    from agglomerationmultigrid1d_amd.uniform import UniformDgAggHierarchy, build_device_hierarchy
+    from agglomerationmultigrid1d_amd.uniform import (UniformCgDgHierarchy, UniformDgAggHierarchy, build_device_cg_hierarchy,
+                                                      build_device_hierarchy)
     ctx = mg.Context(0)
-    U = UniformDgAggHierarchy(2 ** args.log2_elems, p=3, pAgg=1, ratios=(4, 2, 2))
-    H = build_device_hierarchy(U, ctx)
+    if args.cg:
+        U = UniformCgDgHierarchy(2 ** args.log2_elems, ps=(4, 2, 1))
+        H = build_device_cg_hierarchy(U, ctx)
+    else:
+        U = UniformDgAggHierarchy(2 ** args.log2_elems, p=3, pAgg=1, ratios=(4, 2, 2))
+        H = build_device_hierarchy(U, ctx)
     b = ctx.to_device(U.rhs())
     N = len(U.rhs())
     x0 = ctx.to_device(np.zeros(N))
-    out = {"log2_elems": args.log2_elems}
+    out = {"log2_elems": args.log2_elems, "hierarchy": "cg p=4,2,1 -> dg p=0" if args.cg else "dg p=3 -> agg 4:1, 2:1, 2:1"}
     for ce in (1, 2, 8):
         mg.multigrid_dev(H, x0, b, 2 * ce, 1e-30, check_every=ce)
         ctx.synchronize()
