@@ -521,6 +521,7 @@ def cg_bench(mg, ctx, args, nPre, nPost, alpha):
         t2 = time.perf_counter()
         _, ncyc, res = mg.multigrid_dev(H, ctx.to_device(np.zeros(N)), b, 200, 1e-8, check_every=4)
         outer["multigrid"] = {"cycles": ncyc, "ms": 1e3 * (time.perf_counter() - t2), "final_residual": res[-1]}
+        mg.multigrid_dev(H, ctx.to_device(np.zeros(N)), b, 2, 1e-30, check_every=1)         # (work vectors, first use of the variant)
         t2 = time.perf_counter()     # the reference's semantics: a check after every cycle, formed inside the chain kernel's launch
         _, ncyc1, res1 = mg.multigrid_dev(H, ctx.to_device(np.zeros(N)), b, 200, 1e-8, check_every=1)
         dt1 = 1e3 * (time.perf_counter() - t2)
@@ -683,6 +684,7 @@ def main():
             outer["multigrid"] = {"cycles": ncyc, "ms": 1e3 * (time.perf_counter() - t2), "final_residual": res[-1]}
             # the reference's own semantics -- res / err after EVERY cycle (src/solvers.jl:124-131): the norms are formed
             # inside the fine-level launch that post-smooths cycle i and pre-smooths cycle i + 1
+            mg.multigrid_dev(H, ctx.to_device(np.zeros(N)), b, 2, 1e-30, check_every=1)     # (work vectors, first use of the variant)
             t2 = time.perf_counter()
             _, ncyc1, res1 = mg.multigrid_dev(H, ctx.to_device(np.zeros(N)), b, 400, 1e-8, check_every=1)
             dt1 = 1e3 * (time.perf_counter() - t2)
