@@ -2576,7 +2576,6 @@ extern "C" int aggmg_multigrid_dev(aggmg_ctx* ctx, aggmg_hier* h, const double* 
         if (check) {
           a.chk_sweep = nPost;
           a.chk_stride = 1 << 30;   // one checkpoint per launch
-          a.chk_x = it < maxiter ? x_out : nullptr;
           a.chk_exact = u_exact;
           a.chk_part = part;
         }
@@ -2594,12 +2593,28 @@ extern "C" int aggmg_multigrid_dev(aggmg_ctx* ctx, aggmg_hier* h, const double* 
           HIPCHK(hipStreamSynchronize(ctx->stream));
           if (u_exact) err_hist[checks] = host[1];   // err[i] = ||x - u_exact||, src/solvers.jl:128
           res_hist[checks++] = host[0];              // res[i] = ||A x - b||,      :127
-          if (host[0] < tol * nb) break;             // :131
+          if (host[0] < tol * nb) {                  // :131
+            if (it < maxiter) {
+              // x_it passed through LDS only (no store per checked cycle: 8 B/DoF saved every time).  The launch's input --
+              // the pre-smoothed iterate of cycle `it`, now in it_alt -- and the coarse correction are untouched: the
+              // ascent once more, alone, gives x_it with the same arithmetic
+              FusedArgs f = btd_args(B0);
+              f.u_in = it_alt;
+              f.b = b;
+              f.alpha = alpha;
+              f.lf_in = l0.tb->lf;
+              f.uc = uc;
+              xfer_in(f, *l0.tb);
+              f.u_out = x_out;
+              f.nsweeps = nPost;
+              ProfScope ps(ctx, AGGMG_KIND_FUSED_UP, 0);
+              CHECK(launch_btd(ctx, B0, f, nPost));
+            }
+            break;
+          }
         }
         if (it < maxiter) CHECK(coarse_part(true));
       }
-      // (a cycle that was not the last one left x_done in x_out at its checkpoint; the last ascent wrote it there itself.
-      // Stopping happens at checks only, so x_out holds the iterate the histories end with.)
       HIPCHK(hipStreamSynchronize(ctx->stream));
       *n_cycles = done;
       *n_checks = checks;
@@ -2633,7 +2648,6 @@ extern "C" int aggmg_multigrid_dev(aggmg_ctx* ctx, aggmg_hier* h, const double* 
         const bool check = (it % check_every == 0) || it == maxiter;
         CgtChk chk;
         chk.sweep = nPost;
-        chk.x = it < maxiter ? x_out : nullptr;
         chk.exact = u_exact;
         chk.part = part;
         if (it < maxiter) {
@@ -2650,7 +2664,11 @@ extern "C" int aggmg_multigrid_dev(aggmg_ctx* ctx, aggmg_hier* h, const double* 
           HIPCHK(hipStreamSynchronize(ctx->stream));
           if (u_exact) err_hist[checks] = host[1];
           res_hist[checks++] = host[0];
-          if (host[0] < tol * nb) break;
+          if (host[0] < tol * nb) {
+            // (no store of x at the checkpoints: the ascent once more from the launch's untouched input, now in it_alt)
+            if (it < maxiter) CHECK(cgt_up(ctx, h, 0, b, nPost, alpha, x_out, it_alt));
+            break;
+          }
         }
         if (it < maxiter) {
           CHECK(vcycle_down(ctx, h, nullptr, b, nPre, alpha, 1));

@@ -221,10 +221,9 @@ static int cgt_run(aggmg_ctx* ctx, const CgtDev& g, const CgtChain& c, double al
       a.chk_sweep = chk->sweep;
       a.chk_stride = chk->stride;
       a.chk_final = chk->final;
-      a.chk_x = chk->x;
       a.chk_exact = chk->exact;
       a.chk_part = chk->part;
-      a.ext |= kExtB;   // (the caller-side indices are formed: chk_x / chk_exact go through them)
+      a.ext |= kExtB;   // (the caller-side indices are formed: chk_exact goes through them)
       if (!c.b_ext) return fail(ctx, AGGMG_ERR_UNSUPPORTED, "internal: checkpoint launch on block-ordered vectors");
     }
     {

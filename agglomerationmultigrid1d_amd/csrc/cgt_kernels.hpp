@@ -78,11 +78,10 @@ struct CgtArgs {
   int gs;  // SW == 3: colour order of a sweep, 1 = even elements then odd ones, 2 = the reverse (post-smoothing)
   // checkpoints (CHK variant; the fields and their meaning as FusedArgs's, kernels.hpp): after chk_sweep, chk_sweep +
   // chk_stride, ... sweeps, and (chk_final) after the last, the tile's sums of squares of b - A u and of u - chk_exact over
-  // its owned rows go to chk_part[(k * chk_tiles + tile)][2], the iterate to chk_x; chk_exact / chk_x live in the caller's
-  // numbering (through perm, like b)
+  // its owned rows go to chk_part[(k * chk_tiles + tile)][2]; chk_exact lives in the caller's numbering (through perm,
+  // like b)
   int chk_sweep, chk_stride, chk_final;
   int64_t chk_tiles;
-  double* chk_x;
   const double* chk_exact;
   double* chk_part;
 };
@@ -291,12 +290,9 @@ __global__ __launch_bounds__(NT) void cgt_fused_kernel(CgtArgs a) {
         if (valid[s] && x >= c0 && x < c1) {
           const double r = bb[s] - t;
           sr2 += r * r;
-          if (pr[s] >= 0) {   // (padding rows of the trailing block: identity rows with b = u = 0, no caller-side entry)
-            if (a.chk_exact) {
-              const double dd = uu[s] - a.chk_exact[pr[s]];
-              se2 += dd * dd;
-            }
-            if (a.chk_x) AGGMG_ST(a.chk_x[pr[s]], uu[s]);
+          if (a.chk_exact && pr[s] >= 0) {   // (padding rows of the trailing block have no caller-side entry)
+            const double dd = uu[s] - a.chk_exact[pr[s]];
+            se2 += dd * dd;
           }
         }
       }

@@ -385,11 +385,10 @@ struct ProfScope {
 // ---------------------------------------------------------------------------------------------
 int cgt_tile_blocks(int m);
 // checkpoints of a chain launch (CgtArgs::chk_*): in -- after `sweep`, `sweep + stride`, ... sweeps and (`final`) after the
-// last one, norms' partial sums to `part`, iterate to `x`, error against `exact` (both in the caller's numbering, may be
-// null); out -- the launch's tile count (the stride of `part` between checkpoints)
+// last one, norms' partial sums to `part`, error against `exact` (caller's numbering, may be null); out -- the launch's
+// tile count (the stride of `part` between checkpoints)
 struct CgtChk {
   int sweep = 0, stride = 1 << 30, final = 0;
-  double* x = nullptr;
   const double* exact = nullptr;
   double* part = nullptr;
   int64_t ntiles = 0;

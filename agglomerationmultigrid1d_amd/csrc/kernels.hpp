@@ -661,9 +661,10 @@ struct FusedArgs {
   int gs;
   // Checkpoint (btd_fused_kernel<..., CHK = true> only; the loop of multigrid, src/solvers.jl:124-131, with its
   // residual test after EVERY cycle): after chk_sweep of the nsweeps sweeps -- between the post-smoothing of one cycle
-  // and the pre-smoothing of the next, which share this launch -- the iterate of the owned elements goes to chk_x (may
-  // be null), and the tile's sums of squares of b - A u and (chk_exact not null) of u - u_exact over its owned rows to
-  // chk_part[tile][2]: ||A x - b|| (:127) and ||x - u_exact|| (:128) without a residual launch of their own.
+  // and the pre-smoothing of the next, which share this launch -- the tile's sums of squares of b - A u and (chk_exact
+  // not null) of u - u_exact over its owned rows go to chk_part[tile][2]: ||A x - b|| (:127) and ||x - u_exact|| (:128)
+  // without a residual launch of their own.  The iterate itself is not stored: when the loop stops at this check, the
+  // launch's input is still there and the ascent is run once more on its own.
   int chk_sweep;
   // more than one checkpoint per launch (iterative_smoother_solve's test after every sweep, src/solvers.jl:198-206):
   // after chk_sweep, chk_sweep + chk_stride, ... sweeps, and (chk_final) after the last one; checkpoint k's tile sums go
@@ -671,7 +672,6 @@ struct FusedArgs {
   int chk_stride;
   int chk_final;
   int64_t chk_tiles;
-  double* chk_x;
   const double* chk_exact;
   double* chk_part;
 };
@@ -1036,18 +1036,14 @@ __global__ __launch_bounds__(NT, CHK ? AGGMG_CHK_WAVES : 1) void btd_fused_kerne
       }
       __builtin_amdgcn_sched_barrier(0);   // one slab's row entries in flight at a time: the sweeps' registers stay live here
     }
-    // (the error norm and the store of the iterate after the residual rows, not among them: fewer registers live at once)
-    if (a.chk_exact || a.chk_x) {
+    // (the error norm after the residual rows, not among them: fewer registers live at once)
+    if (a.chk_exact) {
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
         const int x = s * EPS + le;
         if (valid[s] && x >= own0 && x < own1) {
-          const int64_t row = (e0 + x) * M + i;
-          if (a.chk_exact) {
-            const double d = uu[s] - a.chk_exact[row];
-            se += d * d;
-          }
-          if (a.chk_x) AGGMG_ST(a.chk_x[row], uu[s]);
+          const double d = uu[s] - a.chk_exact[(e0 + x) * M + i];
+          se += d * d;
         }
         __builtin_amdgcn_sched_barrier(0);
       }

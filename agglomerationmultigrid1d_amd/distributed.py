@@ -981,10 +981,14 @@ def multigrid(dv, x0, b, maxiter, tol, nPre=3, nPost=3, alpha=2.0 / 3.0, check_e
     history needs `A \\ b` of the GLOBAL fine operator (:120) and is not formed here."""
     e, L, c = dv.e, dv.L, dv.c
     own = L.owned_ranges(0)
+    if hasattr(e, "torch") and e.torch.cuda.is_available():
+        e.torch.cuda.synchronize()     # (x0 / b may have been filled on torch's stream just now)
     nb = np.sqrt(c.sum(e.owned_sumsq(own, b)))
     if maxiter <= 0:           # the reference returns its initial `x = zeros(length(x0))` (:119)
         return e.new(L.local_dofs(0)), 0, []
     bufs = [e.new(L.local_dofs(0)), e.new(L.local_dofs(0))]
+    if hasattr(e, "torch") and e.torch.cuda.is_available():
+        e.torch.cuda.synchronize()     # torch zero-filled the new vectors on ITS stream; the library may run on its own
     src, res, done, valid = x0, [], 0, False
     for it in range(1, int(maxiter) + 1):
         dst = bufs[it % 2]
