@@ -427,8 +427,9 @@ static int launch_csr(aggmg_ctx* ctx, const CsrDev& A, const double* x, const do
   if (A.nrows == 0) return AGGMG_OK;
   // (single passes stay on the stream kernel also for banded operators: measured on the config-2 matrix, the window
   // kernel's extra LDS and barrier make one sweep 121 us against 105 us; it pays from two sweeps per launch on)
-  // every row short: one thread per row, no LDS staging (AGGMG_CSR_ROWTHREAD=0: the stream kernel, A/B runs)
-  static const bool rowthread = cr_env_int_early("AGGMG_CSR_ROWTHREAD", 1) != 0;
+  // every row short: one thread per row, no LDS staging -- AGGMG_CSR_ROWTHREAD=1 (the default until the stream kernel's
+  // blocks were reshaped: 92 us against its 75 us on config 2's residual; kept for A/B runs, the same bits)
+  static const bool rowthread = cr_env_int_early("AGGMG_CSR_ROWTHREAD", 0) != 0;
   if (rowthread && A.maxrow >= 0 && A.maxrow <= kRowThreadMax && A.nrows < ((int64_t)1 << 31) * kThreads) {
     const unsigned nb = (unsigned)((A.nrows + kThreads - 1) / kThreads);
     static const bool bandrow = cr_env_int_early("AGGMG_CSR_BANDROW", 1) != 0;

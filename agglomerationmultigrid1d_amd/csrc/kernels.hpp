@@ -70,7 +70,29 @@ __global__ __launch_bounds__(kThreads) void csr_row_kernel(CsrView A, const doub
 // fully coalesced loads, parks the products a_ij * x_j in LDS and lets one thread per row add its
 // products in ascending column order -- the order SparseArrays' CSC scatter accumulates them.
 // A row longer than kStreamNnz forms a block of its own and is reduced across the workgroup.
-constexpr int kStreamNnz = 4096;
+// Block shape (r04, held against rocSPARSE's adaptive csrmv on the same operators, tools/exp_rocsparse_calib.py: 69 us for
+// y = A x on config 2's matrix): 4096 entries and up to 1024 rows per block -- 32 KB of LDS, five workgroups per CU, a
+// reduction phase in which a thread walks up to four rows -- ran the residual at 105 us; at most ONE row per thread
+// (256 rows) and 2048 entries 82 us, and with the entry streams loaded non-temporally (they are used once; the
+// gathered x stays in the caches) 75 us = 0.70 of 8 TB/s, the vendor kernel's rate.  1024 entries: 92 us; 1536 / 1792 /
+// 2048: 75 - 76 (1536 = 12 KB of LDS kept).  Non-temporal stores of y: no gain.
+#ifndef AGGMG_STREAM_NNZ
+#define AGGMG_STREAM_NNZ 1536
+#endif
+constexpr int kStreamNnz = AGGMG_STREAM_NNZ;
+#ifndef AGGMG_STREAM_ROWS
+#define AGGMG_STREAM_ROWS kThreads
+#endif
+constexpr int kStreamRows = AGGMG_STREAM_ROWS;   // most rows of a block
+#ifndef AGGMG_STREAM_NTLOAD
+#define AGGMG_STREAM_NTLOAD 1
+#endif
+#if AGGMG_STREAM_NTLOAD
+#define AGGMG_SLD(p) __builtin_nontemporal_load(&(p))
+#else
+#define AGGMG_SLD(p) (p)
+#endif
+constexpr int kBandNnz = 4096;   // csr_band_kernel's product buffer (entries of a block and its halo rows)
 template <int MODE>
 __global__ __launch_bounds__(kThreads) void csr_stream_kernel(CsrView A, const int32_t* __restrict__ rowblk,
                                                               const double* __restrict__ x,
@@ -97,16 +119,16 @@ __global__ __launch_bounds__(kThreads) void csr_stream_kernel(CsrView A, const i
     // four independent (value, index, gather) chains in flight per thread
     int p = tid;
     for (; p + 3 * kThreads < nn; p += 4 * kThreads) {
-      const int c0 = A.colind[p0 + p], c1 = A.colind[p0 + p + kThreads], c2 = A.colind[p0 + p + 2 * kThreads],
-                c3 = A.colind[p0 + p + 3 * kThreads];
-      const double v0 = A.vals[p0 + p], v1 = A.vals[p0 + p + kThreads], v2 = A.vals[p0 + p + 2 * kThreads],
-                   v3 = A.vals[p0 + p + 3 * kThreads];
+      const int c0 = AGGMG_SLD(A.colind[p0 + p]), c1 = AGGMG_SLD(A.colind[p0 + p + kThreads]), c2 = AGGMG_SLD(A.colind[p0 + p + 2 * kThreads]),
+                c3 = AGGMG_SLD(A.colind[p0 + p + 3 * kThreads]);
+      const double v0 = AGGMG_SLD(A.vals[p0 + p]), v1 = AGGMG_SLD(A.vals[p0 + p + kThreads]), v2 = AGGMG_SLD(A.vals[p0 + p + 2 * kThreads]),
+                   v3 = AGGMG_SLD(A.vals[p0 + p + 3 * kThreads]);
       prod[p] = v0 * x[c0];
       prod[p + kThreads] = v1 * x[c1];
       prod[p + 2 * kThreads] = v2 * x[c2];
       prod[p + 3 * kThreads] = v3 * x[c3];
     }
-    for (; p < nn; p += kThreads) prod[p] = A.vals[p0 + p] * x[A.colind[p0 + p]];
+    for (; p < nn; p += kThreads) prod[p] = AGGMG_SLD(A.vals[p0 + p]) * x[AGGMG_SLD(A.colind[p0 + p])];
     __syncthreads();
     for (int r = r0 + tid; r < r1; r += kThreads) {
       const int q0 = A.rowptr[r] - p0, q1 = A.rowptr[r + 1] - p0;
@@ -238,7 +260,7 @@ __global__ __launch_bounds__(kThreads) void csr_band_kernel(CsrView A, const int
                                                             const double* __restrict__ x, const double* __restrict__ b,
                                                             const double* __restrict__ dg, double alpha,
                                                             double* __restrict__ y) {
-  __shared__ double prod[kStreamNnz];
+  __shared__ double prod[kBandNnz];
   __shared__ double xw[2][kBandWin];
   const int tid = threadIdx.x;
   const int N = (int)A.nrows;
@@ -323,6 +345,14 @@ __global__ __launch_bounds__(kThreads) void block_apply_kernel(const double* __r
     y[id[i]] = acc;
 }
 
+#ifndef AGGMG_BLOCK_NTLOAD
+#define AGGMG_BLOCK_NTLOAD 0
+#endif
+#if AGGMG_BLOCK_NTLOAD
+#define AGGMG_BLD(p) __builtin_nontemporal_load(&(p))
+#else
+#define AGGMG_BLD(p) (p)
+#endif
 // One damped sweep of a block smoother on arbitrary index lists, u <- u + alpha * sum_k scatter(B_k^{-1} (b - A u)[inds_k])
 // (apply_smoother of BlockJacobi / AdditiveSchwarzSmoother / HybridSchwarzSmoother inside the sweep loop,
 // src/smoother.jl:6-46,69-81, src/solvers.jl:32-34), without the residual vector ever reaching HBM: a workgroup takes
@@ -353,8 +383,8 @@ __global__ __launch_bounds__(kThreads) void block_sweep_kernel(CsrView A, const 
 #pragma clang fp contract(off)
       int p = p0;
       for (; p + 3 < p1; p += 4) {
-        const int c0 = A.colind[p], c1 = A.colind[p + 1], c2 = A.colind[p + 2], c3 = A.colind[p + 3];
-        const double v0 = A.vals[p], v1 = A.vals[p + 1], v2 = A.vals[p + 2], v3 = A.vals[p + 3];
+        const int c0 = AGGMG_BLD(A.colind[p]), c1 = AGGMG_BLD(A.colind[p + 1]), c2 = AGGMG_BLD(A.colind[p + 2]), c3 = AGGMG_BLD(A.colind[p + 3]);
+        const double v0 = AGGMG_BLD(A.vals[p]), v1 = AGGMG_BLD(A.vals[p + 1]), v2 = AGGMG_BLD(A.vals[p + 2]), v3 = AGGMG_BLD(A.vals[p + 3]);
         const double t0 = v0 * u[c0], t1 = v1 * u[c1], t2 = v2 * u[c2], t3 = v3 * u[c3];
         acc = acc + t0;
         acc = acc + t1;
@@ -362,7 +392,7 @@ __global__ __launch_bounds__(kThreads) void block_sweep_kernel(CsrView A, const 
         acc = acc + t3;
       }
       for (; p < p1; ++p) {
-        const double t = A.vals[p] * u[A.colind[p]];
+        const double t = AGGMG_BLD(A.vals[p]) * u[AGGMG_BLD(A.colind[p])];
         acc = acc + t;
       }
     }

@@ -122,11 +122,11 @@ int setup_stream_blocks(aggmg_ctx* ctx, CsrDev* d) {
     d->maxrow = mx;
   }
   const int64_t nrows = d->nrows;
-  const std::vector<int32_t> blk = stream_row_blocks(rowptr.data(), nrows, kStreamNnz, 4 * kThreads);   // host_plan.hpp
+  const std::vector<int32_t> blk = stream_row_blocks(rowptr.data(), nrows, kStreamNnz, kStreamRows);   // host_plan.hpp
   d->nblk = (int64_t)blk.size() - 1;
   CHECK(dev_upload(ctx, blk, &d->rowblk));
   // square and banded: row blocks for csr_band_kernel (x window in LDS, several point-Jacobi sweeps per launch) --
-  // a block's rows plus (kBandSweeps - 1) * bw halo rows hold at most kStreamNnz entries, its window fits kBandWin
+  // a block's rows plus (kBandSweeps - 1) * bw halo rows hold at most kBandNnz entries, its window fits kBandWin
   static const bool band_on = [] {
     const char* e = std::getenv("AGGMG_CSR_BAND");
     return !(e && e[0] == '0');
@@ -140,7 +140,7 @@ int setup_stream_blocks(aggmg_ctx* ctx, CsrDev* d) {
     if (bwv <= kBandMaxBw) {
       const int bw = std::max(bwv, 1);
       std::vector<int32_t> bb;
-      const bool ok = band_row_blocks(rowptr.data(), nrows, bw, kBandSweeps, kStreamNnz, kBandWin, 4 * kThreads, &bb);   // host_plan.hpp
+      const bool ok = band_row_blocks(rowptr.data(), nrows, bw, kBandSweeps, kBandNnz, kBandWin, 4 * kThreads, &bb);   // host_plan.hpp
       if (ok) {
         d->bw = bw;
         d->nbandblk = (int64_t)bb.size() - 1;

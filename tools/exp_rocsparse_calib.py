@@ -22,8 +22,9 @@ def main():
     import agglomerationmultigrid1d_amd as mg
     from agglomerationmultigrid1d_amd import _lib
     from agglomerationmultigrid1d_amd.uniform import UniformCgDgHierarchy, UniformDgAggHierarchy
-    rs = ctypes.CDLL("/opt/rocm/lib/librocsparse.so")
     ctx = mg.Context(0)
+    rs = ctypes.CDLL("/opt/rocm/lib/librocsparse.so")
+    hip = ctypes.CDLL("/opt/rocm/lib/libamdhip64.so.7")      # (the runtime the library already loaded: rocSPARSE runs on the null stream)
     handle, descr = ctypes.c_void_p(), ctypes.c_void_p()
     assert rs.rocsparse_create_handle(ctypes.byref(handle)) == 0
     assert rs.rocsparse_create_mat_descr(ctypes.byref(descr)) == 0
@@ -65,18 +66,18 @@ def main():
             for _ in range(5):
                 run()
             ctx.synchronize()
-            import torch
-            torch.cuda.synchronize()
+            hip.hipDeviceSynchronize()
             t0 = time.perf_counter()
             reps = 200
             for _ in range(reps):
                 run()
-            torch.cuda.synchronize()
+            hip.hipDeviceSynchronize()
             us = 1e6 * (time.perf_counter() - t0) / reps
             key = "rocsparse_csrmv_adaptive" if analysed else "rocsparse_csrmv_no_analysis"
             res[key] = {"us": us, "algorithmic_GBs": alg_bytes / us / 1e3, "frac_of_8TBs": alg_bytes / us / 1e3 / 8000.0}
             # the result is what scipy computes
             if analysed:
+                hip.hipDeviceSynchronize()
                 yh = y.download()
                 ref = A @ x.download()
                 res["max_rel_err_vs_scipy"] = float(np.max(np.abs(yh - ref)) / np.max(np.abs(ref)))
