@@ -345,14 +345,6 @@ __global__ __launch_bounds__(kThreads) void block_apply_kernel(const double* __r
     y[id[i]] = acc;
 }
 
-#ifndef AGGMG_BLOCK_NTLOAD
-#define AGGMG_BLOCK_NTLOAD 0
-#endif
-#if AGGMG_BLOCK_NTLOAD
-#define AGGMG_BLD(p) __builtin_nontemporal_load(&(p))
-#else
-#define AGGMG_BLD(p) (p)
-#endif
 // One damped sweep of a block smoother on arbitrary index lists, u <- u + alpha * sum_k scatter(B_k^{-1} (b - A u)[inds_k])
 // (apply_smoother of BlockJacobi / AdditiveSchwarzSmoother / HybridSchwarzSmoother inside the sweep loop,
 // src/smoother.jl:6-46,69-81, src/solvers.jl:32-34), without the residual vector ever reaching HBM: a workgroup takes
@@ -363,6 +355,8 @@ __global__ __launch_bounds__(kThreads) void block_apply_kernel(const double* __r
 //           out must not alias u (rows of other blocks are still being read).
 //   else:   Y[block * m + i] = y, and block_combine_kernel adds up the entries covering each row -- in list order, no
 //           atomics, no zeroing: the same bits run to run.
+// (Non-temporal loads of the entry streams, which lifted the stream kernel, cost this one 36 % -- 283 against 208 us per
+// Schwarz sweep: a thread walks its row entry by entry and lives on the lines staying in the cache between its iterations.)
 template <bool DIRECT>
 __global__ __launch_bounds__(kThreads) void block_sweep_kernel(CsrView A, const double* __restrict__ binv,
                                                                const int32_t* __restrict__ inds, int m, int64_t nb,
@@ -383,8 +377,8 @@ __global__ __launch_bounds__(kThreads) void block_sweep_kernel(CsrView A, const 
 #pragma clang fp contract(off)
       int p = p0;
       for (; p + 3 < p1; p += 4) {
-        const int c0 = AGGMG_BLD(A.colind[p]), c1 = AGGMG_BLD(A.colind[p + 1]), c2 = AGGMG_BLD(A.colind[p + 2]), c3 = AGGMG_BLD(A.colind[p + 3]);
-        const double v0 = AGGMG_BLD(A.vals[p]), v1 = AGGMG_BLD(A.vals[p + 1]), v2 = AGGMG_BLD(A.vals[p + 2]), v3 = AGGMG_BLD(A.vals[p + 3]);
+        const int c0 = A.colind[p], c1 = A.colind[p + 1], c2 = A.colind[p + 2], c3 = A.colind[p + 3];
+        const double v0 = A.vals[p], v1 = A.vals[p + 1], v2 = A.vals[p + 2], v3 = A.vals[p + 3];
         const double t0 = v0 * u[c0], t1 = v1 * u[c1], t2 = v2 * u[c2], t3 = v3 * u[c3];
         acc = acc + t0;
         acc = acc + t1;
@@ -392,7 +386,7 @@ __global__ __launch_bounds__(kThreads) void block_sweep_kernel(CsrView A, const 
         acc = acc + t3;
       }
       for (; p < p1; ++p) {
-        const double t = AGGMG_BLD(A.vals[p]) * u[AGGMG_BLD(A.colind[p])];
+        const double t = A.vals[p] * u[A.colind[p]];
         acc = acc + t;
       }
     }
