@@ -467,12 +467,12 @@ static int launch_csr(aggmg_ctx* ctx, const CsrDev& A, const double* x, const do
 }
 
 // n point-Jacobi sweeps u <- u + alpha D^-1 (b - A u) from src into dst (dst != src; tmp: a second vector of the
-// same length, may be clobbered).  Banded operators take up to kBandSweeps sweeps per launch (csr_band_kernel), the
+// same length, may be clobbered).  Banded operators take up to their band_sweeps (<= kBandSweeps) sweeps per launch (csr_band_kernel), the
 // others one; the launches ping-pong so that the last one lands in dst.
 static int launch_csr_jacobi_sweeps(aggmg_ctx* ctx, const CsrDev& A, const double* src, const double* b, const double* dg,
                                     double alpha, int n, double* dst, double* tmp) {
   if (n <= 0 || A.nrows == 0) return AGGMG_OK;
-  const int per = A.bandblk ? kBandSweeps : 1;
+  const int per = A.bandblk ? A.band_sweeps : 1;
   const int nl = (n + per - 1) / per;
   int left = n;
   for (int l = 0; l < nl; ++l) {
@@ -789,7 +789,7 @@ static int generic_jacobi(aggmg_ctx* ctx, aggmg_op* A, aggmg_smoother* sm, const
     if (src != dst) HIPCHK(hipMemcpyAsync(dst, src, N * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
     return AGGMG_OK;
   }
-  const int per = A->csr.bandblk ? kBandSweeps : 1;
+  const int per = A->csr.bandblk ? A->csr.band_sweeps : 1;
   const int nl = (nsweeps + per - 1) / per;
   // the launches alternate between dst and other and end in dst: the first one writes `other` when their number is
   // even -- a source that is the first target has to move out of the way

@@ -84,6 +84,7 @@ struct CsrDev {
   int64_t nblk = 0;
   int32_t* bandblk = nullptr; // CSR-band row blocks (square, entries within bw of the diagonal), nbandblk + 1 entries
   int64_t nbandblk = 0;
+  int band_sweeps = 1;        // most point-Jacobi sweeps a csr_band_kernel launch takes on this operator (the blocks' halo is cut for it)
   int bw = -1;                // band half-width, -1: not banded / not examined
   int maxrow = -1;            // entries of the longest row (-1: not examined); <= kRowThreadMax: csr_rowthread_kernel
   CsrView view() const { return CsrView{rowptr, colind, vals, nrows}; }

@@ -92,7 +92,7 @@ constexpr int kStreamRows = AGGMG_STREAM_ROWS;   // most rows of a block
 #else
 #define AGGMG_SLD(p) (p)
 #endif
-constexpr int kBandNnz = 4096;   // csr_band_kernel's product buffer (entries of a block and its halo rows)
+constexpr int kBandNnz = 2048;   // csr_band_kernel: most entries of a tile (block + halo rows); kBandNnz / kThreads per thread in registers
 template <int MODE>
 __global__ __launch_bounds__(kThreads) void csr_stream_kernel(CsrView A, const int32_t* __restrict__ rowblk,
                                                               const double* __restrict__ x,
@@ -240,68 +240,89 @@ __global__ __launch_bounds__(kThreads) void csr_rowthread_band_kernel(CsrView A,
   }
 }
 
-// "CSR-band" variant: the same streaming pattern for square operators whose entries all lie within `bw` of the
-// diagonal (every DG / agglomerated operator of the reference in its own numbering; detected on the device at
-// upload).  A workgroup owns a run of rows plus S * bw rows of halo on either side and
-//   * reads the window of x it needs ONCE, coalesced, into LDS -- the gathers x[col] of csr_stream_kernel fetch the
-//     lines of neighbouring rows several times (measured r02: 13 % more HBM bytes than the model),
-//   * runs S point-Jacobi sweeps on it (temporal blocking, as the fused block-tridiagonal kernel does: sweep s
-//     updates the rows within (S - 1 - s) * bw of the block, so that after S sweeps the block's own rows are exact):
-//     the operator's entries come from HBM once per launch and from the caches for the later sweeps.
-// Products are summed per row in ascending column order (SparseArrays' CSC scatter order), so S sweeps in one
-// launch give bit for bit what S launches give.  Row blocks (bandblk) are cut on the host so that the entries of a
-// block and its halo rows fit `prod` and its window fits kBandWin.
-constexpr int kBandSweeps = 4;   // most sweeps per launch (halo sized for it)
+// "CSR-band" variant for square operators whose entries all lie within `bw` of the diagonal (every DG / agglomerated
+// operator of the reference in its own numbering; detected on the device at upload): S point-Jacobi sweeps per launch
+// by temporal blocking, as the fused block-tridiagonal kernel does -- a workgroup owns a run of rows plus (S - 1) * bw
+// rows of halo on either side, reads the window of x it needs ONCE, coalesced, into LDS, and after S sweeps the block's
+// own rows are exact.  Products are summed per row in ascending column order (SparseArrays' CSC scatter order), so S
+// sweeps in one launch give bit for bit what S launches give.  Row blocks (bandblk) are cut on the host (band_row_blocks).
+constexpr int kBandSweeps = 8;   // most sweeps per launch (an operator's own limit, CsrDev::band_sweeps: 1 + 32 / bw, at least 2)
 constexpr int kBandMaxBw = 32;   // widest band the window kernels take (csr_rowthread_band_kernel sizes its LDS for it)
 static_assert(kBandMaxBw == 32, "csr_rowthread_band_kernel's window");
-constexpr int kBandWin = 4 * kThreads + 2 * kBandSweeps * kBandMaxBw;
+constexpr int kBandWin = kThreads + 2 * kBandMaxBw;   // a tile's rows (block + halo, <= kThreads) and bw columns beyond them
 template <int MODE>
 __global__ __launch_bounds__(kThreads) void csr_band_kernel(CsrView A, const int32_t* __restrict__ bandblk, int bw, int S,
                                                             const double* __restrict__ x, const double* __restrict__ b,
                                                             const double* __restrict__ dg, double alpha,
                                                             double* __restrict__ y) {
+  static_assert(MODE == kJacobi, "the multi-sweep window kernel runs point-Jacobi sweeps");
+  // r04: a tile is the block's rows PLUS its (S - 1) * bw halo rows on either side, at most kThreads rows and kBandNnz
+  // entries (cut at upload, band_row_blocks): one row per thread in every sweep, and the tile's entries -- values and
+  // window-relative columns -- live in REGISTERS for the whole launch (kBandNnz / kThreads per thread, loaded once,
+  // coalesced, non-temporally), as do the row's b, diagonal and entry range.  A sweep is then LDS work only: products
+  // out of the x window, a barrier, one row sum per thread, the new value into the other window buffer, a barrier.  Every
+  // row of the tile is updated in every sweep; what is wrong near the tile's ends (stale neighbours) moves inwards by bw
+  // rows per sweep and stops short of the block's own rows, as in the fused tile kernels.  (Before: the entries were
+  // re-read from memory in every sweep, 52 KB of LDS per workgroup, up to four rows per thread: 3 / 4 sweeps per launch
+  // ran at 81 / 75 us per sweep on config 2's matrix, no better than single-sweep launches of the stream kernel.)
+  constexpr int K = kBandNnz / kThreads;
   __shared__ double prod[kBandNnz];
   __shared__ double xw[2][kBandWin];
   const int tid = threadIdx.x;
   const int N = (int)A.nrows;
   const int r0 = bandblk[blockIdx.x], r1 = bandblk[blockIdx.x + 1];
-  const int w0 = max(0, r0 - S * bw), w1 = min(N, r1 + S * bw);
-  for (int w = w0 + tid; w < w1; w += kThreads) xw[0][w - w0] = x[w];
+  const int H = (S - 1) * bw;
+  const int ra = max(0, r0 - H), rb = min(N, r1 + H);
+  const int w0 = max(0, ra - bw), w1 = min(N, rb + bw);
+  const int pa = A.rowptr[ra], nn = A.rowptr[rb] - pa;
+  double v[K];
+  int c[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const int p = tid + k * kThreads;
+    v[k] = 0.0;
+    c[k] = 0;
+    if (p < nn) {
+      v[k] = __builtin_nontemporal_load(&A.vals[pa + p]);
+      c[k] = __builtin_nontemporal_load(&A.colind[pa + p]) - w0;
+    }
+  }
+  const int r = ra + tid;
+  const bool has = r < rb;
+  int q0 = 0, q1 = 0;
+  double br = 0.0, dr = 1.0;
+  if (has) {
+    q0 = A.rowptr[r] - pa;
+    q1 = A.rowptr[r + 1] - pa;
+    br = b[r];
+    dr = dg[r];
+  }
+  // (the window cells beyond the tile's rows are never written again: both buffers hold them)
+  for (int w = w0 + tid; w < w1; w += kThreads) {
+    const double xv = x[w];
+    xw[0][w - w0] = xv;
+    xw[1][w - w0] = xv;
+  }
   __syncthreads();
   int cur = 0;
   for (int s = 0; s < S; ++s) {
-    const int h = (S - 1 - s) * bw;
-    const int ra = max(0, r0 - h), rb = min(N, r1 + h);
-    const int pa = A.rowptr[ra], nn = A.rowptr[rb] - pa;
     const double* xa = xw[cur];
-    int p = tid;
-    for (; p + 3 * kThreads < nn; p += 4 * kThreads) {
-      const int c0 = A.colind[pa + p], c1 = A.colind[pa + p + kThreads], c2 = A.colind[pa + p + 2 * kThreads],
-                c3 = A.colind[pa + p + 3 * kThreads];
-      const double v0 = A.vals[pa + p], v1 = A.vals[pa + p + kThreads], v2 = A.vals[pa + p + 2 * kThreads],
-                   v3 = A.vals[pa + p + 3 * kThreads];
-      prod[p] = v0 * xa[c0 - w0];
-      prod[p + kThreads] = v1 * xa[c1 - w0];
-      prod[p + 2 * kThreads] = v2 * xa[c2 - w0];
-      prod[p + 3 * kThreads] = v3 * xa[c3 - w0];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int p = tid + k * kThreads;
+      if (p < nn) prod[p] = v[k] * xa[c[k]];
     }
-    for (; p < nn; p += kThreads) prod[p] = A.vals[pa + p] * xa[A.colind[pa + p] - w0];
     __syncthreads();
-    const bool last = s == S - 1;
-    for (int r = ra + tid; r < rb; r += kThreads) {
-      const int q0 = A.rowptr[r] - pa, q1 = A.rowptr[r + 1] - pa;
+    if (has) {
       double acc = 0.0;
       for (int q = q0; q < q1; ++q) acc += prod[q];
-      if (MODE == kJacobi) {
-        const double res = b[r] - acc;
-        const double yy = res / dg[r];
-        const double v = xa[r - w0] + alpha * yy;
-        if (last) y[r] = v;                 // (the last sweep's range is the block itself)
-        else xw[cur ^ 1][r - w0] = v;
+      const double res = br - acc;
+      const double yy = res / dr;
+      const double val = xa[r - w0] + alpha * yy;
+      if (s == S - 1) {
+        if (r >= r0 && r < r1) y[r] = val;
       } else {
-        if (MODE == kSpmvSet) y[r] = acc;
-        if (MODE == kSpmvAdd) y[r] += acc;
-        if (MODE == kResidual) y[r] = b[r] - acc;
+        xw[cur ^ 1][r - w0] = val;
       }
     }
     __syncthreads();

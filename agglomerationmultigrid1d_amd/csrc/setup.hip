@@ -126,7 +126,8 @@ int setup_stream_blocks(aggmg_ctx* ctx, CsrDev* d) {
   d->nblk = (int64_t)blk.size() - 1;
   CHECK(dev_upload(ctx, blk, &d->rowblk));
   // square and banded: row blocks for csr_band_kernel (x window in LDS, several point-Jacobi sweeps per launch) --
-  // a block's rows plus (kBandSweeps - 1) * bw halo rows hold at most kBandNnz entries, its window fits kBandWin
+  // a tile -- a block's rows plus (S - 1) * bw halo rows on either side -- has at most kThreads rows and kBandNnz entries;
+  // S, the most sweeps per launch, is chosen per operator so that the halo stays near a quarter of the tile
   static const bool band_on = [] {
     const char* e = std::getenv("AGGMG_CSR_BAND");
     return !(e && e[0] == '0');
@@ -140,8 +141,11 @@ int setup_stream_blocks(aggmg_ctx* ctx, CsrDev* d) {
     if (bwv <= kBandMaxBw) {
       const int bw = std::max(bwv, 1);
       std::vector<int32_t> bb;
-      const bool ok = band_row_blocks(rowptr.data(), nrows, bw, kBandSweeps, kBandNnz, kBandWin, 4 * kThreads, &bb);   // host_plan.hpp
+      const int S = std::max(2, std::min(kBandSweeps, 1 + 32 / bw));
+      // (band_row_blocks: block rows + 2 * S * bw <= window  <=>  tile rows = block rows + 2 (S - 1) bw <= kThreads)
+      const bool ok = band_row_blocks(rowptr.data(), nrows, bw, S, kBandNnz, kThreads + 2 * bw, kThreads, &bb);   // host_plan.hpp
       if (ok) {
+        d->band_sweeps = S;
         d->bw = bw;
         d->nbandblk = (int64_t)bb.size() - 1;
         CHECK(dev_upload(ctx, bb, &d->bandblk));

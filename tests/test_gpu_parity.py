@@ -172,7 +172,7 @@ def test_generic_point_jacobi_sweeps(oracle, mg):
 @pytest.mark.parametrize("n,p", [(7, 3), (64, 3), (700, 3), (2000, 1), (1500, 4), (333, 7)])
 def test_banded_generic_point_jacobi_many_sweeps_per_launch(oracle, mg, n, p):
     """dg_smoother(mesh, A, :jac) (src/smoother.jl:146-151) on DG operators through the GENERIC kernels: the operator is
-    banded, so csr_band_kernel keeps the x window of a row block in LDS and runs up to four sweeps per launch
+    banded, so csr_band_kernel keeps the x window of a row block in LDS and runs several sweeps per launch (the operator's own limit, 1 + 32 / bw, at most 8)
     (temporal blocking with halo rows) -- 1 .. 9 sweeps (one launch, several launches, uneven splits; several row
     blocks with halos at n = 700 .. 2000; tiny systems whose halo is the whole matrix), in place and out of place,
     against the oracle's sweeps; the residual and y = A x take the window kernel too"""
