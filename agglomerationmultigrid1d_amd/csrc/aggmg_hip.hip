@@ -469,10 +469,14 @@ static int launch_csr(aggmg_ctx* ctx, const CsrDev& A, const double* x, const do
 // n point-Jacobi sweeps u <- u + alpha D^-1 (b - A u) from src into dst (dst != src; tmp: a second vector of the
 // same length, may be clobbered).  Banded operators take up to their band_sweeps (<= kBandSweeps) sweeps per launch (csr_band_kernel), the
 // others one; the launches ping-pong so that the last one lands in dst.
+// rout / fused (optional): the residual b - A dst wanted next -- a banded operator's last launch forms it in the same pass
+// (one sweep less per launch so that the halo holds) and *fused says so; otherwise the caller launches it.
 static int launch_csr_jacobi_sweeps(aggmg_ctx* ctx, const CsrDev& A, const double* src, const double* b, const double* dg,
-                                    double alpha, int n, double* dst, double* tmp) {
+                                    double alpha, int n, double* dst, double* tmp, double* rout = nullptr, bool* fused = nullptr) {
+  if (fused) *fused = false;
   if (n <= 0 || A.nrows == 0) return AGGMG_OK;
-  const int per = A.bandblk ? A.band_sweeps : 1;
+  const bool want_r = rout && fused && A.bandblk && A.band_sweeps >= 2;
+  const int per = A.bandblk ? (want_r ? A.band_sweeps - 1 : A.band_sweeps) : 1;
   const int nl = (n + per - 1) / per;
   int left = n;
   for (int l = 0; l < nl; ++l) {
@@ -480,10 +484,12 @@ static int launch_csr_jacobi_sweeps(aggmg_ctx* ctx, const CsrDev& A, const doubl
     const int s = (left + (nl - l) - 1) / (nl - l);
     double* out = ((nl - 1 - l) % 2 == 0) ? dst : tmp;
     if (out == src) return fail(ctx, AGGMG_ERR_ARGUMENT, "point-Jacobi sweeps: source and destination alias");
-    if (A.bandblk && s > 1) {
+    const bool with_r = want_r && l == nl - 1;
+    if (A.bandblk && (s > 1 || with_r)) {
       hipLaunchKernelGGL((csr_band_kernel<kJacobi>), dim3((unsigned)A.nbandblk), dim3(kThreads), 0, ctx->stream, A.view(),
-                         (const int32_t*)A.bandblk, A.bw, s, src, b, dg, alpha, out);
+                         (const int32_t*)A.bandblk, A.bw, s, src, b, dg, alpha, out, with_r ? rout : (double*)nullptr);
       HIPCHK(hipGetLastError());
+      if (with_r) *fused = true;
     } else {
       CHECK(launch_csr<kJacobi>(ctx, A, src, b, dg, alpha, out));
     }
@@ -783,13 +789,15 @@ static int generic_sweep(aggmg_ctx* ctx, aggmg_op* A, aggmg_smoother* sm, const 
 
 // nsweeps generic point-Jacobi sweeps from src into dst (dst may be src); `other` is a second vector of the level
 static int generic_jacobi(aggmg_ctx* ctx, aggmg_op* A, aggmg_smoother* sm, const double* src, const double* rhs, double alpha,
-                          int nsweeps, double* dst, double* other) {
+                          int nsweeps, double* dst, double* other, double* rout = nullptr, bool* fused = nullptr) {
   const int64_t N = A->m;
+  if (fused) *fused = false;
   if (nsweeps <= 0) {
     if (src != dst) HIPCHK(hipMemcpyAsync(dst, src, N * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
     return AGGMG_OK;
   }
-  const int per = A->csr.bandblk ? A->csr.band_sweeps : 1;
+  const bool want_r = rout && fused && A->csr.bandblk && A->csr.band_sweeps >= 2;
+  const int per = A->csr.bandblk ? (want_r ? A->csr.band_sweeps - 1 : A->csr.band_sweeps) : 1;
   const int nl = (nsweeps + per - 1) / per;
   // the launches alternate between dst and other and end in dst: the first one writes `other` when their number is
   // even -- a source that is the first target has to move out of the way
@@ -797,14 +805,14 @@ static int generic_jacobi(aggmg_ctx* ctx, aggmg_op* A, aggmg_smoother* sm, const
   if (first == src) {
     double* spare = first == dst ? other : dst;
     if (nl == 1) {   // one launch, in place: through the spare vector
-      CHECK(launch_csr_jacobi_sweeps(ctx, A->csr, src, rhs, sm->diag, alpha, nsweeps, spare, dst));
+      CHECK(launch_csr_jacobi_sweeps(ctx, A->csr, src, rhs, sm->diag, alpha, nsweeps, spare, dst, rout, fused));
       HIPCHK(hipMemcpyAsync(dst, spare, N * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
       return AGGMG_OK;
     }
     HIPCHK(hipMemcpyAsync(spare, src, N * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
     src = spare;
   }
-  return launch_csr_jacobi_sweeps(ctx, A->csr, src, rhs, sm->diag, alpha, nsweeps, dst, other);
+  return launch_csr_jacobi_sweeps(ctx, A->csr, src, rhs, sm->diag, alpha, nsweeps, dst, other, rout, fused);
 }
 
 static int check_pair(aggmg_ctx* ctx, aggmg_op* A, aggmg_smoother* sm, const char* who) {
@@ -1673,6 +1681,7 @@ static int vcycle_down(aggmg_ctx* ctx, aggmg_hier* h, const double* x0, const do
       ProfScope ps(ctx, AGGMG_KIND_FUSED_DOWN, k);
       CHECK(launch_btd(ctx, *l.S->btd, a, nPre + 1));
     } else {
+      bool resid_done = false;
       if (structured) {
         CHECK(btd_smooth(ctx, *l.S->btd, uin, rhs, alpha, nPre, l.u[0], k, l.N, l.S->gs ? 1 : 0));
       } else {
@@ -1687,7 +1696,8 @@ static int vcycle_down(aggmg_ctx* ctx, aggmg_hier* h, const double* x0, const do
         if (l.S->kind == 0 && nPre > 0) {   // point Jacobi: several sweeps per launch where the operator is banded
           CHECK(op_ensure_csr(ctx, l.A));
           ProfScope ps(ctx, AGGMG_KIND_JACOBI, k);
-          CHECK(generic_jacobi(ctx, l.A, l.S, src, rhs, alpha, nPre, l.u[0], l.u[1]));
+          // (banded operators: the residual for the restriction comes out of the sweeps' own launch)
+          CHECK(generic_jacobi(ctx, l.A, l.S, src, rhs, alpha, nPre, l.u[0], l.u[1], l.tmp, &resid_done));
         } else {
           for (int s = 0; s < nPre; ++s) {
             CHECK(generic_sweep(ctx, l.A, l.S, src, rhs, alpha, l.u[0], k));
@@ -1695,7 +1705,7 @@ static int vcycle_down(aggmg_ctx* ctx, aggmg_hier* h, const double* x0, const do
           }
         }
       }
-      {
+      if (!resid_done) {
         ProfScope ps(ctx, AGGMG_KIND_RESIDUAL, k);
         CHECK(op_ensure_csr(ctx, l.A));
         CHECK(launch_csr<kResidual>(ctx, l.A->csr, l.u[0], rhs, nullptr, 0.0, l.tmp));

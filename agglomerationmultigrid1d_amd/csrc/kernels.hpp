@@ -254,8 +254,11 @@ template <int MODE>
 __global__ __launch_bounds__(kThreads) void csr_band_kernel(CsrView A, const int32_t* __restrict__ bandblk, int bw, int S,
                                                             const double* __restrict__ x, const double* __restrict__ b,
                                                             const double* __restrict__ dg, double alpha,
-                                                            double* __restrict__ y) {
+                                                            double* __restrict__ y, double* __restrict__ rout) {
   static_assert(MODE == kJacobi, "the multi-sweep window kernel runs point-Jacobi sweeps");
+  // rout (may be null): the residual b - A y of the swept iterate on the block's rows, one more pass over the tile and
+  // one more bw of halo -- the descent of a generic banded level (sweeps, then the residual for the restriction,
+  // src/solvers.jl:32-36) in ONE pass over the operator; the same products and row sums as the stream kernel's residual
   // r04: a tile is the block's rows PLUS its (S - 1) * bw halo rows on either side, at most kThreads rows and kBandNnz
   // entries (cut at upload, band_row_blocks): one row per thread in every sweep, and the tile's entries -- values and
   // window-relative columns -- live in REGISTERS for the whole launch (kBandNnz / kThreads per thread, loaded once,
@@ -271,7 +274,8 @@ __global__ __launch_bounds__(kThreads) void csr_band_kernel(CsrView A, const int
   const int tid = threadIdx.x;
   const int N = (int)A.nrows;
   const int r0 = bandblk[blockIdx.x], r1 = bandblk[blockIdx.x + 1];
-  const int H = (S - 1) * bw;
+  const int P = S + (rout ? 1 : 0);   // passes over the tile
+  const int H = (P - 1) * bw;
   const int ra = max(0, r0 - H), rb = min(N, r1 + H);
   const int w0 = max(0, ra - bw), w1 = min(N, rb + bw);
   const int pa = A.rowptr[ra], nn = A.rowptr[rb] - pa;
@@ -305,7 +309,7 @@ __global__ __launch_bounds__(kThreads) void csr_band_kernel(CsrView A, const int
   }
   __syncthreads();
   int cur = 0;
-  for (int s = 0; s < S; ++s) {
+  for (int s = 0; s < P; ++s) {
     const double* xa = xw[cur];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
@@ -314,15 +318,17 @@ __global__ __launch_bounds__(kThreads) void csr_band_kernel(CsrView A, const int
     }
     __syncthreads();
     if (has) {
+      const bool own = r >= r0 && r < r1;
       double acc = 0.0;
       for (int q = q0; q < q1; ++q) acc += prod[q];
       const double res = br - acc;
-      const double yy = res / dr;
-      const double val = xa[r - w0] + alpha * yy;
-      if (s == S - 1) {
-        if (r >= r0 && r < r1) y[r] = val;
-      } else {
-        xw[cur ^ 1][r - w0] = val;
+      if (s < S) {
+        const double yy = res / dr;
+        const double val = xa[r - w0] + alpha * yy;
+        if (s == S - 1 && own) y[r] = val;
+        if (s < P - 1) xw[cur ^ 1][r - w0] = val;
+      } else if (own) {
+        rout[r] = res;
       }
     }
     __syncthreads();
