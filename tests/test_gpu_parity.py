@@ -224,6 +224,41 @@ def test_vcycle_on_banded_generic_levels_with_point_jacobi(oracle, mg, n, ps):
         assert np.linalg.norm(Ho.mStiffness[0] @ (xg - xo)) < 1e-11 * np.linalg.norm(b), (nPre, nPost)
 
 
+@pytest.mark.parametrize("N,bw,fill", [(5, 1, 1.0), (3000, 1, 1.0), (2500, 6, 0.6), (4000, 13, 0.3), (3000, 30, 0.15),
+                                       (3000, 32, 0.1), (1200, 32, 1.0), (2000, 40, 0.2)])
+def test_band_kernel_on_synthetic_bands(mg, N, bw, fill):
+    """csr_band_kernel beyond the DG operators: random diagonally dominant matrices with entries within `bw` of the diagonal
+    -- tridiagonal, mid bands, the widest band the window kernels take (32: two sweeps per launch), a FULL band of 65
+    entries per row (a tile could not hold its own halo: the planner declines and the stream kernel runs), a band too wide
+    (40: stream kernel) -- 1 .. 11 point-Jacobi sweeps against NumPy; several launches, uneven splits, ragged rows."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(N * 131 + bw)
+    rows, cols, vals = [], [], []
+    for d in range(-bw, bw + 1):
+        if d == 0:
+            continue
+        i = np.arange(max(0, -d), min(N, N - d))
+        keep = rng.random(i.size) < fill
+        if d in (-bw, bw):
+            keep[:] = True                      # the band's edge is really there
+        i = i[keep]
+        rows.append(i); cols.append(i + d); vals.append(rng.standard_normal(i.size))
+    rows, cols, vals = map(np.concatenate, (rows, cols, vals))
+    A = sp.csr_matrix((vals, (rows, cols)), shape=(N, N))
+    A = A + sp.diags(np.asarray(abs(A).sum(axis=1)).ravel() + 1.0)
+    A = sp.csc_matrix(A)
+    Sg = mg.JacobiSmoother(A, detect=False)
+    assert not Sg.structured
+    dg = A.diagonal()
+    u0, b = rng.standard_normal(N), rng.standard_normal(N)
+    for ns in (1, 2, 3, 5, 8, 11):
+        x = u0.copy()
+        for _ in range(ns):
+            x = x + 0.7 * ((b - A @ x) / dg)
+        got = mg.smooth(Sg.A, Sg, u0, b, 0.7, ns)
+        assert np.linalg.norm(got - x) <= 1e-13 * np.linalg.norm(x), (ns, np.linalg.norm(got - x) / np.linalg.norm(x))
+
+
 def test_iterative_smoother_solve_matches(oracle, mg):
     """tests/dg_smoother_test.jl call pattern through the product API: same iteration count,
     same iterate."""
