@@ -180,6 +180,35 @@ def test_checkpoints_inside_the_chain_kernel_launches(oracle, mg, ne):
     assert np.linalg.norm(xg - xo) <= 1e-11 * np.linalg.norm(xo)
 
 
+@pytest.mark.parametrize("kind", ["dg", "cg"])
+def test_checkpoints_with_no_pre_or_no_post_smoothing(oracle, mg, kind):
+    """the checked loops at V(0, nPost), V(nPre, 0) and V(0, 0) -- the checkpoint then sits before the first or after the
+    last sweep of the shared launch (or is all of it) -- and at uneven sweep counts: iterates bitwise, histories to
+    round-off against the separate-launch form, on both kernel families"""
+    from agglomerationmultigrid1d_amd import _lib
+    o = oracle
+    if kind == "dg":
+        Ho, b = o.build_dg_agg_hierarchy(1536, p=3, pAgg=1, nAgg=2, first=4)
+    else:
+        Ho, b = o.build_cg_hierarchy(1500, ps=(4, 2, 1), nDG=1)
+    x0 = o.splitmix_normal(len(b), 9)
+    cases = ((0, 2), (2, 0), (0, 0), (1, 4), (4, 1))
+    out = {}
+    for chk in (1, 0):
+        ctx = mg.Context(0)
+        ctx.set_option(_lib.OPT_MG_CHECKPOINT, chk)
+        H = mg.MeshHierarchy.from_reference(Ho, ctx=ctx)
+        out[chk] = [mg.multigrid(H, x0, b, 5, 1e-30, exact=(k % 2 == 0), nPre=a, nPost=c, alpha=0.5) for k, (a, c) in enumerate(cases)]
+    for case, (xa, ia, ra, ea), (xb, ib, rb, eb) in zip(cases, out[1], out[0]):
+        assert ia == ib == 5 and len(ra) == len(rb) == 5, case
+        assert np.array_equal(xa, xb), case
+        assert np.allclose(ra, rb, rtol=1e-10, atol=1e-13 * np.linalg.norm(b)) and np.allclose(ea, eb, rtol=1e-8, atol=1e-11), case
+    xo = x0
+    for _ in range(5):
+        xo = o.multigrid_v_cycle(Ho, xo, b, nPre=1, nPost=4, alpha=0.5)
+    assert np.linalg.norm(Ho.mStiffness[0] @ (out[1][3][0] - xo)) < 1e-11 * np.linalg.norm(b)
+
+
 def test_err_histories_are_formed_on_the_device(oracle, mg):
     """multigrid / iterative_smoother_solve return the reference's full 4-tuple (x, iter, res, err) with
     err[i] = ||x_i - A \\ b||_2 (src/solvers.jl:120,128 and :194,202) -- exact=True, the default of both mirrors -- and the
