@@ -736,7 +736,9 @@ __device__ __forceinline__ int64_t fused_tile(const FusedArgs& a) {
 // AGGMG_NT bit 0: non-temporal loads of the read-once operator streams; bit 1: non-temporal
 // stores of the iterate (tuning knobs, see tools/exp_fused.py)
 #ifndef AGGMG_NT
-#define AGGMG_NT 2  // measured: non-temporal iterate stores -2.6 % per V-cycle, NT operator loads no gain
+#define AGGMG_NT 2  // measured: non-temporal iterate stores -2.6 % per V-cycle, NT operator loads no gain (r01); r04, on the
+                    // symmetric-packed path -- packed inverses, closing residual's rows, b --: 19 % SLOWER (fine descent 1.15 ->
+                    // 1.37 ms: the four lanes of an element read overlapping entries of the packed triangle in successive loads)
 #endif
 #if AGGMG_NT & 1
 #define AGGMG_LD(p) __builtin_nontemporal_load(&(p))
