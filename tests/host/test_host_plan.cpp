@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <set>
+#include <utility>
 #include <vector>
 
 #include "../../agglomerationmultigrid1d_amd/csrc/host_plan.hpp"
@@ -116,12 +117,31 @@ static void test_row_blocks() {
         rp[(size_t)i + 1] = rp[(size_t)i] + len;
       }
       const int max_nnz = 4096, max_rows = 1024;
-      const std::vector<int32_t> blk = stream_row_blocks(rp.data(), nrows, max_nnz, max_rows);
-      EXPECT(blk.front() == 0 && blk.back() == nrows);
-      for (size_t k = 0; k + 1 < blk.size(); ++k) {
-        const int r0 = blk[k], r1 = blk[k + 1];
-        EXPECT(r1 > r0 && r1 - r0 <= max_rows);                                    // a partition into non-empty runs
-        EXPECT(rp[(size_t)r1] - rp[(size_t)r0] <= max_nnz || r1 == r0 + 1);        // that fit the LDS stage, or one long row
+      // (4096 / 1024: the r03 block shape; 1536 / 256: what csr_stream_kernel takes since r04 -- one row per thread)
+      for (const auto& shape : {std::pair<int, int>{4096, 1024}, std::pair<int, int>{1536, 256}}) {
+        const std::vector<int32_t> blk = stream_row_blocks(rp.data(), nrows, shape.first, shape.second);
+        EXPECT(blk.front() == 0 && blk.back() == nrows);
+        for (size_t k = 0; k + 1 < blk.size(); ++k) {
+          const int r0 = blk[k], r1 = blk[k + 1];
+          EXPECT(r1 > r0 && r1 - r0 <= shape.second);                                 // a partition into non-empty runs
+          EXPECT(rp[(size_t)r1] - rp[(size_t)r0] <= shape.first || r1 == r0 + 1);     // that fit the LDS stage, or one long row
+        }
+      }
+      // csr_band_kernel's tiles since r04 (setup.hip): S = 1 + 32 / bw sweeps at most 8, a block's rows plus (S - 1) bw halo
+      // rows per side are at most 256 rows (window = 256 + 2 bw in band_row_blocks' terms) holding at most 2048 entries
+      for (int bw : {1, 4, 7, 16, 32}) {
+        const int S = std::max(2, std::min(8, 1 + 32 / bw));
+        std::vector<int32_t> bb;
+        if (!band_row_blocks(rp.data(), nrows, bw, S, 2048, 256 + 2 * bw, 256, &bb)) continue;
+        EXPECT(bb.front() == 0 && bb.back() == nrows);
+        const int64_t H = (int64_t)(S - 1) * bw;
+        for (size_t k = 0; k + 1 < bb.size(); ++k) {
+          const int64_t r0 = bb[k], r1 = bb[k + 1];
+          EXPECT(r1 > r0);
+          const int64_t lo = std::max<int64_t>(0, r0 - H), hi = std::min<int64_t>(nrows, r1 + H);
+          EXPECT(hi - lo <= 256);                                    // one row of the tile per thread
+          EXPECT(rp[(size_t)hi] - rp[(size_t)lo] <= 2048);           // 8 entries per thread in registers
+        }
       }
       for (int bw : {1, 5, 32})
         for (int sweeps : {1, 4}) {
